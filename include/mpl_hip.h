@@ -1,0 +1,173 @@
+/*
+ * mpl_hip.h -- C ABI of libmpl_hip.so: the MI355X (gfx950) implementation of OpenMPL's
+ * multi-view pose-lifting forward pass.
+ *
+ * The reference has no FFI layer: its "operator API" for this path is the Python
+ * nn.Module contract of MPL/lib/models/multiview_mpl.py.  This
+ * header is the boundary a binding for that contract calls: plain pointers and sizes,
+ * no torch types.  All `const float*` below are DEVICE pointers to fp32 data in the
+ * reference's own parameter layouts (nn.Linear weight = [out][in] row-major, i.e. the
+ * tensors of the reference state_dict are consumed as they are -- nothing is re-packed,
+ * so an optimizer updating parameters in place never invalidates anything).
+ * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); every call only
+ * enqueues work on it and never synchronises.  Every function returns 0 on success or a
+ * negative MPL_E_* code (mpl_hip_error_string() explains it); nothing falls back to a CPU
+ * path.
+ *
+ * Reference interface each entry point replaces (file:line in /root/reference/MPL/lib/models/):
+ *   mpl_forward            MultiView_MPL.forward              multiview_mpl.py:450-525
+ *   mpl_spt_tokens         Spatial_forward_features + per-view glue   :349-414, :458-499
+ *   mpl_block_stack        the `for blk in self.blocks` loop of forward_features  :420-423
+ *                          (Block :84-92, Attention :53-67, Mlp :31-37)
+ *   mpl_ln_linear          nn.LayerNorm + nn.Linear (+GELU | +residual) pairs inside Block
+ *   mpl_token_attention    Attention.forward minus the two Linear layers   :55-64
+ *   mpl_fuse_head          forward_features tail :425-446 + default head :283-286,:521-523
+ */
+#ifndef MPL_HIP_H_
+#define MPL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPL_HIP_ABI_VERSION 1
+#define MPL_MAX_VIEWS 32
+#define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
+
+/* error codes */
+#define MPL_OK 0
+#define MPL_E_INVALID (-1)     /* bad argument / shape */
+#define MPL_E_UNSUPPORTED (-2) /* flag combination or size not implemented in HIP */
+#define MPL_E_WORKSPACE (-3)   /* workspace too small */
+#define MPL_E_LAUNCH (-4)      /* hip runtime reported an error at launch */
+
+/* flag bits of mpl_config.flags == constructor kwargs of MultiView_MPL (multiview_mpl.py:98-117) */
+#define MPL_F_MULTI_SPT (1u << 0)       /* multiple_spatial_blocks */
+#define MPL_F_CONF_ADD (1u << 1)        /* add_confidence_input */
+#define MPL_F_CONF_MULT (1u << 2)       /* mult_confidence_emb */
+#define MPL_F_CONF_ATTN_W (1u << 3)     /* confidence_as_attention_uncertainty_weight */
+#define MPL_F_POS3D_LEARN (1u << 4)     /* pose_3d_emb_learnable */
+#define MPL_F_POS3D_SPATIAL (1u << 5)   /* add_3D_pos_encoding_in_Spatial */
+#define MPL_F_RAYS_TOKEN (1u << 6)      /* input_rays_as_token */
+#define MPL_F_POS3D_TO_RAYS (1u << 7)   /* add_3D_pos_encoding_to_rays */
+#define MPL_F_NO_SPT (1u << 8)          /* no_transformer_spt */
+#define MPL_F_NO_FPT (1u << 9)          /* no_transformer_fpt */
+#define MPL_F_CONF_IN_FPT (1u << 10)    /* confidence_in_FPT */
+#define MPL_F_KPTOK (1u << 11)          /* FPT_blocks_view_keypoint_tokens */
+
+/* epilogues of mpl_ln_linear */
+#define MPL_EPI_BIAS 0          /* y = a W^T + b                       (attn.qkv) */
+#define MPL_EPI_BIAS_GELU 1     /* y = gelu_erf(a W^T + b)             (mlp.fc1 + nn.GELU) */
+#define MPL_EPI_BIAS_RESIDUAL 2 /* y = r + a W^T + b                   (attn.proj / mlp.fc2 + residual) */
+
+/* Parameters of one Block (multiview_mpl.py:70-92), device pointers, reference layouts:
+ * norm{1,2}.{weight,bias} (D); attn.qkv (3D,D),(3D); attn.proj (D,D),(D);
+ * mlp.fc1 (2D,D),(2D); mlp.fc2 (D,2D),(D). */
+typedef struct mpl_block_weights {
+    const float *ln1_w, *ln1_b;
+    const float *qkv_w, *qkv_b;
+    const float *proj_w, *proj_b;
+    const float *ln2_w, *ln2_b;
+    const float *fc1_w, *fc1_b;
+    const float *fc2_w, *fc2_b;
+} mpl_block_weights;
+
+/* Per-view (or shared) spatial parameter set, multiview_mpl.py:159-195, :236-249. */
+typedef struct mpl_spt_set {
+    const float *embed_w, *embed_b;  /* Spatial_patch_to_embedding[.v]  (d,in_chans),(d) */
+    const float *conf_w, *conf_b;    /* confidence_to_embedding[.v]     (d,1),(d) or NULL */
+    const float *pos_embed;          /* Spatial_pos_embed[.v]           (J,d) */
+    const mpl_block_weights *blocks; /* DEVICE array [depth]            Spatial_blocks[.v] */
+} mpl_spt_set;
+
+typedef struct mpl_config {
+    int32_t num_joints; /* NETWORK.NUM_JOINTS (17) */
+    int32_t dim;        /* NETWORK.DIM = embed_dim_ratio (32) */
+    int32_t depth;      /* NETWORK.TRANSFORMER_DEPTH */
+    int32_t heads;      /* NETWORK.TRANSFORMER_HEADS */
+    int32_t num_views;  /* V, a constructor constant (multiview_mpl.py:534-546) */
+    int32_t in_chans;   /* 2, or 3 with confidence_input_as_third (:159-168) */
+    uint32_t flags;     /* MPL_F_* */
+    int32_t reserved;
+} mpl_config;
+
+typedef struct mpl_weights {
+    const mpl_spt_set *spt_sets;       /* DEVICE array: [V] if MPL_F_MULTI_SPT else [1] */
+    const float *spatial_norm_w, *spatial_norm_b;          /* Spatial_norm (d) */
+    const float *pos_3d_embed;                             /* (J, d|2d) */
+    const float *pos_3d_view_coding;                       /* (J, d|2d) */
+    const float *pos_3d_linear_w, *pos_3d_linear_b;        /* (d|2d,3),(d|2d) */
+    const float *ray_embed_w, *ray_embed_b;                /* ray_to_embedding (d,3),(d) or NULL */
+    const float *conf_fpt_w, *conf_fpt_b;                  /* confidence_to_embedding_FPT (d,1),(d) or NULL */
+    const mpl_block_weights *fpt_blocks;                   /* HOST array [depth]: blocks.{l} */
+    const float *view_norm_w, *view_norm_b;                /* View_norm (J*d) */
+    const float *wmean_w, *wmean_b;                        /* weighted_mean Conv1d (1,V,1),(1) */
+    const float *head_ln_w, *head_ln_b;                    /* head.0 (J*d) */
+    const float *head_w, *head_b;                          /* head.1 (3J, J*d),(3J) */
+} mpl_weights;
+
+typedef struct mpl_inputs {
+    int32_t batch;
+    int32_t reserved;
+    const float *poses[MPL_MAX_VIEWS];   /* V x (B,J,3) contiguous: x_norm, y_norm, conf (function_mpl.py:350) */
+    const float *rays[MPL_MAX_VIEWS];    /* V x (B,J,3) or NULL when unused by the flags */
+    const float *centers[MPL_MAX_VIEWS]; /* V x (B,1,3) or NULL */
+} mpl_inputs;
+
+int mpl_hip_abi_version(void);
+const char *mpl_hip_error_string(int code);
+
+/* FPT token width D_f = J*d (x2 with MPL_F_RAYS_TOKEN), multiview_mpl.py:140-142. */
+int mpl_fpt_width(const mpl_config *cfg);
+
+/* Bytes of scratch mpl_forward needs for `batch` poses (activations only; 256-B aligned). */
+size_t mpl_forward_workspace_bytes(const mpl_config *cfg, int batch);
+
+/* Whole forward: V x (B,J,3) keypoints -> out (B,J,3).  MultiView_MPL.forward :450-525. */
+int mpl_forward(const mpl_config *cfg, const mpl_weights *w, const mpl_inputs *in, float *out,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Stage 1: embedding + SPT stack + Spatial_norm + per-view glue -> xs (B*V, D_f) row-major,
+ * row = b*V + v.  Spatial_forward_features :349-414 and forward :458-499. */
+int mpl_spt_tokens(const mpl_config *cfg, const mpl_weights *w, const mpl_inputs *in, float *xs, void *stream);
+
+/* Stage 2: a stack of Blocks applied in place on x (n_seq*n_tok, D).  `schedule[i]` = layer
+ * index of the i-th application (the reference applies the last layer twice, :420-423).
+ * `blocks` is a HOST array.  Workspace: mpl_block_stack_workspace_bytes(). */
+size_t mpl_block_stack_workspace_bytes(int n_seq, int n_tok, int dim);
+int mpl_block_stack(float *x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights *blocks,
+                    const uint8_t *schedule, int n_apps, void *workspace, size_t workspace_bytes, void *stream);
+
+/* y[M,N] = epilogue( LN(x)[M,K] . W[N,K]^T + bias ); ln_w == NULL skips the LayerNorm.
+ * `stats` is scratch for M*2 floats (row mean / rstd) when ln_w != NULL.  residual may alias y. */
+int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *ln_b, float eps, const float *W,
+                  const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
+                  void *stream);
+
+/* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
+int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);
+
+/* Stage 3: strip ray features, View_norm, Conv1d weighted mean over views, head LN + Linear.
+ * x (B*V, D_f) -> out (B, 3J).  forward_features :425-446, head :521-523. */
+int mpl_fuse_head(const mpl_config *cfg, const mpl_weights *w, const float *x, int batch, float *out, void *stream);
+
+/* Measurement aid (bench.py roofline leg): between start and stop every kernel launched by this
+ * library on ANY stream is bracketed by a hipEvent pair recorded on that same stream.  stop()
+ * synchronises the events and returns, per kernel kind, the summed device time (ms) and the launch
+ * count.  Process-global and not thread safe; never enabled on the product path. */
+#define MPL_K_SPT 0
+#define MPL_K_ROW_STATS 1
+#define MPL_K_GEMM 2
+#define MPL_K_ATTENTION 3
+#define MPL_K_FUSE_HEAD 4
+#define MPL_K_COUNT 5
+int mpl_profile_start(void);
+int mpl_profile_stop(float *kind_ms, int *kind_launches, int n_kinds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPL_HIP_H_ */

@@ -1,0 +1,149 @@
+"""ctypes binding of libmpl_hip.so (the C ABI declared in include/mpl_hip.h).
+
+This is the only place Python touches the native library.  There is no CPU or eager
+fallback: if the library cannot be loaded the import of the binding raises, and every
+non-zero return code becomes a ``RuntimeError`` (SURVEY.md section 8b "Error convention").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+MPL_MAX_VIEWS = 32
+MPL_MAX_APPS = 64
+ABI_VERSION = 1
+
+# flag bits (mpl_hip.h MPL_F_*)
+F_MULTI_SPT = 1 << 0
+F_CONF_ADD = 1 << 1
+F_CONF_MULT = 1 << 2
+F_CONF_ATTN_W = 1 << 3
+F_POS3D_LEARN = 1 << 4
+F_POS3D_SPATIAL = 1 << 5
+F_RAYS_TOKEN = 1 << 6
+F_POS3D_TO_RAYS = 1 << 7
+F_NO_SPT = 1 << 8
+F_NO_FPT = 1 << 9
+F_CONF_IN_FPT = 1 << 10
+F_KPTOK = 1 << 11
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+
+_fp = C.c_void_p  # device float* carried as an integer address
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                   "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class SptSet(C.Structure):
+    _fields_ = [("embed_w", _fp), ("embed_b", _fp), ("conf_w", _fp), ("conf_b", _fp),
+                ("pos_embed", _fp), ("blocks", _fp)]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_joints", C.c_int32), ("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32),
+                ("num_views", C.c_int32), ("in_chans", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("spt_sets", _fp),
+                ("spatial_norm_w", _fp), ("spatial_norm_b", _fp),
+                ("pos_3d_embed", _fp), ("pos_3d_view_coding", _fp),
+                ("pos_3d_linear_w", _fp), ("pos_3d_linear_b", _fp),
+                ("ray_embed_w", _fp), ("ray_embed_b", _fp),
+                ("conf_fpt_w", _fp), ("conf_fpt_b", _fp),
+                ("fpt_blocks", C.POINTER(BlockWeights)),
+                ("view_norm_w", _fp), ("view_norm_b", _fp),
+                ("wmean_w", _fp), ("wmean_b", _fp),
+                ("head_ln_w", _fp), ("head_ln_b", _fp),
+                ("head_w", _fp), ("head_b", _fp)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("reserved", C.c_int32),
+                ("poses", _fp * MPL_MAX_VIEWS), ("rays", _fp * MPL_MAX_VIEWS), ("centers", _fp * MPL_MAX_VIEWS)]
+
+
+EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
+           "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
+           "mpl_ln_linear", "mpl_token_attention", "mpl_fuse_head", "mpl_profile_start", "mpl_profile_stop")
+KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the .so is absent and hipcc exists).  Raises on any failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            _build.build()
+        lib = C.CDLL(path)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError("libmpl_hip.so does not export %s" % name)
+        lib.mpl_hip_abi_version.restype = C.c_int
+        if lib.mpl_hip_abi_version() != ABI_VERSION:
+            raise RuntimeError("libmpl_hip.so ABI %d != binding ABI %d (rebuild: python -m openmpl_amd.build --force)"
+                               % (lib.mpl_hip_abi_version(), ABI_VERSION))
+        lib.mpl_hip_error_string.restype = C.c_char_p
+        lib.mpl_hip_error_string.argtypes = [C.c_int]
+        lib.mpl_fpt_width.restype = C.c_int
+        lib.mpl_fpt_width.argtypes = [C.POINTER(Config)]
+        lib.mpl_forward_workspace_bytes.restype = C.c_size_t
+        lib.mpl_forward_workspace_bytes.argtypes = [C.POINTER(Config), C.c_int]
+        lib.mpl_forward.restype = C.c_int
+        lib.mpl_forward.argtypes = [C.POINTER(Config), C.POINTER(Weights), C.POINTER(Inputs), _fp, _fp, C.c_size_t, _fp]
+        lib.mpl_spt_tokens.restype = C.c_int
+        lib.mpl_spt_tokens.argtypes = [C.POINTER(Config), C.POINTER(Weights), C.POINTER(Inputs), _fp, _fp]
+        lib.mpl_block_stack_workspace_bytes.restype = C.c_size_t
+        lib.mpl_block_stack_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.mpl_block_stack.restype = C.c_int
+        lib.mpl_block_stack.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BlockWeights),
+                                        C.POINTER(C.c_uint8), C.c_int, _fp, C.c_size_t, _fp]
+        lib.mpl_ln_linear.restype = C.c_int
+        lib.mpl_ln_linear.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int, C.c_int, _fp,
+                                      _fp, _fp, _fp]
+        lib.mpl_token_attention.restype = C.c_int
+        lib.mpl_token_attention.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]
+        lib.mpl_fuse_head.restype = C.c_int
+        lib.mpl_fuse_head.argtypes = [C.POINTER(Config), C.POINTER(Weights), _fp, C.c_int, _fp, _fp]
+        lib.mpl_profile_start.restype = C.c_int
+        lib.mpl_profile_start.argtypes = []
+        lib.mpl_profile_stop.restype = C.c_int
+        lib.mpl_profile_stop.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
+        _lib = lib
+    return _lib
+
+
+def profile_start():
+    check(load().mpl_profile_start(), "mpl_profile_start")
+
+
+def profile_stop():
+    """-> {kind: (total_ms, launches)} for the launches since profile_start()."""
+    ms = (C.c_float * len(KINDS))()
+    n = (C.c_int * len(KINDS))()
+    check(load().mpl_profile_stop(ms, n, len(KINDS)), "mpl_profile_stop")
+    return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KINDS)}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mpl_hip_error_string(rc).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, rc))

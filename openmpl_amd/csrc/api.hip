@@ -1,0 +1,221 @@
+// C ABI of libmpl_hip.so (include/mpl_hip.h): argument validation + launch orchestration.
+// One mpl_forward call enqueues the whole forward on the caller's stream; nothing synchronises.
+#include "common.hpp"
+
+#include <vector>
+
+using namespace mpl;
+
+// ------------------------------------------------------------------ profiling aid (not thread safe)
+namespace {
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int kind;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+mpl::ProfScope::ProfScope(int kind, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.kind = kind;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+mpl::ProfScope::~ProfScope() {
+    if (slot >= 0) hipEventRecord(g_prof[slot].e1, stream);
+}
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct StackWs {
+    float *qkv, *att, *hid, *stats;
+    size_t bytes;
+};
+
+StackWs carve_stack_ws(void* base, size_t M, size_t D) {
+    StackWs w;
+    size_t off = 0;
+    auto take = [&](size_t n_floats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align_up(n_floats * sizeof(float), 256);
+        return p;
+    };
+    w.qkv = take(M * 3 * D);
+    w.att = take(M * D);
+    w.hid = take(M * 2 * D);
+    w.stats = take(M * 2);
+    w.bytes = off;
+    return w;
+}
+
+int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
+                     const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!x || n_seq <= 0 || n_tok <= 0 || D <= 0 || H <= 0 || n_apps < 0) return MPL_E_INVALID;
+    if (n_apps == 0) return MPL_OK;
+    if (!blocks || !schedule) return MPL_E_INVALID;
+    const int M = n_seq * n_tok;
+    const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
+    if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
+    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
+    int rc;
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
+        if ((rc = launch_row_stats(x, M, D, D, eps, w.stats, s))) return rc;
+        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M, 3 * D,
+                                 D, MPL_EPI_BIAS, s)))
+            return rc;
+        if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
+        if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
+                                 MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+        // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
+        if ((rc = launch_row_stats(x, M, D, D, eps, w.stats, s))) return rc;
+        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M, 2 * D,
+                                 D, MPL_EPI_BIAS_GELU, s)))
+            return rc;
+        if ((rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, b.fc2_w, b.fc2_b, x, D, x, D, M, D, 2 * D,
+                                 MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+    }
+    return MPL_OK;
+}
+
+int check_cfg(const mpl_config* cfg) {
+    if (!cfg) return MPL_E_INVALID;
+    if (cfg->num_views < 1 || cfg->num_views > MPL_MAX_VIEWS || cfg->depth < 0 || cfg->depth > 60) return MPL_E_INVALID;
+    if (cfg->flags & MPL_F_KPTOK) return MPL_E_UNSUPPORTED;  // SURVEY.md 8f rank f1, not built yet
+    return MPL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpl_profile_start(void) {
+    g_prof.clear();
+    g_prof_on = true;
+    return MPL_OK;
+}
+
+int mpl_profile_stop(float* kind_ms, int* kind_launches, int n_kinds) {
+    g_prof_on = false;
+    if (!kind_ms || !kind_launches || n_kinds < MPL_K_COUNT) return MPL_E_INVALID;
+    for (int k = 0; k < n_kinds; ++k) {
+        kind_ms[k] = 0.f;
+        kind_launches[k] = 0;
+    }
+    int rc = MPL_OK;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) rc = MPL_E_LAUNCH;
+        kind_ms[r.kind] += ms;
+        kind_launches[r.kind] += 1;
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return rc;
+}
+
+int mpl_hip_abi_version(void) { return MPL_HIP_ABI_VERSION; }
+
+const char* mpl_hip_error_string(int code) {
+    switch (code) {
+        case MPL_OK: return "ok";
+        case MPL_E_INVALID: return "invalid argument or shape";
+        case MPL_E_UNSUPPORTED: return "configuration not supported by the HIP path";
+        case MPL_E_WORKSPACE: return "workspace missing or too small";
+        case MPL_E_LAUNCH: return "HIP runtime error at kernel launch";
+        default: return "unknown error";
+    }
+}
+
+int mpl_fpt_width(const mpl_config* cfg) {
+    return cfg->num_joints * cfg->dim * ((cfg->flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
+}
+
+size_t mpl_block_stack_workspace_bytes(int n_seq, int n_tok, int dim) {
+    return carve_stack_ws(nullptr, (size_t)n_seq * n_tok, (size_t)dim).bytes;
+}
+
+size_t mpl_forward_workspace_bytes(const mpl_config* cfg, int batch) {
+    if (!cfg || batch <= 0) return 0;
+    const size_t M = (size_t)batch * cfg->num_views, D = (size_t)mpl_fpt_width(cfg);
+    return align_up(M * D * sizeof(float), 256) + carve_stack_ws(nullptr, M, D).bytes;
+}
+
+int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || !in || !xs) return MPL_E_INVALID;
+    return launch_spt(cfg, w, in, xs, (hipStream_t)stream);
+}
+
+int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
+                    const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, void* stream) {
+    return block_stack_impl(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const float* W,
+                  const float* bias, int N, int epilogue, const float* residual, float* y, float* stats,
+                  void* stream) {
+    if (!x || !W || !bias || !y) return MPL_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (ln_w) {
+        if (!stats) return MPL_E_INVALID;
+        int rc = launch_row_stats(x, M, K, K, eps, stats, s);
+        if (rc) return rc;
+    }
+    return launch_ln_gemm(x, K, stats, ln_w, ln_b, W, bias, residual, N, y, N, M, N, K, epilogue, s);
+}
+
+int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {
+    if (!qkv || !out) return MPL_E_INVALID;
+    return launch_token_attention(qkv, n_seq, n_tok, dim, heads, out, (hipStream_t)stream);
+}
+
+int mpl_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || !x || !out) return MPL_E_INVALID;
+    return launch_fuse_head(cfg, w, x, batch, out, (hipStream_t)stream);
+}
+
+int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* out, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || !in || !out || in->batch <= 0) return MPL_E_INVALID;
+    const size_t need = mpl_forward_workspace_bytes(cfg, in->batch);
+    if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = in->batch, V = cfg->num_views, D = mpl_fpt_width(cfg);
+    float* xs = reinterpret_cast<float*>(workspace);
+    char* rest = reinterpret_cast<char*>(workspace) + align_up((size_t)B * V * D * sizeof(float), 256);
+    const size_t rest_bytes = workspace_bytes - (size_t)(rest - reinterpret_cast<char*>(workspace));
+
+    if ((rc = launch_spt(cfg, w, in, xs, s))) return rc;
+
+    if (!(cfg->flags & MPL_F_NO_FPT) && cfg->depth > 0) {
+        // forward_features :420-423: the last block is applied twice
+        uint8_t sched[MPL_MAX_APPS];
+        int n = 0;
+        for (int l = 0; l < cfg->depth; ++l) {
+            if (n + 2 > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
+            if (l == cfg->depth - 1) sched[n++] = (uint8_t)l;
+            sched[n++] = (uint8_t)l;
+        }
+        if ((rc = block_stack_impl(xs, B, V, D, cfg->heads, w->fpt_blocks, sched, n, rest, rest_bytes, s))) return rc;
+    }
+    return launch_fuse_head(cfg, w, xs, B, out, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 kernels (wave64, fp32 MFMA 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpl_hip.h"
+
+namespace mpl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// D(16x16) += A(16x4) * B(4x16), exact fp32 (v_mfma_f32_16x16x4_f32, 32 cycles/SIMD).
+// Operand layout: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// result reg r of lane l is D[row = 4*(l>>4) + r][col = l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// K-permuted 16-deep step: lane (i, kq) holds a = X[i][kb + 4*kq + 0..3], b = W[j][kb + 4*kq + 0..3].
+// Step q contracts k = {kb + 4*kq' + q : kq' = 0..3}; the four steps cover kb..kb+15 exactly once.
+__device__ __forceinline__ f32x4 mfma16_k16(const float4& a, const float4& b, f32x4 c) {
+    c = mfma16(a.x, b.x, c);
+    c = mfma16(a.y, b.y, c);
+    c = mfma16(a.z, b.z, c);
+    c = mfma16(a.w, b.w, c);
+    return c;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact-erf GELU == torch.nn.GELU() default (multiview_mpl.py:22 act_layer=nn.GELU)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---- optional per-launch event bracketing (mpl_profile_start/stop) ----------------------------
+struct ProfScope {
+    ProfScope(int kind, hipStream_t s);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
+inline int hip_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MPL_OK : MPL_E_LAUNCH;
+}
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------
+int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* stats, hipStream_t s);
+int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
+                   const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi,
+                   hipStream_t s);
+int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
+int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
+int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out,
+                     hipStream_t s);
+
+}  // namespace mpl

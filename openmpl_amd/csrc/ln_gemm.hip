@@ -1,0 +1,248 @@
+// LayerNorm-fused fp32 MFMA GEMM for the FPT blocks:  C = epi( LN(A) . W^T + bias ).
+//
+// Reference ops replaced (MPL/lib/models/multiview_mpl.py): Block.norm1 + Attention.qkv (:55),
+// Attention.proj + residual (:65, :88-90), Block.norm2 + Mlp.fc1 + nn.GELU (:32-33),
+// Mlp.fc2 + residual (:35, :91).
+//
+// Shapes: A [M][K] row-major (M = B*V rows of the fusion transformer), W [N][K] row-major
+// (nn.Linear layout, consumed as stored), K, N in {544, 1088, 1632, 2176, 3264} = multiples of
+// 136 = 17*8.  Tile: 64 x 136 outputs per 256-thread workgroup -- at M = 4096 that is
+// 64 x {4, 8, 12} = 256 / 512 / 768 workgroups, an exact multiple of the 256 CUs for every GEMM of
+// a block.  Each of the 4 waves owns 16 rows x 9 MFMA tiles of 16 columns (the 9th tile is half
+// padding: 136 = 8.5 * 16).  BK = 32; LDS tiles are padded to a 36-float row so that the
+// ds_read_b128 fragment reads and ds_write_b128 staging writes stay (nearly) conflict free.
+// The k index inside a 16-deep step is permuted identically for A and B (common.hpp) so that each
+// lane fetches its four k values with ONE 128-bit LDS read.
+#include "common.hpp"
+
+namespace mpl {
+
+constexpr int BM = 64;
+constexpr int BN = 136;
+constexpr int BNP = 144;  // 9 MFMA column tiles
+constexpr int NT = 9;
+constexpr int BK = 32;
+constexpr int LDT = 36;  // LDS row stride in floats
+constexpr int B_F4 = BN * (BK / 4);  // 1088 float4 per B tile
+constexpr int B_IT = (B_F4 + 255) / 256;  // 5
+
+// ------------------------------------------------------------------------------------------
+// Row statistics for LayerNorm: stats[m] = {mean, rstd}; two-pass, one wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int M, int K, int ldx, float eps,
+                                                         float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int n4 = K >> 2;
+    float s = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        float4 v = ld4(xr + 4 * i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)K;
+    float ss = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        float4 v = ld4(xr + 4 * i);
+        float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        ss += (a * a + b * b) + (c * c + d * d);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = 1.0f / sqrtf(ss / (float)K + eps);
+    }
+}
+
+int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* stats, hipStream_t s) {
+    if (M <= 0 || (K & 3)) return MPL_E_INVALID;
+    ProfScope prof(MPL_K_ROW_STATS, s);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, K, ldx, eps, stats);
+    return hip_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool LN>
+__global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ ln_w,
+                                                          const float* __restrict__ ln_b,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          const float* R, int ldr, float* C, int ldc, int M, int N,
+                                                          int K, int grid_m, int grid_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BNP * LDT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int kq = lane >> 4;
+
+    // XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD (and its 4 MiB L2).  Give each XCD a
+    // contiguous band of m-tiles and let consecutive workgroups of the XCD sweep m first, so the A band
+    // (grid_m/8 * 64 rows) and the current W column tile stay L2 resident.
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        if ((grid_m & 7) == 0) {
+            const int per = grid_m >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            tm = xcd * per + (i % per);
+            tn = i / per;
+        } else {
+            tm = b % grid_m;
+            tn = b / grid_m;
+        }
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    // ---- staging assignment: A 64x32 floats = 512 float4 (2/thread), B 136x32 = 1088 float4 (<=5/thread)
+    const int c4 = tid & 7;       // float4 column inside the 32-wide k tile
+    const int rA0 = tid >> 3;     // rows rA0, rA0+32
+    const float* a_ptr[2];
+    float mu[2], rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + rA0 + 32 * i;
+        m = m < M ? m : M - 1;
+        a_ptr[i] = A + (size_t)m * lda + 4 * c4;
+        if (LN) {
+            mu[i] = stats[2 * m];
+            rs[i] = stats[2 * m + 1];
+        }
+    }
+    const float* b_ptr[B_IT];
+    bool b_on[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + 256 * i;
+        b_on[i] = idx < B_F4;
+        int n = n0 + (idx >> 3);
+        n = n < N ? n : N - 1;
+        b_ptr[i] = W + (size_t)n * K + 4 * c4;
+    }
+
+    // zero the 8 padding rows of both B buffers once (columns 136..143 are never stored)
+    for (int i = tid; i < 2 * 8 * LDT; i += 256) {
+        const int buf = i / (8 * LDT);
+        Bs[buf][BN * LDT + (i % (8 * LDT))] = 0.f;
+    }
+
+    float4 ra[2], rb[B_IT];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = ld4(a_ptr[i] + k0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (b_on[i]) rb[i] = ld4(b_ptr[i] + k0);
+        if (LN) {
+            const float4 g = ld4(ln_w + k0 + 4 * c4);
+            const float4 be = ld4(ln_b + k0 + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i].x = (ra[i].x - mu[i]) * rs[i] * g.x + be.x;
+                ra[i].y = (ra[i].y - mu[i]) * rs[i] * g.y + be.y;
+                ra[i].z = (ra[i].z - mu[i]) * rs[i] * g.z + be.z;
+                ra[i].w = (ra[i].w - mu[i]) * rs[i] * g.w + be.w;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) st4(&As[buf][(rA0 + 32 * i) * LDT + 4 * c4], ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (b_on[i]) st4(&Bs[buf][((tid + 256 * i) >> 3) * LDT + 4 * c4], rb[i]);
+    };
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* as = &As[buf][(wave * 16 + li) * LDT + 4 * kq];
+        const float* bs = &Bs[buf][li * LDT + 4 * kq];
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 16) {
+            const float4 a = ld4(as + kb);
+            float4 b[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + kb);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.x, b[n].x, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.y, b[n].y, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.z, b[n].z, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.w, b[n].w, acc[n]);
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = 4*kq + r][col = li] of each 16x16 tile
+    const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n0 + n * 16 + li;
+        if (col < n_end) {
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wave * 16 + 4 * kq + r;
+                if (row < M) {
+                    float v = acc[n][r] + bv;
+                    if (EPI == MPL_EPI_BIAS_GELU) v = gelu_erf(v);
+                    if (EPI == MPL_EPI_BIAS_RESIDUAL) v += R[(size_t)row * ldr + col];
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, bool LN>
+static int launch_cfg(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
+                      const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+                      int K, hipStream_t s) {
+    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL((ln_gemm_kernel<EPI, LN>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias, R,
+                       ldr, C, ldc, M, N, K, gm, gn);
+    return hip_check_launch();
+}
+
+int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
+                   const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi,
+                   hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda & 3)) return MPL_E_INVALID;
+    const bool ln = ln_w != nullptr;
+    if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
+    if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
+#define MPL_GEMM_CASE(E)                                                                                         \
+    case E:                                                                                                      \
+        return ln ? launch_cfg<E, true>(A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s)          \
+                  : launch_cfg<E, false>(A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s);
+    switch (epi) {
+        MPL_GEMM_CASE(MPL_EPI_BIAS)
+        MPL_GEMM_CASE(MPL_EPI_BIAS_GELU)
+        MPL_GEMM_CASE(MPL_EPI_BIAS_RESIDUAL)
+        default:
+            return MPL_E_INVALID;
+    }
+#undef MPL_GEMM_CASE
+}
+
+}  // namespace mpl

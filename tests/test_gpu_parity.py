@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the reference goldens.
+
+Tolerance (BASELINE.json north_star: "within 1e-4 relative fp32"), applied max-scaled AND norm-wise
+(SURVEY.md section 8c):   max|out-ref| <= 1e-4 * max|ref|   and   ||out-ref||_2 <= 1e-4 * ||ref||_2.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from openmpl_amd import cabi, detrng
+from openmpl_amd.multiview_mpl import MultiView_MPL
+from oracle import mpl_oracle
+from tests.golden.cases import CASES
+from tests.util import golden_inputs, golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _supported(flags):
+    m = MultiView_MPL(**flags)
+    return m._unsupported is None
+
+
+SUPPORTED = [c["name"] for c in CASES if _supported(c["flags"])]
+UNSUPPORTED = [c["name"] for c in CASES if not _supported(c["flags"])]
+
+
+def _model(name, g=None):
+    g = g or load_golden(name)
+    m = MultiView_MPL(**g["flags"])
+    m.load_state_dict(golden_state_dict(name, g), strict=True)
+    return m.to(DEV).eval(), g
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _assert_close(out, ref, what, tol=TOL):
+    mx, nw = mpl_oracle.rel_errors(out.detach().cpu(), ref.detach().cpu())
+    assert mx <= tol and nw <= tol, "%s: max-scaled %.3e norm-wise %.3e (tol %.0e)" % (what, mx, nw, tol)
+    return mx, nw
+
+
+# ----------------------------------------------------------------------------- stage level
+@pytest.mark.parametrize("M,K,N,epi,ln", [
+    (4096, 544, 1632, cabi.EPI_BIAS, True),
+    (200, 544, 1088, cabi.EPI_BIAS_GELU, True),
+    (77, 1088, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (4096, 544, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (130, 1088, 3264, cabi.EPI_BIAS, True),
+    (64, 2176, 1088, cabi.EPI_BIAS_RESIDUAL, False),
+    (3, 544, 544, cabi.EPI_BIAS, False),
+])
+def test_ln_linear_matches_torch(M, K, N, epi, ln):
+    lib = cabi.load()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(DEV)
+    W = (torch.rand(N, K, generator=g) * 2 - 1).mul_(K ** -0.5).to(DEV)     # asymmetric, not symmetric in (n,k)
+    b = torch.randn(N, generator=g).to(DEV)
+    lw = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    lb = (torch.randn(K, generator=g) * 0.1).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    stats = torch.empty(M * 2, device=DEV)
+    rc = lib.mpl_ln_linear(x.data_ptr(), M, K, lw.data_ptr() if ln else None, lb.data_ptr() if ln else None, 1e-6,
+                           W.data_ptr(), b.data_ptr(), N, epi, res.data_ptr() if epi == 2 else None, y.data_ptr(),
+                           stats.data_ptr(), _stream())
+    cabi.check(rc, "mpl_ln_linear")
+    xd, Wd = x.double().cpu(), W.double().cpu()
+    a = F.layer_norm(xd, (K,), lw.double().cpu(), lb.double().cpu(), 1e-6) if ln else xd
+    ref = a @ Wd.t() + b.double().cpu()
+    if epi == cabi.EPI_BIAS_GELU:
+        ref = F.gelu(ref)
+    if epi == cabi.EPI_BIAS_RESIDUAL:
+        ref = ref + res.double().cpu()
+    assert torch.isfinite(y).all()
+    _assert_close(y, ref, "ln_linear", tol=2e-6)
+
+
+def test_ln_linear_residual_in_place():
+    lib = cabi.load()
+    M, K, N = 256, 544, 544
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    x = torch.randn(M, N, generator=g).to(DEV)
+    ref = x.double().cpu() + a.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    rc = lib.mpl_ln_linear(a.data_ptr(), M, K, None, None, 0.0, W.data_ptr(), b.data_ptr(), N, 2, x.data_ptr(),
+                           x.data_ptr(), None, _stream())
+    cabi.check(rc, "mpl_ln_linear")
+    _assert_close(x, ref, "in-place residual", tol=2e-6)
+
+
+@pytest.mark.parametrize("n_tok,dim", [(2, 544), (4, 544), (4, 1088), (5, 544), (8, 1088), (31, 544), (17, 32)])
+def test_token_attention_matches_torch(n_tok, dim):
+    lib = cabi.load()
+    n_seq, H = 37, 8
+    g = torch.Generator().manual_seed(n_tok * 100 + dim)
+    qkv = torch.randn(n_seq * n_tok, 3 * dim, generator=g).to(DEV)
+    out = torch.full((n_seq * n_tok, dim), float("nan"), device=DEV)
+    cabi.check(lib.mpl_token_attention(qkv.data_ptr(), n_seq, n_tok, dim, H, out.data_ptr(), _stream()), "attention")
+    hd = dim // H
+    t = qkv.double().cpu().reshape(n_seq, n_tok, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = ((t[0] @ t[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (att @ t[2]).transpose(1, 2).reshape(n_seq * n_tok, dim)
+    _assert_close(out, ref, "token_attention", tol=2e-6)
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_spt_tokens_match_reference_tap(name):
+    """mpl_spt_tokens output == the (B,V,D_f) tensor the reference feeds forward_features (:495-499)."""
+    lib = cabi.load()
+    m, g = _model(name)
+    poses, rays, centers = golden_inputs(g, DEV)
+    dev, B, poses, rays, centers = m._check_inputs(poses, rays, centers)
+    ent = m._marshal(dev)
+    inp = cabi.Inputs()
+    inp.batch = B
+    for v in range(m.num_views):
+        inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
+    Df = lib.mpl_fpt_width(C.byref(ent["cfg"]))
+    xs = torch.full((B, m.num_views, Df), float("nan"), device=DEV)
+    cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(),
+                                  _stream()), "mpl_spt_tokens")
+    assert torch.isfinite(xs).all()
+    _assert_close(xs, torch.from_numpy(g["tap_fpt_in"]), "fpt_in", tol=2e-5)
+
+
+# ----------------------------------------------------------------------------- whole forward
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_forward_matches_reference_golden(name):
+    m, g = _model(name)
+    poses, rays, centers = golden_inputs(g, DEV)
+    with torch.no_grad():
+        out = m(poses, rays=rays, centers=centers)
+    assert out.shape == (g["meta"]["batch"], 17, 3) and out.dtype == torch.float32
+    ref = torch.from_numpy(g["out"])
+    mx, nw = _assert_close(out, ref, name)
+    print("%s: max-scaled %.2e norm-wise %.2e MPJPE-vs-ref %.3e" % (name, mx, nw, mpl_oracle.mpjpe(out.cpu(), ref)))
+
+
+@pytest.mark.parametrize("name", UNSUPPORTED)
+def test_unsupported_flags_raise_loudly(name):
+    g = load_golden(name)
+    m = MultiView_MPL(**g["flags"]).to(DEV).eval()
+    poses, rays, centers = golden_inputs(g, DEV)
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        m(poses, rays=rays, centers=centers)
+
+
+@pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 1024), ("full_v4_b8_l12", 256)])
+def test_full_size_batch_against_oracle(name, B):
+    """BASELINE.json configs[1] (V=4, J=17, batch 1024, fp32): HIP vs the oracle (fp32 CPU and fp64 CPU)."""
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    p, r, c = detrng.make_inputs(B, V, seed=2024)
+    P = [torch.from_numpy(x) for x in p]
+    R = [torch.from_numpy(x) for x in r]
+    Cn = [torch.from_numpy(x) for x in c]
+    with torch.no_grad():
+        out = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn]).cpu()
+    sd = golden_state_dict(name, g)
+    ref64 = mpl_oracle.forward(sd, g["flags"], P, R, Cn, dtype=torch.float64)
+    ref32 = mpl_oracle.forward(sd, g["flags"], P, R, Cn, dtype=torch.float32)
+    mx, nw = _assert_close(out, ref64, name + " vs fp64 oracle")
+    mx32, nw32 = mpl_oracle.rel_errors(ref32, ref64)
+    print("%s B=%d: HIP vs fp64 %.2e/%.2e ; CPU-fp32 oracle vs fp64 %.2e/%.2e ; MPJPE-vs-ref %.3e"
+          % (name, B, mx, nw, mx32, nw32, mpl_oracle.mpjpe(out, ref32)))
+    _assert_close(out, ref32, name + " vs fp32 oracle")
+
+
+# ----------------------------------------------------------------------------- size-independent properties
+def _big_inputs(B, V, seed):
+    p, r, c = detrng.make_inputs(B, V, seed=seed)
+    mk = lambda lst: [torch.from_numpy(x).to(DEV) for x in lst]
+    return mk(p), mk(r), mk(c)
+
+
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2"])
+def test_poses_are_independent_bitwise(name):
+    """Every pose is independent: permuting / splitting the batch must not change a bit."""
+    m, g = _model(name)
+    B, V = 1024, g["flags"]["num_views"]
+    P, R, Cn = _big_inputs(B, V, 99)
+    with torch.no_grad():
+        full = m(P, rays=R, centers=Cn)
+        again = m(P, rays=R, centers=Cn)
+        perm = torch.from_numpy(np.random.RandomState(0).permutation(B)).to(DEV)
+        shuf = m([x[perm].contiguous() for x in P], rays=[x[perm].contiguous() for x in R],
+                 centers=[x[perm].contiguous() for x in Cn])
+        lo = m([x[:300].contiguous() for x in P], rays=[x[:300].contiguous() for x in R],
+               centers=[x[:300].contiguous() for x in Cn])
+        hi = m([x[300:].contiguous() for x in P], rays=[x[300:].contiguous() for x in R],
+               centers=[x[300:].contiguous() for x in Cn])
+    assert torch.equal(full, again), "non-deterministic"
+    assert torch.equal(full[perm], shuf), "batch permutation changed results"
+    assert torch.equal(full, torch.cat([lo, hi], 0)), "batch split changed results"
+    assert torch.isfinite(full).all()
+
+
+def test_view_order_matters_only_through_weights():
+    """With shared SPT weights (CHOSEN) swapping two views == swapping the Conv1d view weights."""
+    m, g = _model("chosen_v4_b8_l2")
+    P, R, Cn = _big_inputs(64, 4, 5)
+    with torch.no_grad():
+        a = m(P, rays=R, centers=Cn)
+        b = m([P[1], P[0], P[2], P[3]], rays=R, centers=Cn)
+    assert not torch.allclose(a, b)   # FPT tokens are order dependent through the weighted mean
+
+
+def test_data_parallel_wrapper_and_g_module():
+    """The as-is valid_mpl.py path: DataParallel(model).cuda(), CPU inputs, kwargs centers/rays (function_mpl.py:350)."""
+    from tests.test_boundary_cpu import _cfg
+    from openmpl_amd.multiview_mpl import get_multiview_mpl_net
+    net = get_multiview_mpl_net(_cfg(TRANSFORMER_DEPTH=2), is_train=False)
+    detrng.fill_module_(net, seed=4)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    dp = torch.nn.DataParallel(net, device_ids=[0]).cuda().eval()
+    p, r, c = detrng.make_inputs(9, 2, seed=1)
+    P, R, Cn = ([torch.from_numpy(x) for x in lst] for lst in (p, r, c))
+    with torch.no_grad():
+        out = dp(P, centers=Cn, rays=R)
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=2, num_views=2, pose_3d_emb_learnable=True)
+    ref = mpl_oracle.forward(sd, flags, P, R, Cn)
+    _assert_close(out, ref, "DataParallel path")
+
+
+def test_gpu_input_validation():
+    m, g = _model("chosen_v4_b8_l2")
+    P, R, Cn = golden_inputs(g, DEV)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="float32"):
+            m([x.double() for x in P], rays=R, centers=Cn)
+        with pytest.raises(RuntimeError, match="shape"):
+            m([x[:, :16] for x in P], rays=R, centers=Cn)
+        with pytest.raises(RuntimeError, match="model is on"):
+            m([x.cpu() for x in P], rays=R, centers=Cn)
+        out = m([x.expand(2, *x.shape)[0] for x in P], rays=None, centers=None)   # rays unused by CHOSEN
+    assert torch.isfinite(out).all()

@@ -1,0 +1,100 @@
+"""Per-kernel timing at the BASELINE config-2 shapes (V=4, B=1024): prints ms and TFLOP/s per stage.
+
+    python tools/microbench.py [--flagset chosen|full] [--batch 1024] [--views 4] [--depth 12]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openmpl_amd import cabi, detrng  # noqa: E402
+from openmpl_amd.multiview_mpl import MultiView_MPL  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flagset", default="chosen")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=12)
+    a = ap.parse_args()
+    lib = cabi.load()
+    dev = "cuda:0"
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    D = 544 if a.flagset == "chosen" else 1088
+    M = a.batch * a.views
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, D, generator=g).to(dev)
+    stats = torch.empty(2 * M, device=dev)
+    lw, lb = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    print("M=%d D=%d" % (M, D))
+    tot = 0.0
+    for name, K, N, epi, ln in [("qkv", D, 3 * D, 0, True), ("proj", D, D, 2, False), ("fc1", D, 2 * D, 1, True),
+                                ("fc2", 2 * D, D, 2, False)]:
+        A = torch.randn(M, K, generator=g).to(dev)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        R = torch.randn(M, N, generator=g).to(dev)
+        Y = torch.empty(M, N, device=dev)
+        if ln:
+            lib.mpl_ln_linear(A.data_ptr(), M, K, lw.data_ptr(), lb.data_ptr(), 1e-6, W.data_ptr(), b.data_ptr(), N, epi,
+                              None, Y.data_ptr(), stats.data_ptr(), st())
+        # time the GEMM kernel alone: LN variant needs stats present; call the gemm through mpl_ln_linear w/o LN
+        fn_full = lambda: lib.mpl_ln_linear(A.data_ptr(), M, K, lw.data_ptr() if ln else None,
+                                            lb.data_ptr() if ln else None, 1e-6, W.data_ptr(), b.data_ptr(), N, epi,
+                                            R.data_ptr() if epi == 2 else None, Y.data_ptr(), stats.data_ptr(), st())
+        ms = timeit(fn_full)
+        fl = 2.0 * M * N * K
+        tot += ms
+        print("  %-5s M=%d N=%d K=%d %s: %.3f ms  %.1f TFLOP/s (incl. row_stats: %s)" % (name, M, N, K, "LN" if ln else "  ",
+                                                                                     ms, fl / ms / 1e9, ln))
+    qkv = torch.randn(M, 3 * D, generator=g).to(dev)
+    att = torch.empty(M, D, device=dev)
+    ms = timeit(lambda: lib.mpl_token_attention(qkv.data_ptr(), a.batch, a.views, D, 8, att.data_ptr(), st()))
+    print("  attention: %.3f ms (%.0f GB/s)" % (ms, (M * 4 * D * 4) / ms / 1e6))
+    tot += ms
+    print("  one FPT block (sum): %.3f ms -> x%d = %.3f ms" % (tot, a.depth + 1, tot * (a.depth + 1)))
+
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=a.depth, num_views=a.views,
+                 pose_3d_emb_learnable=True)
+    if a.flagset == "full":
+        flags.update(confidence_input_as_third=True, input_rays_as_token=True, multiple_spatial_blocks=True,
+                     add_3D_pos_encoding_to_rays=True)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=11)
+    m = m.to(dev).eval()
+    p, r, c = detrng.make_inputs(a.batch, a.views, seed=1)
+    P = [torch.from_numpy(t).to(dev) for t in p]
+    R_ = [torch.from_numpy(t).to(dev) for t in r]
+    Cn = [torch.from_numpy(t).to(dev) for t in c]
+    with torch.no_grad():
+        ms = timeit(lambda: m(P, rays=R_, centers=Cn), iters=10)
+        print("whole forward: %.3f ms -> %.0f poses/s" % (ms, a.batch / ms * 1e3))
+        cabi.profile_start()
+        for _ in range(5):
+            m(P, rays=R_, centers=Cn)
+        torch.cuda.synchronize()
+        prof = cabi.profile_stop()
+    for k, (t, n) in prof.items():
+        print("  %-10s %8.3f ms / forward  (%d launches/forward, %.1f us each)" % (k, t / 5, n // 5, 1e3 * t / max(n, 1)))
+    print("  sum of kernel time: %.3f ms / forward" % (sum(t for t, _ in prof.values()) / 5))
+
+
+if __name__ == "__main__":
+    main()
