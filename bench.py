@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X multi-view pose-lifting forward pass.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): poses/s at V=4, J=17, batch 1024 (per GPU), fp32, the paper's CHOSEN flag set
+(configs/h36m: NETWORK.DIM 32, depth 12, heads 8).  A "step" = one forward of one batch of 1024 synthetic
+poses that are already resident in HBM when the timed region starts; with N ranks every rank lifts its own
+1024 poses (weak scaling) and the per-shard (B,17,3) outputs are exchanged with ONE RCCL all-gather per
+step, the MI355X equivalent of the reference's DataParallel gather (valid_mpl.py:178).
+
+Rank 0 prints ONE JSON line: value = whole-job poses/s, plus
+  roofline     -- dominant kernel (ln_gemm_kernel, the fp32-MFMA GEMMs of the FPT blocks): algorithmic
+                  FLOPs per launch / mean launch duration measured live with HIP events on the launch stream
+                  (mpl_profile_start/stop) against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline -- the oracle (a port of the reference's CPU PyTorch path) timed on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+CHOSEN = dict(pose_3d_emb_learnable=True)
+FULL = dict(pose_3d_emb_learnable=True, confidence_input_as_third=True, input_rays_as_token=True,
+            multiple_spatial_blocks=True, add_3D_pos_encoding_to_rays=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="poses per GPU per step")
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--flagset", choices=("chosen", "full"), default="chosen")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary FULL-flag-set measurement")
+    return ap.parse_args()
+
+
+def build_model(flagset, views, depth, dev):
+    import torch
+    from openmpl_amd import detrng
+    from openmpl_amd.multiview_mpl import MultiView_MPL
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=depth, num_views=views)
+    flags.update(CHOSEN if flagset == "chosen" else FULL)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=11)          # random-init weights of the named architecture (no checkpoints offline)
+    return m.to(dev).eval(), flags
+
+
+def make_batch(batch, views, dev, seed, step=0):
+    import torch
+    from openmpl_amd import detrng
+    p, r, c = detrng.make_inputs(batch, views, seed=seed, step=step)
+    mk = lambda lst: [torch.from_numpy(x).to(dev) for x in lst]
+    return mk(p), mk(r), mk(c)
+
+
+def gemm_flops_per_forward(flags, batch):
+    """Algorithmic FLOPs of the ln_gemm launches of one forward: per FPT block 16*N*D^2 (= the four Linear
+    layers, 2*MAC) x (depth+1) applications (the 4*N^2*D attention term runs in another kernel)."""
+    D = 17 * 32 * (2 if flags.get("input_rays_as_token") else 1)
+    V = flags["num_views"]
+    apps = flags["depth"] + 1
+    return apps * 16.0 * V * D * D * batch, apps * 4
+
+
+def timed_steps(model, batches, steps, warmup, dist, gather_buf):
+    import torch
+    def step(i):
+        P, R, C = batches[i % len(batches)]
+        out = model(P, rays=R, centers=C)
+        if dist is not None:
+            dist.all_gather_into_tensor(gather_buf, out)
+        return out
+    with torch.no_grad():
+        for i in range(warmup):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist_mod.init_process_group("nccl", device_id=dev)   # backend "nccl" IS RCCL on ROCm
+        dist = dist_mod
+
+    model, flags = build_model(a.flagset, a.views, a.depth, dev)
+    # a few distinct resident batches so that no step can reuse a cached result
+    batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
+    gather_buf = torch.empty((world * a.batch, 17, 3), device=dev) if dist is not None else None
+
+    dt = timed_steps(model, batches, a.steps, a.warmup, dist, gather_buf)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * a.batch * a.steps / dt
+
+    result = None
+    if rank == 0:
+        from openmpl_amd import cabi
+        from oracle import mpl_oracle
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+        P, R, C = batches[0]
+        n_prof = 5
+        with torch.no_grad():
+            cabi.profile_start()
+            for _ in range(n_prof):
+                model(P, rays=R, centers=C)
+            torch.cuda.synchronize()
+            prof = cabi.profile_stop()
+        gemm_ms, gemm_n = prof["gemm"]
+        fl, launches = gemm_flops_per_forward(flags, a.batch)
+        assert gemm_n == launches * n_prof, (gemm_n, launches)
+        avg_launch_ms = gemm_ms / gemm_n
+        achieved = (fl / launches) / (avg_launch_ms * 1e-3) / 1e12
+        kernel_ms = {k: round(t / n_prof, 4) for k, (t, n) in prof.items()}
+        total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
+        io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
+        weight_bytes = sum(p.numel() for p in model.parameters()) * 4
+        roof = dict(bound="mfma", kernel="ln_gemm_kernel", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    avg_launch_us=round(avg_launch_ms * 1e3, 2), launches_per_step=launches,
+                    flops_per_launch=fl / launches,
+                    whole_forward_tflops=round(value / world * total_flop / 1e12, 2),
+                    whole_forward_frac=round(value / world * total_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    hbm_frac=round(value / world * (io_bytes + weight_bytes / a.batch) / 1e9 / PEAK_HBM_GBS, 5),
+                    kernel_ms_per_step=kernel_ms)
+
+        # ---- parity of this very run against the oracle (bounded: 64 poses)
+        nb = min(64, a.batch)
+        cp = [x[:nb].cpu() for x in P]; cr = [x[:nb].cpu() for x in R]; cc = [x[:nb].cpu() for x in C]
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            got = model([x[:nb].contiguous() for x in P], rays=[x[:nb].contiguous() for x in R],
+                        centers=[x[:nb].contiguous() for x in C]).cpu()
+        ref = mpl_oracle.forward(sd, flags, cp, cr, cc)
+        mx, nw = mpl_oracle.rel_errors(got, ref)
+        parity = dict(max_scaled=float("%.3e" % mx), norm_wise=float("%.3e" % nw),
+                      mpjpe_vs_ref=float("%.3e" % mpl_oracle.mpjpe(got, ref)), poses=nb, tol=1e-4)
+
+        # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
+        cpu = None
+        if not a.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            cb = min(a.batch, 1024)
+            cp = [x[:cb].cpu() for x in P]; cr = [x[:cb].cpu() for x in R]; cc = [x[:cb].cpu() for x in C]
+            mpl_oracle.forward(sd, flags, cp, cr, cc)      # warm-up
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+                mpl_oracle.forward(sd, flags, cp, cr, cc)
+                reps += 1
+            cdt = time.perf_counter() - t0
+            cpu = dict(value=round(cb * reps / cdt, 1), unit="poses/s", cores=cores, kind="port",
+                       sample="%d forwards of %d poses (V=%d, depth %d, fp32, torch %d threads), oracle/mpl_oracle.py"
+                              % (reps, cb, a.views, a.depth, cores))
+
+        extra = {}
+        if not a.no_extra and world == 1 and a.flagset == "chosen":
+            # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
+            m2, f2 = build_model("full", a.views, a.depth, dev)
+            dt2 = timed_steps(m2, batches, max(5, a.steps // 4), 3, None, None)
+            v2 = a.batch * max(5, a.steps // 4) / dt2
+            extra["full_flagset_poses_per_s"] = round(v2, 1)
+            extra["full_flagset_tflops"] = round(v2 * mpl_oracle.flop_count(f2) / 1e12, 2)
+            del m2
+
+        result = {
+            "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) fp32" % (a.views, a.batch),
+            "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Human3.6M config: V=%d J=17 batch=%d fp32, %s flag set, depth %d, DIM 32, heads 8"
+                                   % (a.views, a.batch, a.flagset.upper(), a.depth),
+                       "global_batch": world * a.batch, "parallelism": "dp%d (batch shards + 1 all_gather/step)" % world
+                       if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "extra": extra,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

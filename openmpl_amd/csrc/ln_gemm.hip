@@ -13,7 +13,13 @@
 // ds_read_b128 fragment reads and ds_write_b128 staging writes stay (nearly) conflict free.
 // The k index inside a 16-deep step is permuted identically for A and B (common.hpp) so that each
 // lane fetches its four k values with ONE 128-bit LDS read.
+#include <stdlib.h>
+
 #include "common.hpp"
+
+#ifndef MPL_GEMM_DEFAULT_VAR
+#define MPL_GEMM_DEFAULT_VAR 1
+#endif
 
 namespace mpl {
 
@@ -22,7 +28,7 @@ constexpr int BN = 136;
 constexpr int BNP = 144;  // 9 MFMA column tiles
 constexpr int NT = 9;
 constexpr int BK = 32;
-constexpr int LDT = 36;  // LDS row stride in floats
+constexpr int LDT_PAD = 36;  // padded LDS row stride in floats (VAR bit0 == 0)
 constexpr int B_F4 = BN * (BK / 4);  // 1088 float4 per B tile
 constexpr int B_IT = (B_F4 + 255) / 256;  // 5
 
@@ -63,16 +69,25 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* st
 }
 
 // ------------------------------------------------------------------------------------------
-template <int EPI, bool LN>
-__global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const float* __restrict__ A, int lda,
+// VAR bit0: XOR-swizzled unpadded LDS rows (conflict-free ds_read_b128) instead of 36-float padded rows
+// VAR bit1: register budget for 3 workgroups per CU instead of 2
+// ABL (bench-only ablations): 1 = no global loads inside the k loop, 2 = no MFMA
+template <int EPI, bool LN, int VAR, int ABL>
+__global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ ln_w,
                                                           const float* __restrict__ ln_b,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           const float* R, int ldr, float* C, int ldc, int M, int N,
                                                           int K, int grid_m, int grid_n) {
+    constexpr bool SWZ = (VAR & 1) != 0;
+    constexpr int LDT = SWZ ? BK : LDT_PAD;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BNP * LDT];
+    // 16-byte column c (0..7) of tile row r lives at physical column c ^ ((r >> 1) & 7) when swizzled:
+    // two 128-B rows share one 256-B bank row, so rows r and r^1 take the two halves and the 8 row pairs
+    // of a ds_read_b128 lane group are spread over the 8 16-B slots of each half.
+    auto col = [](int r, int c) -> int { return SWZ ? ((c ^ ((r >> 1) & 7)) << 2) : (c << 2); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const float* __restrict
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) st4(&As[buf][(rA0 + 32 * i) * LDT + 4 * c4], ra[i]);
+        for (int i = 0; i < 2; ++i) st4(&As[buf][(rA0 + 32 * i) * LDT + col(rA0 + 32 * i, c4)], ra[i]);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (b_on[i]) st4(&Bs[buf][((tid + 256 * i) >> 3) * LDT + 4 * c4], rb[i]);
+            if (b_on[i]) st4(&Bs[buf][((tid + 256 * i) >> 3) * LDT + col((tid + 256 * i) >> 3, c4)], rb[i]);
     };
 
     f32x4 acc[NT];
@@ -170,15 +185,25 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const float* __restrict
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const float* as = &As[buf][(wave * 16 + li) * LDT + 4 * kq];
-        const float* bs = &Bs[buf][li * LDT + 4 * kq];
+        if (kt + 1 < KT && ABL != 1) load_tile(kt + 1);
+        // rows wave*16+li and n*16+li all have (row >> 1) & 7 == (li >> 1) & 7
+        const float* as = &As[buf][(wave * 16 + li) * LDT];
+        const float* bs = &Bs[buf][li * LDT];
 #pragma unroll
         for (int kb = 0; kb < BK; kb += 16) {
-            const float4 a = ld4(as + kb);
+            const int cc = col(li, (kb >> 2) + kq);
+            const float4 a = ld4(as + cc);
             float4 b[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + kb);
+            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + cc);
+            if (ABL == 2) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[n][0] += a.x * b[n].x;
+                    acc[n][1] += a.y * b[n].y;
+                }
+                continue;
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.x, b[n].x, acc[n]);
 #pragma unroll
@@ -213,13 +238,13 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const float* __restrict
     }
 }
 
-template <int EPI, bool LN>
+template <int EPI, bool LN, int VAR, int ABL>
 static int launch_cfg(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
                       const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
                       int K, hipStream_t s) {
     const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_kernel<EPI, LN>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias, R,
+    hipLaunchKernelGGL((ln_gemm_kernel<EPI, LN, VAR, ABL>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias, R,
                        ldr, C, ldc, M, N, K, gm, gn);
     return hip_check_launch();
 }
@@ -231,10 +256,25 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
     const bool ln = ln_w != nullptr;
     if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-#define MPL_GEMM_CASE(E)                                                                                         \
-    case E:                                                                                                      \
-        return ln ? launch_cfg<E, true>(A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s)          \
-                  : launch_cfg<E, false>(A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s);
+    // bench-only knobs (tools/microbench.py): kernel variant and ablation
+    static const int var = getenv("MPL_GEMM_VAR") ? atoi(getenv("MPL_GEMM_VAR")) : MPL_GEMM_DEFAULT_VAR;
+    static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;
+#define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s
+    if (abl) {
+        if (abl == 1) return (var & 1) ? launch_cfg<0, false, 1, 1>(MPL_ARGS) : launch_cfg<0, false, 0, 1>(MPL_ARGS);
+        return (var & 1) ? launch_cfg<0, false, 1, 2>(MPL_ARGS) : launch_cfg<0, false, 0, 2>(MPL_ARGS);
+    }
+#define MPL_GEMM_VARS(E, L)                                            \
+    switch (var) {                                                     \
+        case 0: return launch_cfg<E, L, 0, 0>(MPL_ARGS);               \
+        case 1: return launch_cfg<E, L, 1, 0>(MPL_ARGS);               \
+        case 2: return launch_cfg<E, L, 2, 0>(MPL_ARGS);               \
+        default: return launch_cfg<E, L, 3, 0>(MPL_ARGS);              \
+    }
+#define MPL_GEMM_CASE(E)                 \
+    case E:                              \
+        if (ln) { MPL_GEMM_VARS(E, true) } \
+        else { MPL_GEMM_VARS(E, false) }
     switch (epi) {
         MPL_GEMM_CASE(MPL_EPI_BIAS)
         MPL_GEMM_CASE(MPL_EPI_BIAS_GELU)
@@ -242,6 +282,8 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
         default:
             return MPL_E_INVALID;
     }
+#undef MPL_GEMM_VARS
+#undef MPL_ARGS
 #undef MPL_GEMM_CASE
 }
 
