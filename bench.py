@@ -51,6 +51,24 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def build_model(flagset, views, depth, dev):
     import torch
     from openmpl_amd import detrng
@@ -81,11 +99,14 @@ def gemm_flops_per_forward(flags, batch):
 
 def timed_steps(model, batches, steps, warmup, dist, gather_buf):
     import torch
+    if dist is not None:
+        from openmpl_amd.dist import gather_outputs as _go
+        gather_outputs = lambda out, total: _go(out, total)
     def step(i):
         P, R, C = batches[i % len(batches)]
         out = model(P, rays=R, centers=C)
         if dist is not None:
-            dist.all_gather_into_tensor(gather_buf, out)
+            out = gather_outputs(out, gather_buf)      # ONE RCCL all-gather of the (B/G,17,3) shards
         return out
     with torch.no_grad():
         for i in range(warmup):
@@ -123,7 +144,7 @@ def main():
     model, flags = build_model(a.flagset, a.views, a.depth, dev)
     # a few distinct resident batches so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
-    gather_buf = torch.empty((world * a.batch, 17, 3), device=dev) if dist is not None else None
+    gather_buf = world * a.batch if dist is not None else None   # global batch size of the gathered result
 
     dt = timed_steps(model, batches, a.steps, a.warmup, dist, gather_buf)
     if dist is not None:
@@ -179,19 +200,19 @@ def main():
         # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
         cpu = None
         if not a.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            cores = effective_cpus()
             torch.set_num_threads(cores)
-            cb = min(a.batch, 1024)
+            cb = min(a.batch, 256)                     # bounded sample: batches of 256 poses of the same workload
             cp = [x[:cb].cpu() for x in P]; cr = [x[:cb].cpu() for x in R]; cc = [x[:cb].cpu() for x in C]
             mpl_oracle.forward(sd, flags, cp, cr, cc)      # warm-up
             reps, t0 = 0, time.perf_counter()
-            while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+            while time.perf_counter() - t0 < 12.0 and reps < 400:
                 mpl_oracle.forward(sd, flags, cp, cr, cc)
                 reps += 1
             cdt = time.perf_counter() - t0
             cpu = dict(value=round(cb * reps / cdt, 1), unit="poses/s", cores=cores, kind="port",
-                       sample="%d forwards of %d poses (V=%d, depth %d, fp32, torch %d threads), oracle/mpl_oracle.py"
-                              % (reps, cb, a.views, a.depth, cores))
+                       sample="%d forwards of %d poses in %.1f s (V=%d, depth %d, fp32, torch threads=%d = cgroup CPU "
+                              "quota of the box), oracle/mpl_oracle.py" % (reps, cb, cdt, a.views, a.depth, cores))
 
         extra = {}
         if not a.no_extra and world == 1 and a.flagset == "chosen":

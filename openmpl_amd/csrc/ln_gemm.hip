@@ -18,7 +18,7 @@
 #include "common.hpp"
 
 #ifndef MPL_GEMM_DEFAULT_VAR
-#define MPL_GEMM_DEFAULT_VAR 1
+#define MPL_GEMM_DEFAULT_VAR 4
 #endif
 
 namespace mpl {
@@ -68,10 +68,48 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* st
     return hip_check_launch();
 }
 
+// Epilogue shared by both GEMM kernels.  acc[n][r] = D[row0 + r][n0 + 16 n + li].  All loads (bias, residual)
+// are issued before the first store: vmcnt counts stores too, so a load queued behind stores would wait for
+// them to drain.
+template <int EPI>
+__device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], const float* __restrict__ bias,
+                                                    const float* R, int ldr, float* C, int ldc, int M, int N,
+                                                    int row0, int n0, int li) {
+    const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
+    float bv[NT];
+    float rv[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n0 + n * 16 + li;
+        const bool on = col < n_end;
+        bv[n] = on ? bias[col] : 0.f;
+        if (EPI == MPL_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[n][r] = (on && row0 + r < M) ? R[(size_t)(row0 + r) * ldr + col] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n0 + n * 16 + li;
+        if (col < n_end) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (row0 + r < M) {
+                    float v = acc[n][r] + bv[n];
+                    if (EPI == MPL_EPI_BIAS_GELU) v = gelu_erf(v);
+                    if (EPI == MPL_EPI_BIAS_RESIDUAL) v += rv[n][r];
+                    C[(size_t)(row0 + r) * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // VAR bit0: XOR-swizzled unpadded LDS rows (conflict-free ds_read_b128) instead of 36-float padded rows
 // VAR bit1: register budget for 3 workgroups per CU instead of 2
-// ABL (bench-only ablations): 1 = no global loads inside the k loop, 2 = no MFMA
+// ABL (bench-only ablation bit mask, results are garbage): 1 no global loads in the k loop, 2 no MFMA,
+// 4 no barrier, 8 no LDS staging writes, 16 no LDS fragment reads (loop-invariant operands)
 template <int EPI, bool LN, int VAR, int ABL>
 __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ stats,
@@ -178,6 +216,9 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const f
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float4 inv_a = {0.f, 0.f, 0.f, 0.f}, inv_b[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) inv_b[n] = inv_a;
     const int KT = K / BK;
     load_tile(0);
     store_tile(0);
@@ -185,18 +226,30 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const f
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT && ABL != 1) load_tile(kt + 1);
+        if (kt + 1 < KT && !(ABL & 1)) load_tile(kt + 1);
         // rows wave*16+li and n*16+li all have (row >> 1) & 7 == (li >> 1) & 7
         const float* as = &As[buf][(wave * 16 + li) * LDT];
         const float* bs = &Bs[buf][li * LDT];
 #pragma unroll
         for (int kb = 0; kb < BK; kb += 16) {
             const int cc = col(li, (kb >> 2) + kq);
-            const float4 a = ld4(as + cc);
+            float4 a;
             float4 b[NT];
+            if (!(ABL & 16) || kt == 0) {
+                a = ld4(as + cc);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + cc);
-            if (ABL == 2) {
+                for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + cc);
+                if (ABL & 16) {
+                    inv_a = a;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) inv_b[n] = b[n];
+                }
+            } else {
+                a = inv_a;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = inv_b[n];
+            }
+            if (ABL & 2) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     acc[n][0] += a.x * b[n].x;
@@ -213,29 +266,201 @@ __global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const f
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.w, b[n].w, acc[n]);
         }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < KT && !(ABL & 8)) store_tile(buf ^ 1);
+        if (!(ABL & 4)) __syncthreads();
     }
 
     // ---- epilogue: D[row = 4*kq + r][col = li] of each 16x16 tile
-    const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n0 + n * 16 + li;
-        if (col < n_end) {
-            const float bv = bias[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wave * 16 + 4 * kq + r;
-                if (row < M) {
-                    float v = acc[n][r] + bv;
-                    if (EPI == MPL_EPI_BIAS_GELU) v = gelu_erf(v);
-                    if (EPI == MPL_EPI_BIAS_RESIDUAL) v += R[(size_t)row * ldr + col];
-                    C[(size_t)row * ldc + col] = v;
-                }
-            }
+    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + wave * 16 + 4 * kq, n0, li);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// DMA-staged variant: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
+// ds_write), a 3-stage LDS ring keeps two k tiles in flight, one raw s_barrier per k tile, counted vmcnt.
+// Stage layout (26 KiB): A 64 rows x 128 B | B 136 rows x 128 B | 1 KiB piece holding gamma[32], beta[32]
+// of the k tile (its tail doubles as the 8 padding rows of B: finite data, columns never stored).
+// Rows are unpadded; the 16-B column c of row r sits at c ^ ((r >> 1) & 7).  A DMA piece is 1 KiB =
+// 8 rows; its LDS image is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
+// LayerNorm is applied when the A fragment is read (8 values per lane per k tile).
+constexpr int ST_A = 0;
+constexpr int ST_B = BM * BK * 4;                 // 8192
+constexpr int ST_GB = ST_B + BN * BK * 4;         // 25600
+constexpr int ST_BYTES = ST_GB + 1024;            // 26624
+constexpr int NSTAGE = 3;
+constexpr int NPIECE_LN = 26, NPIECE = 25;
+
+// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform).
+// Issued from inline asm on purpose: with the builtin hipcc assumes the LDS write may alias every later
+// ds_read and drains vmcnt(0) in front of it, which serialises the ring.  The asm DMA is invisible to the
+// compiler's counters; completion is tracked by the explicit counted s_waitcnt vmcnt below.  M0 is saved and
+// restored inside the same statement (the compiler does not preserve it around asm).
+__device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, bool LN>
+__global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* R, int ldr,
+                                                              float* C, int ldc, int M, int N, int K, int grid_m,
+                                                              int grid_n) {
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * ST_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int kq = lane >> 4;
+
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        if ((grid_m & 7) == 0) {
+            const int per = grid_m >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            tm = xcd * per + (i % per);
+            tn = i / per;
+        } else {
+            tm = b % grid_m;
+            tn = b / grid_m;
         }
     }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    float mu = 0.f, rs = 1.f;
+    if (LN) {
+        int m = m0 + wave * 16 + li;
+        m = m < M ? m : M - 1;
+        mu = stats[2 * m];
+        rs = stats[2 * m + 1];
+        // consume the two loads here: otherwise hipcc parks their s_waitcnt vmcnt(0) at the first use INSIDE
+        // the k loop, where it would drain the (compiler-invisible) DMA ring every iteration
+        asm volatile("" : "+v"(mu), "+v"(rs));
+    }
+
+    // ---- DMA piece assignment: piece p -> wave p & 3, slot p >> 2 (7 slots max)
+    constexpr int NP = LN ? NPIECE_LN : NPIECE;
+    const float* src[7];
+#pragma unroll
+    for (int sl = 0; sl < 7; ++sl) {
+        const int p = sl * 4 + wave;
+        const float* g;
+        if (p < 8) {
+            const int r = p * 8 + (lane >> 3);
+            int m = m0 + r;
+            m = m < M ? m : M - 1;
+            g = A + (size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        } else if (p < 25) {
+            const int r = (p - 8) * 8 + (lane >> 3);
+            int n = n0 + r;
+            n = n < N ? n : N - 1;
+            g = W + (size_t)n * K + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        } else {  // gamma | beta slice of this k tile (lanes >= 16 re-load the same 256 B: finite filler)
+            g = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);
+        }
+        src[sl] = g;
+    }
+    const int my_np = (NP - wave + 3) >> 2;  // pieces this wave issues per tile (wave-uniform): 7 or 6
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue_tile = [&](int kt) {
+        const unsigned st = lds0 + (unsigned)((kt % NSTAGE) * ST_BYTES);
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int sl = 0; sl < 7; ++sl) {
+            const int p = sl * 4 + wave;
+            if (p < NP) dma16(src[sl] + k0, st + (unsigned)(p * 1024));
+        }
+    };
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = K / BK;
+    issue_tile(0);
+    if (KT > 1) issue_tile(1);
+
+    const int swz = (li >> 1) & 7;
+    for (int kt = 0; kt < KT; ++kt) {
+        // my DMAs of tile kt have landed once at most the pieces of tile kt+1 are outstanding
+        if (kt + 1 < KT) {
+            if (my_np == 7) wait_vm<7>(); else wait_vm<6>();
+        } else {
+            wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < KT) issue_tile(kt + 2);
+
+        const char* st = smem + (kt % NSTAGE) * ST_BYTES;
+        const float* as = reinterpret_cast<const float*>(st + ST_A) + (wave * 16 + li) * BK;
+        const float* bs = reinterpret_cast<const float*>(st + ST_B) + li * BK;
+        const float* gb = reinterpret_cast<const float*>(st + ST_GB);
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 16) {
+            const int cl = (kb >> 2) + kq;           // logical 16-B column
+            const int cc = (cl ^ swz) << 2;
+            float4 a = ld4(as + cc);
+            float4 b[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * BK + cc);
+            if (LN) {
+                const float4 g = ld4(gb + 4 * cl), be = ld4(gb + 32 + 4 * cl);
+                a.x = (a.x - mu) * rs * g.x + be.x;
+                a.y = (a.y - mu) * rs * g.y + be.y;
+                a.z = (a.z - mu) * rs * g.z + be.z;
+                a.w = (a.w - mu) * rs * g.w + be.w;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.x, b[n].x, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.y, b[n].y, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.z, b[n].z, acc[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.w, b[n].w, acc[n]);
+        }
+    }
+
+    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + wave * 16 + 4 * kq, n0, li);
+}
+
+template <int EPI, bool LN>
+static int launch_dma(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
+                      const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+                      int K, hipStream_t s) {
+    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+    if (!attr_set[dev]) {
+        // 78 KiB of static LDS per workgroup: nothing to opt into, but keep the carve-out maximal
+        attr_set[dev] = true;
+    }
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL((ln_gemm_dma_kernel<EPI, LN>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias,
+                       R, ldr, C, ldc, M, N, K, gm, gn);
+    return hip_check_launch();
 }
 
 template <int EPI, bool LN, int VAR, int ABL>
@@ -261,11 +486,21 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
     static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;
 #define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s
     if (abl) {
-        if (abl == 1) return (var & 1) ? launch_cfg<0, false, 1, 1>(MPL_ARGS) : launch_cfg<0, false, 0, 1>(MPL_ARGS);
-        return (var & 1) ? launch_cfg<0, false, 1, 2>(MPL_ARGS) : launch_cfg<0, false, 0, 2>(MPL_ARGS);
+        switch (abl) {
+            case 1: return launch_cfg<0, false, 1, 1>(MPL_ARGS);
+            case 2: return launch_cfg<0, false, 1, 2>(MPL_ARGS);
+            case 9: return launch_cfg<0, false, 1, 9>(MPL_ARGS);
+            case 13: return launch_cfg<0, false, 1, 13>(MPL_ARGS);
+            case 29: return launch_cfg<0, false, 1, 29>(MPL_ARGS);
+            case 25: return launch_cfg<0, false, 1, 25>(MPL_ARGS);
+            case 17: return launch_cfg<0, false, 1, 17>(MPL_ARGS);
+            case 5: return launch_cfg<0, false, 1, 5>(MPL_ARGS);
+            default: return MPL_E_INVALID;
+        }
     }
 #define MPL_GEMM_VARS(E, L)                                            \
     switch (var) {                                                     \
+        case 4: return launch_dma<E, L>(MPL_ARGS);                     \
         case 0: return launch_cfg<E, L, 0, 0>(MPL_ARGS);               \
         case 1: return launch_cfg<E, L, 1, 0>(MPL_ARGS);               \
         case 2: return launch_cfg<E, L, 2, 0>(MPL_ARGS);               \

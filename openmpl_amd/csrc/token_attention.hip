@@ -6,6 +6,8 @@
 // Work per (sequence, head) is tiny (V^2 * hd MACs); the kernel is bound by reading the packed qkv
 // rows, so one thread owns one (query row, head), keeps its V scores in registers (static unroll,
 // VT = padded token count) and streams q/k/v as float4.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mpl {
@@ -73,6 +75,86 @@ __global__ __launch_bounds__(256) void token_attention_kernel(const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged version (the one used whenever a sequence's packed qkv rows fit in LDS): a workgroup copies
+// the qkv rows of SPW consecutive sequences into LDS with fully coalesced 16-byte loads (the kernel is
+// bound by that read: 3*D floats in, D floats out per token), then
+//   phase 1  one thread per (sequence, head, i, j): s_ij = scale * <q_i, k_j>        -> LDS
+//   phase 2  one thread per (sequence, head, i):    softmax over j, in place
+//   phase 3  one thread per output float4:          o_i = sum_j p_ij v_j             -> global, coalesced
+// Rows are padded by 4 floats (3*D is a multiple of 32 banks, so unpadded rows of different tokens alias).
+__global__ __launch_bounds__(256) void token_attention_lds_kernel(const float* __restrict__ qkv,
+                                                                   float* __restrict__ out, int n_seq, int n_tok,
+                                                                   int D, int H, float scale, int spw) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x;
+    const int seq0 = blockIdx.x * spw;
+    const int ns = (n_seq - seq0 < spw) ? (n_seq - seq0) : spw;
+    const int ld = 3 * D + 4;
+    const int hd = D / H, hd4 = hd >> 2;
+    const int rows = ns * n_tok;
+    float* sc = sm + (size_t)spw * n_tok * ld;  // [spw][H][n_tok][n_tok]
+
+    const int row4 = (3 * D) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(qkv + (size_t)seq0 * n_tok * 3 * D);
+    for (int i = tid; i < rows * row4; i += 256) {
+        const int r = i / row4, c = i - r * row4;
+        st4(sm + r * ld + 4 * c, g4[i]);
+    }
+    __syncthreads();
+
+    const int nn = n_tok * n_tok;
+    for (int t = tid; t < ns * H * nn; t += 256) {
+        const int j = t % n_tok, i = (t / n_tok) % n_tok, h = (t / nn) % H, s = t / (nn * H);
+        const float* q = sm + (s * n_tok + i) * ld + h * hd;
+        const float* k = sm + (s * n_tok + j) * ld + D + h * hd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int e = 0; e < hd4; ++e) {
+            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+            s0 = fmaf(a.x, b.x, s0);
+            s1 = fmaf(a.y, b.y, s1);
+            s2 = fmaf(a.z, b.z, s2);
+            s3 = fmaf(a.w, b.w, s3);
+        }
+        sc[t] = ((s0 + s1) + (s2 + s3)) * scale;
+    }
+    __syncthreads();
+    for (int t = tid; t < ns * H * n_tok; t += 256) {
+        float* p = sc + t * n_tok;
+        float mx = p[0];
+        for (int j = 1; j < n_tok; ++j) mx = fmaxf(mx, p[j]);
+        float l = 0.f;
+        for (int j = 0; j < n_tok; ++j) {
+            const float e = __expf(p[j] - mx);
+            p[j] = e;
+            l += e;
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < n_tok; ++j) p[j] *= inv;
+    }
+    __syncthreads();
+    const int d4 = D >> 2;
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)seq0 * n_tok * D);
+    for (int t = tid; t < rows * d4; t += 256) {
+        const int c = t % d4, r = t / d4;          // r = s*n_tok + i
+        const int h = (4 * c) / hd;
+        const int s = r / n_tok, i = r - s * n_tok;
+        const float* p = sc + ((s * H + h) * n_tok + i) * n_tok;
+        const float* v = sm + (s * n_tok) * ld + 2 * D + 4 * c;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < n_tok; ++j) {
+            const float4 vv = ld4(v + j * ld);
+            const float pj = p[j];
+            acc.x = fmaf(pj, vv.x, acc.x);
+            acc.y = fmaf(pj, vv.y, acc.y);
+            acc.z = fmaf(pj, vv.z, acc.z);
+            acc.w = fmaf(pj, vv.w, acc.w);
+        }
+        o4[t] = acc;
+    }
+}
+
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s) {
     if (n_seq <= 0 || n_tok <= 0 || heads <= 0 || dim % heads) return MPL_E_INVALID;
     const int hd = dim / heads;
@@ -81,6 +163,30 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
     const float scale = 1.0f / sqrtf((float)hd);
     const int total = n_seq * n_tok * heads;
     ProfScope prof(MPL_K_ATTENTION, s);
+    {
+        const size_t seq_bytes = (size_t)n_tok * (3 * dim + 4) * 4 + (size_t)heads * n_tok * n_tok * 4;
+        static const bool force_v1 = getenv("MPL_ATT_V1") != nullptr;   // bench-only A/B switch
+        if (seq_bytes <= 150 * 1024 && !force_v1) {
+            int spw = (int)((56 * 1024) / seq_bytes);
+            if (spw < 1) spw = 1;
+            if (spw > 8) spw = 8;
+            const size_t lds = spw * seq_bytes;
+            if (lds > 64 * 1024) {
+                static bool attr_set[64] = {};
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+                if (!attr_set[dev]) {
+                    if (hipFuncSetAttribute((const void*)token_attention_lds_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                        return MPL_E_LAUNCH;
+                    attr_set[dev] = true;
+                }
+            }
+            hipLaunchKernelGGL(token_attention_lds_kernel, dim3((n_seq + spw - 1) / spw), dim3(256), lds, s, qkv, out,
+                               n_seq, n_tok, dim, heads, scale, spw);
+            return hip_check_launch();
+        }
+    }
     const dim3 grid((total + 255) / 256), block(256);
 #define MPL_ATT(VT) hipLaunchKernelGGL((token_attention_kernel<VT>), grid, block, 0, s, qkv, out, n_seq, n_tok, dim, heads, scale)
     if (n_tok <= 2) MPL_ATT(2);

@@ -1,0 +1,83 @@
+"""World-size-2 gloo tests (CPU) of the batch-sharded multi-GPU path: partitioning + the single all-gather.
+
+The model callable here is the ORACLE (test infrastructure) -- the HIP forward cannot run without a GPU; what
+is under test is openmpl_amd/dist.py, which is device agnostic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from openmpl_amd import detrng
+from openmpl_amd.dist import ShardedLifter, gather_outputs, shard_range
+from oracle import mpl_oracle
+
+
+def test_shard_range_is_a_contiguous_balanced_partition():
+    for batch in (0, 1, 2, 7, 8, 1023, 1024, 8192):
+        for world in (1, 2, 3, 4, 8):
+            r = [shard_range(batch, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == batch
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+FLAGS = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=1, num_views=2, pose_3d_emb_learnable=True)
+
+
+def _worker(rank, world, port, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    shapes = mpl_oracle.param_shapes(FLAGS)
+    sd = {k: torch.from_numpy(v) for k, v in detrng.make_state_dict(shapes, seed=3).items()}
+    p, r, c = detrng.make_inputs(batch, 2, seed=9)
+    P, R, C = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    model = lambda poses, rays=None, centers=None: mpl_oracle.forward(sd, FLAGS, poses, rays, centers)
+    out = ShardedLifter(model)(P, rays=R, centers=C)
+    lo, hi = shard_range(batch, world, rank)
+    # explicit gather of a rank-tagged tensor checks ordering independently of the model
+    tag = torch.full((hi - lo, 17, 3), float(rank)) + torch.arange(lo, hi).reshape(-1, 1, 1)
+    g = gather_outputs(tag, batch)
+    if rank == 0:
+        full = mpl_oracle.forward(sd, FLAGS, P, R, C)
+        # CPU GEMM blocking depends on the batch size, so compare to rounding, not bitwise
+        q.put((max(mpl_oracle.rel_errors(out, full)) < 1e-6 and out.shape == full.shape, g[:, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [8, 7])
+def test_sharded_lifter_world2_gloo(batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, tags = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same, "sharded result differs from the single-process result"
+    want = []
+    for r in range(world):
+        lo, hi = shard_range(batch, world, r)
+        want += [float(r + i) for i in range(lo, hi)]
+    assert tags == want
