@@ -142,7 +142,8 @@ int mpl_block_stack(float *x, int n_seq, int n_tok, int dim, int heads, const mp
                     const uint8_t *schedule, int n_apps, void *workspace, size_t workspace_bytes, void *stream);
 
 /* y[M,N] = epilogue( LN(x)[M,K] . W[N,K]^T + bias ); ln_w == NULL skips the LayerNorm.
- * `stats` is scratch for M*2 floats (row mean / rstd) when ln_w != NULL.  residual may alias y. */
+ * `stats` is scratch for 2*M*max(1, K/136) floats (per-slice LayerNorm partials) when ln_w != NULL.
+ * residual may alias y. */
 int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *ln_b, float eps, const float *W,
                   const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
                   void *stream);

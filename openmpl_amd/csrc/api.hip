@@ -49,7 +49,7 @@ StackWs carve_stack_ws(void* base, size_t M, size_t D) {
     w.qkv = take(M * 3 * D);
     w.att = take(M * D);
     w.hid = take(M * 2 * D);
-    w.stats = take(M * 2);
+    w.stats = take(M * 2 * (size_t)ln_stat_slices((int)D));
     w.bytes = off;
     return w;
 }
@@ -64,25 +64,30 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     int rc;
+    // LayerNorm statistics are produced by whoever writes x: a stand-alone pass for the incoming x, then the
+    // epilogues of proj (-> norm2) and fc2 (-> norm1 of the next application).
+    float* st_out = (D % 136 == 0) ? w.stats : nullptr;
+    bool have_stats = false;
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
-        if ((rc = launch_row_stats(x, M, D, D, eps, w.stats, s))) return rc;
-        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M, 3 * D,
-                                 D, MPL_EPI_BIAS, s)))
+        if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
+        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
+                                 3 * D, D, MPL_EPI_BIAS, nullptr, s)))
             return rc;
         if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
-        if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
-                                 MPL_EPI_BIAS_RESIDUAL, s)))
+        if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
+                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)))
             return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
-        if ((rc = launch_row_stats(x, M, D, D, eps, w.stats, s))) return rc;
-        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M, 2 * D,
-                                 D, MPL_EPI_BIAS_GELU, s)))
+        if (!st_out && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
+        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
+                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s)))
             return rc;
-        if ((rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, b.fc2_w, b.fc2_b, x, D, x, D, M, D, 2 * D,
-                                 MPL_EPI_BIAS_RESIDUAL, s)))
+        if ((rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
+                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s)))
             return rc;
+        have_stats = st_out != nullptr;
     }
     return MPL_OK;
 }
@@ -171,10 +176,10 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (ln_w) {
         if (!stats) return MPL_E_INVALID;
-        int rc = launch_row_stats(x, M, K, K, eps, stats, s);
+        int rc = launch_row_stats(x, M, K, K, stats, s);
         if (rc) return rc;
     }
-    return launch_ln_gemm(x, K, stats, ln_w, ln_b, W, bias, residual, N, y, N, M, N, K, epilogue, s);
+    return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue, nullptr, s);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {

@@ -54,10 +54,14 @@ inline int hip_check_launch() {
 }
 
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
-int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* stats, hipStream_t s);
-int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
-                   const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi,
-                   hipStream_t s);
+// LayerNorm statistics buffer: 2 * M * ln_stat_slices(K) floats (per-slice {mean, M2}, see ln_gemm.hip)
+inline int ln_stat_slices(int K) { return (K % 136 == 0) ? K / 136 : 1; }
+int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStream_t s);
+// stats_out (optional, residual epilogue only, N % 136 == 0): the epilogue also emits the LayerNorm partials of
+// the rows it produced, so the next LN-GEMM needs no statistics pass.
+int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
+                   const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
+                   int epi, float* stats_out, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out,

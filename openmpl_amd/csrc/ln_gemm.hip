@@ -17,9 +17,6 @@
 
 #include "common.hpp"
 
-#ifndef MPL_GEMM_DEFAULT_VAR
-#define MPL_GEMM_DEFAULT_VAR 4
-#endif
 
 namespace mpl {
 
@@ -28,43 +25,64 @@ constexpr int BN = 136;
 constexpr int BNP = 144;  // 9 MFMA column tiles
 constexpr int NT = 9;
 constexpr int BK = 32;
-constexpr int LDT_PAD = 36;  // padded LDS row stride in floats (VAR bit0 == 0)
-constexpr int B_F4 = BN * (BK / 4);  // 1088 float4 per B tile
-constexpr int B_IT = (B_F4 + 255) / 256;  // 5
 
 // ------------------------------------------------------------------------------------------
-// Row statistics for LayerNorm: stats[m] = {mean, rstd}; two-pass, one wave per row.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int M, int K, int ldx, float eps,
+// LayerNorm statistics travel as per-slice partials so that the GEMMs that PRODUCE a row tile by tile can emit
+// them from their epilogue (no extra pass over x, no atomics):  stats[(m * NS + s) * 2 + {0,1}] = {mean_s, M2_s}
+// of columns [s*SL, (s+1)*SL) of row m, SL = 136 when K is a multiple of 136 (the GEMM column-tile width), else
+// K (one slice).  The consumer combines them with Chan's parallel formula:
+//   mean = avg_s(mean_s),  M2 = sum_s M2_s + SL * sum_s (mean_s - mean)^2,  rstd = 1/sqrt(M2 / K + eps).
+// Two-pass inside a slice + exact combination across slices: no E[x^2]-E[x]^2 cancellation anywhere.
+inline int ln_slice_len(int K) { return (K % BN == 0) ? BN : K; }
+
+__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, int sl, int K, float eps, float& mu,
+                                           float& rs) {
+    float msum = 0.f;
+    for (int i = 0; i < ns; ++i) msum += st[2 * i];
+    const float mean = msum / (float)ns;
+    float m2 = 0.f;
+    for (int i = 0; i < ns; ++i) {
+        const float d = st[2 * i] - mean;
+        m2 += st[2 * i + 1] + (float)sl * d * d;
+    }
+    mu = mean;
+    rs = 1.0f / sqrtf(m2 / (float)K + eps);
+}
+
+// one wave per row; used for rows that no GEMM epilogue produced (the SPT output, stand-alone mpl_ln_linear)
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int M, int K, int ldx, int sl,
                                                          float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (size_t)row * ldx;
-    const int n4 = K >> 2;
-    float s = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-        float4 v = ld4(xr + 4 * i);
-        s += (v.x + v.y) + (v.z + v.w);
-    }
-    s = wave_sum(s);
-    const float mean = s / (float)K;
-    float ss = 0.f;
-    for (int i = lane; i < n4; i += 64) {
-        float4 v = ld4(xr + 4 * i);
-        float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        ss += (a * a + b * b) + (c * c + d * d);
-    }
-    ss = wave_sum(ss);
-    if (lane == 0) {
-        stats[2 * row] = mean;
-        stats[2 * row + 1] = 1.0f / sqrtf(ss / (float)K + eps);
+    const int ns = K / sl, n4 = sl >> 2;
+    for (int sidx = 0; sidx < ns; ++sidx) {
+        const float* xr = x + (size_t)row * ldx + sidx * sl;
+        float s = 0.f;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = ld4(xr + 4 * i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        s = wave_sum(s);
+        const float mean = s / (float)sl;
+        float ss = 0.f;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = ld4(xr + 4 * i);
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            ss += (a * a + b * b) + (c * c + d * d);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            stats[((size_t)row * ns + sidx) * 2] = mean;
+            stats[((size_t)row * ns + sidx) * 2 + 1] = ss;
+        }
     }
 }
 
-int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* stats, hipStream_t s) {
+int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStream_t s) {
     if (M <= 0 || (K & 3)) return MPL_E_INVALID;
     ProfScope prof(MPL_K_ROW_STATS, s);
-    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, K, ldx, eps, stats);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, K, ldx, ln_slice_len(K), stats);
     return hip_check_launch();
 }
 
@@ -74,7 +92,7 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float eps, float* st
 template <int EPI>
 __device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], const float* __restrict__ bias,
                                                     const float* R, int ldr, float* C, int ldc, int M, int N,
-                                                    int row0, int n0, int li) {
+                                                    int row0, int n0, int li, float* stats_out, int stats_ns) {
     const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
     float bv[NT];
     float rv[NT][4];
@@ -88,213 +106,83 @@ __device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], cons
             for (int r = 0; r < 4; ++r) rv[n][r] = (on && row0 + r < M) ? R[(size_t)(row0 + r) * ldr + col] : 0.f;
         }
     }
+    float v[NT][4];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n0 + n * 16 + li;
-        if (col < n_end) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (row0 + r < M) {
-                    float v = acc[n][r] + bv[n];
-                    if (EPI == MPL_EPI_BIAS_GELU) v = gelu_erf(v);
-                    if (EPI == MPL_EPI_BIAS_RESIDUAL) v += rv[n][r];
-                    C[(size_t)(row0 + r) * ldc + col] = v;
-                }
+        for (int r = 0; r < 4; ++r) {
+            float t = acc[n][r] + bv[n];
+            if (EPI == MPL_EPI_BIAS_GELU) t = gelu_erf(t);
+            if (EPI == MPL_EPI_BIAS_RESIDUAL) t += rv[n][r];
+            v[n][r] = t;
+            if (col < n_end && row0 + r < M) C[(size_t)(row0 + r) * ldc + col] = t;
+        }
+    }
+    if (EPI == MPL_EPI_BIAS_RESIDUAL && stats_out) {
+        // LayerNorm partials of this 136-column slice for the rows of this wave (the tile is a full slice:
+        // the host only passes stats_out when N is a multiple of 136).  A row's 136 values sit in the 16 lanes
+        // of one kq group (8 full column tiles + lanes li < 8 of the 9th).
+        const bool tail = li < 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = tail ? v[8][r] : 0.f;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) s += v[n][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * (1.0f / (float)BN);
+            float q = 0.f;
+            if (tail) {
+                const float d = v[8][r] - mean;
+                q = d * d;
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const float d = v[n][r] - mean;
+                q = fmaf(d, d, q);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+            if (li == 0 && row0 + r < M) {
+                float* so = stats_out + ((size_t)(row0 + r) * stats_ns + n0 / BN) * 2;
+                so[0] = mean;
+                so[1] = q;
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// VAR bit0: XOR-swizzled unpadded LDS rows (conflict-free ds_read_b128) instead of 36-float padded rows
-// VAR bit1: register budget for 3 workgroups per CU instead of 2
-// ABL (bench-only ablation bit mask, results are garbage): 1 no global loads in the k loop, 2 no MFMA,
-// 4 no barrier, 8 no LDS staging writes, 16 no LDS fragment reads (loop-invariant operands)
-template <int EPI, bool LN, int VAR, int ABL>
-__global__ __launch_bounds__(256, (VAR & 2) ? 3 : 2) void ln_gemm_kernel(const float* __restrict__ A, int lda,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ ln_w,
-                                                          const float* __restrict__ ln_b,
-                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                          const float* R, int ldr, float* C, int ldc, int M, int N,
-                                                          int K, int grid_m, int grid_n) {
-    constexpr bool SWZ = (VAR & 1) != 0;
-    constexpr int LDT = SWZ ? BK : LDT_PAD;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BNP * LDT];
-    // 16-byte column c (0..7) of tile row r lives at physical column c ^ ((r >> 1) & 7) when swizzled:
-    // two 128-B rows share one 256-B bank row, so rows r and r^1 take the two halves and the 8 row pairs
-    // of a ds_read_b128 lane group are spread over the 8 16-B slots of each half.
-    auto col = [](int r, int c) -> int { return SWZ ? ((c ^ ((r >> 1) & 7)) << 2) : (c << 2); };
+// DMA-staged, multi-group kernel (the product path).
+//
+// Workgroup = 64 rows x (NG x 136) columns, 4*NG waves: wave w owns row group w & 3 (16 rows) of column
+// group w >> 2 (136 columns = 9 MFMA tiles, the 9th half padding).  The A k-tile is staged once and shared by
+// the NG column groups, so ONE workgroup per CU has NG waves per SIMD and every barrier interval carries
+// NG x KS x 72 MFMAs per SIMD: the per-k-tile bubble (barrier, DMA issue, first fragment read) is amortised
+// over 2-3x more matrix work than with one 4-wave workgroup per tile, and at M = 4096 every GEMM of a block is
+// exactly 256 workgroups: QKV (N = 3 D) NG = 3, fc1 (N = 2 D) NG = 2, proj / fc2 (N = D) NG = 1 with KS = 2
+// k-tiles per stage.
+//
+// Staging: k-tiles go L2/HBM -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write) into a ring of
+// NST stages; one raw s_barrier and one counted s_waitcnt vmcnt per stage.  Sub-stage layout (per k-tile of 32):
+//   A 64 rows x 128 B | B group 0: 136 rows x 128 B | ... | B group NG-1 | 1 KiB: gamma[32] beta[32] of the tile
+// (the 8 padding rows 136..143 of a B group alias the next region: finite data, results never stored).
+// Rows are unpadded; the 16-B column c of row r sits at c ^ ((r >> 1) & 7) -- applied to the per-lane DMA
+// SOURCE address (the LDS image of a DMA piece is lane-linear) and to the fragment read (bank conflicts: 0).
+// The DMA is issued from inline asm: with the builtin hipcc assumes the LDS write aliases every later ds_read
+// and drains vmcnt(0) in front of it; the asm DMA is invisible to the compiler's counters and is tracked by the
+// explicit counted waits.  LayerNorm is applied when the A fragment is read.
+constexpr int SUB_A = BM * BK * 4;   // 8192 bytes
+constexpr int SUB_B = BN * BK * 4;   // 17408 bytes per column group
+template <int NG> struct SubStage {
+    static constexpr int GB = SUB_A + NG * SUB_B;       // gamma/beta piece offset
+    static constexpr int BYTES = GB + 1024;
+    static constexpr int PIECES = 8 + 17 * NG + 1;      // incl. the gamma/beta piece
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int li = lane & 15;
-    const int kq = lane >> 4;
-
-    // XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD (and its 4 MiB L2).  Give each XCD a
-    // contiguous band of m-tiles and let consecutive workgroups of the XCD sweep m first, so the A band
-    // (grid_m/8 * 64 rows) and the current W column tile stay L2 resident.
-    int tm, tn;
-    {
-        const int b = blockIdx.x;
-        if ((grid_m & 7) == 0) {
-            const int per = grid_m >> 3;
-            const int xcd = b & 7, i = b >> 3;
-            tm = xcd * per + (i % per);
-            tn = i / per;
-        } else {
-            tm = b % grid_m;
-            tn = b / grid_m;
-        }
-    }
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
-
-    // ---- staging assignment: A 64x32 floats = 512 float4 (2/thread), B 136x32 = 1088 float4 (<=5/thread)
-    const int c4 = tid & 7;       // float4 column inside the 32-wide k tile
-    const int rA0 = tid >> 3;     // rows rA0, rA0+32
-    const float* a_ptr[2];
-    float mu[2], rs[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = m0 + rA0 + 32 * i;
-        m = m < M ? m : M - 1;
-        a_ptr[i] = A + (size_t)m * lda + 4 * c4;
-        if (LN) {
-            mu[i] = stats[2 * m];
-            rs[i] = stats[2 * m + 1];
-        }
-    }
-    const float* b_ptr[B_IT];
-    bool b_on[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int idx = tid + 256 * i;
-        b_on[i] = idx < B_F4;
-        int n = n0 + (idx >> 3);
-        n = n < N ? n : N - 1;
-        b_ptr[i] = W + (size_t)n * K + 4 * c4;
-    }
-
-    // zero the 8 padding rows of both B buffers once (columns 136..143 are never stored)
-    for (int i = tid; i < 2 * 8 * LDT; i += 256) {
-        const int buf = i / (8 * LDT);
-        Bs[buf][BN * LDT + (i % (8 * LDT))] = 0.f;
-    }
-
-    float4 ra[2], rb[B_IT];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = ld4(a_ptr[i] + k0);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            if (b_on[i]) rb[i] = ld4(b_ptr[i] + k0);
-        if (LN) {
-            const float4 g = ld4(ln_w + k0 + 4 * c4);
-            const float4 be = ld4(ln_b + k0 + 4 * c4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ra[i].x = (ra[i].x - mu[i]) * rs[i] * g.x + be.x;
-                ra[i].y = (ra[i].y - mu[i]) * rs[i] * g.y + be.y;
-                ra[i].z = (ra[i].z - mu[i]) * rs[i] * g.z + be.z;
-                ra[i].w = (ra[i].w - mu[i]) * rs[i] * g.w + be.w;
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) st4(&As[buf][(rA0 + 32 * i) * LDT + col(rA0 + 32 * i, c4)], ra[i]);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            if (b_on[i]) st4(&Bs[buf][((tid + 256 * i) >> 3) * LDT + col((tid + 256 * i) >> 3, c4)], rb[i]);
-    };
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    float4 inv_a = {0.f, 0.f, 0.f, 0.f}, inv_b[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) inv_b[n] = inv_a;
-    const int KT = K / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT && !(ABL & 1)) load_tile(kt + 1);
-        // rows wave*16+li and n*16+li all have (row >> 1) & 7 == (li >> 1) & 7
-        const float* as = &As[buf][(wave * 16 + li) * LDT];
-        const float* bs = &Bs[buf][li * LDT];
-#pragma unroll
-        for (int kb = 0; kb < BK; kb += 16) {
-            const int cc = col(li, (kb >> 2) + kq);
-            float4 a;
-            float4 b[NT];
-            if (!(ABL & 16) || kt == 0) {
-                a = ld4(as + cc);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * LDT + cc);
-                if (ABL & 16) {
-                    inv_a = a;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) inv_b[n] = b[n];
-                }
-            } else {
-                a = inv_a;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) b[n] = inv_b[n];
-            }
-            if (ABL & 2) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    acc[n][0] += a.x * b[n].x;
-                    acc[n][1] += a.y * b[n].y;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.x, b[n].x, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.y, b[n].y, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.z, b[n].z, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.w, b[n].w, acc[n]);
-        }
-        if (kt + 1 < KT && !(ABL & 8)) store_tile(buf ^ 1);
-        if (!(ABL & 4)) __syncthreads();
-    }
-
-    // ---- epilogue: D[row = 4*kq + r][col = li] of each 16x16 tile
-    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + wave * 16 + 4 * kq, n0, li);
-}
-
-
-// ------------------------------------------------------------------------------------------
-// DMA-staged variant: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
-// ds_write), a 3-stage LDS ring keeps two k tiles in flight, one raw s_barrier per k tile, counted vmcnt.
-// Stage layout (26 KiB): A 64 rows x 128 B | B 136 rows x 128 B | 1 KiB piece holding gamma[32], beta[32]
-// of the k tile (its tail doubles as the 8 padding rows of B: finite data, columns never stored).
-// Rows are unpadded; the 16-B column c of row r sits at c ^ ((r >> 1) & 7).  A DMA piece is 1 KiB =
-// 8 rows; its LDS image is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
-// LayerNorm is applied when the A fragment is read (8 values per lane per k tile).
-constexpr int ST_A = 0;
-constexpr int ST_B = BM * BK * 4;                 // 8192
-constexpr int ST_GB = ST_B + BN * BK * 4;         // 25600
-constexpr int ST_BYTES = ST_GB + 1024;            // 26624
-constexpr int NSTAGE = 3;
-constexpr int NPIECE_LN = 26, NPIECE = 25;
-
-// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform).
-// Issued from inline asm on purpose: with the builtin hipcc assumes the LDS write may alias every later
-// ds_read and drains vmcnt(0) in front of it, which serialises the ring.  The asm DMA is invisible to the
-// compiler's counters; completion is tracked by the explicit counted s_waitcnt vmcnt below.  M0 is saved and
-// restored inside the same statement (the compiler does not preserve it around asm).
+// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
+// M0 is saved/restored inside the statement (the compiler does not preserve it around asm).
 __device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -308,32 +196,73 @@ __device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
         : "memory");
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+#define MPL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        MPL_W(0) MPL_W(1) MPL_W(2) MPL_W(3) MPL_W(4) MPL_W(5) MPL_W(6) MPL_W(7) MPL_W(8) MPL_W(9) MPL_W(10)
+        MPL_W(11) MPL_W(12) MPL_W(13) MPL_W(14) MPL_W(15) MPL_W(16) MPL_W(17) MPL_W(18) MPL_W(19) MPL_W(20)
+        MPL_W(21) MPL_W(22) MPL_W(23) MPL_W(24) MPL_W(25) MPL_W(26) MPL_W(27) MPL_W(28)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef MPL_W
 }
 
-template <int EPI, bool LN>
-__global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(const float* __restrict__ A, int lda,
-                                                              const float* __restrict__ stats,
-                                                              const float* __restrict__ ln_w,
-                                                              const float* __restrict__ ln_b,
-                                                              const float* __restrict__ W,
-                                                              const float* __restrict__ bias, const float* R, int ldr,
-                                                              float* C, int ldc, int M, int N, int K, int grid_m,
-                                                              int grid_n) {
-    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * ST_BYTES];
+struct Frag {
+    float4 a, g, be;
+    float4 b[NT];
+};
+
+// fragments of 16-deep k step `step` (sub-tile step >> 1, half step & 1) of the stage at `st`
+template <bool LN, int NG>
+__device__ __forceinline__ void load_frag(Frag& f, const char* st, int step, int rg, int cg, int li, int kq, int swz) {
+    typedef SubStage<NG> SS;
+    const char* sb = st + (step >> 1) * SS::BYTES;
+    const int cl = ((step & 1) << 2) + kq;          // logical 16-B column of this lane
+    const int cc = (cl ^ swz) << 2;
+    const float* as = reinterpret_cast<const float*>(sb) + (rg * 16 + li) * BK;
+    const float* bs = reinterpret_cast<const float*>(sb + SUB_A + cg * SUB_B) + li * BK;
+    f.a = ld4(as + cc);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) f.b[n] = ld4(bs + n * 16 * BK + cc);
+    if (LN) {
+        const float* gb = reinterpret_cast<const float*>(sb + SS::GB);
+        f.g = ld4(gb + 4 * cl);
+        f.be = ld4(gb + 32 + 4 * cl);
+    }
+}
+
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0>
+__global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const float* __restrict__ A, int lda,
+                                                                       const float* __restrict__ stats,
+                                                                       const float* __restrict__ ln_w,
+                                                                       const float* __restrict__ ln_b,
+                                                                       const float* __restrict__ W,
+                                                                       const float* __restrict__ bias, const float* R,
+                                                                       int ldr, float* C, int ldc, int M, int N, int K,
+                                                                       int grid_m, int grid_n, float eps,
+                                                                       float* stats_out) {
+    typedef SubStage<NG> SS;
+    constexpr int NW = 4 * NG * KG;                  // waves: 4 row groups x NG column groups x KG k groups
+    constexpr int STAGE = KS * SS::BYTES;
+    constexpr int P_SUB = LN ? SS::PIECES : SS::PIECES - 1;
+    constexpr int P_STAGE = KS * P_SUB;              // DMA pieces per full stage
+    constexpr int SLOTS = (P_STAGE + NW - 1) / NW;   // pieces per wave per stage (max)
+    constexpr int SPW = (2 * KS) / KG;               // 16-deep k steps per wave per full stage
+    static_assert(SPW * KG == 2 * KS, "k groups must divide the steps of a stage");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, cg = (wave >> 2) % NG, kg = (wave >> 2) / NG;
     const int li = lane & 15;
     const int kq = lane >> 4;
 
     int tm, tn;
     {
         const int b = blockIdx.x;
-        if ((grid_m & 7) == 0) {
+        if ((grid_m & 7) == 0) {  // XCD-aware: blocks b, b+8, .. share an XCD/L2 -> give each XCD a band of m tiles
             const int per = grid_m >> 3;
             const int xcd = b & 7, i = b >> 3;
             tm = xcd * per + (i % per);
@@ -344,172 +273,221 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(const float* __rest
         }
     }
     const int m0 = tm * BM;
-    const int n0 = tn * BN;
+    const int n0 = tn * (BN * NG);
 
     float mu = 0.f, rs = 1.f;
     if (LN) {
-        int m = m0 + wave * 16 + li;
+        int m = m0 + rg * 16 + li;
         m = m < M ? m : M - 1;
-        mu = stats[2 * m];
-        rs = stats[2 * m + 1];
-        // consume the two loads here: otherwise hipcc parks their s_waitcnt vmcnt(0) at the first use INSIDE
-        // the k loop, where it would drain the (compiler-invisible) DMA ring every iteration
+        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
+        ln_combine(stats + (size_t)m * ns * 2, ns, sl, K, eps, mu, rs);
+        // consume the loads here: otherwise hipcc parks their s_waitcnt vmcnt(0) at the first use INSIDE the
+        // k loop, where it would drain the (compiler-invisible) DMA ring every iteration
         asm volatile("" : "+v"(mu), "+v"(rs));
     }
+    if (!LN) {  // the gamma/beta KiB doubles as padding rows of the last B group: keep it finite
+        for (int i = tid; i < NST * KS * 256; i += 64 * NW) {
+            const int sub = i >> 8;
+            reinterpret_cast<float*>(smem + sub * SS::BYTES + SS::GB)[i & 255] = 0.f;
+        }
+    }
 
-    // ---- DMA piece assignment: piece p -> wave p & 3, slot p >> 2 (7 slots max)
-    constexpr int NP = LN ? NPIECE_LN : NPIECE;
-    const float* src[7];
+    // ---- DMA piece table of this wave: stage piece q = ks * P_SUB + p  ->  wave q % NW, slot q / NW
+    const float* src[SLOTS];
+    unsigned dst[SLOTS];
 #pragma unroll
-    for (int sl = 0; sl < 7; ++sl) {
-        const int p = sl * 4 + wave;
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int q = sl * NW + wave;
+        const int ks = q / P_SUB, p = q - ks * P_SUB;
         const float* g;
         if (p < 8) {
             const int r = p * 8 + (lane >> 3);
             int m = m0 + r;
             m = m < M ? m : M - 1;
             g = A + (size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
-        } else if (p < 25) {
-            const int r = (p - 8) * 8 + (lane >> 3);
+        } else if (p < 8 + 17 * NG) {
+            const int r = (p - 8) * 8 + (lane >> 3);            // row inside the NG*136-row B slab
+            const int rr = r % BN;                              // row inside its column group (swizzle key)
             int n = n0 + r;
             n = n < N ? n : N - 1;
-            g = W + (size_t)n * K + 4 * ((lane & 7) ^ ((r >> 1) & 7));
-        } else {  // gamma | beta slice of this k tile (lanes >= 16 re-load the same 256 B: finite filler)
+            g = W + (size_t)n * K + 4 * ((lane & 7) ^ ((rr >> 1) & 7));
+        } else {  // gamma | beta slice (lanes >= 16 re-load the same 256 B: finite filler)
             g = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);
         }
-        src[sl] = g;
+        src[sl] = g + ks * BK;
+        dst[sl] = (unsigned)(ks * SS::BYTES + p * 1024);
     }
-    const int my_np = (NP - wave + 3) >> 2;  // pieces this wave issues per tile (wave-uniform): 7 or 6
-
+    const int KT = K / BK;                      // k-tiles
+    const int T = (KT + KS - 1) / KS;           // stages
+    const int last_sub = KT - (T - 1) * KS;     // valid sub-tiles of the last stage
+    auto pieces_of = [&](int t) -> int {        // pieces this wave issues for stage t (wave-uniform)
+        const int tot = (t == T - 1 ? last_sub : KS) * P_SUB;
+        return tot > wave ? (tot - wave + NW - 1) / NW : 0;
+    };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue_tile = [&](int kt) {
-        const unsigned st = lds0 + (unsigned)((kt % NSTAGE) * ST_BYTES);
-        const int k0 = kt * BK;
+    auto issue_stage = [&](int t) {
+        const unsigned st = lds0 + (unsigned)((t % NST) * STAGE);
+        const int k0 = t * KS * BK;
+        const int np = pieces_of(t);
 #pragma unroll
-        for (int sl = 0; sl < 7; ++sl) {
-            const int p = sl * 4 + wave;
-            if (p < NP) dma16(src[sl] + k0, st + (unsigned)(p * 1024));
-        }
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (sl < np) dma16(src[sl] + k0, st + dst[sl]);
     };
 
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = K / BK;
-    issue_tile(0);
-    if (KT > 1) issue_tile(1);
+    if (!LN) __syncthreads();                   // zero fill above is ordinary LDS traffic: order it first
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < T) issue_stage(t);
 
     const int swz = (li >> 1) & 7;
-    for (int kt = 0; kt < KT; ++kt) {
-        // my DMAs of tile kt have landed once at most the pieces of tile kt+1 are outstanding
-        if (kt + 1 < KT) {
-            if (my_np == 7) wait_vm<7>(); else wait_vm<6>();
-        } else {
-            wait_vm<0>();
-        }
-        __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+        // stage t has landed for this wave once only the pieces of stages t+1 .. t+NST-2 are outstanding
+        int allow = 0;
+#pragma unroll
+        for (int j = 1; j <= NST - 2; ++j)
+            if (t + j < T) allow += pieces_of(t + j);
+        if (ABL & 1) allow = 0;
+        wait_vm(allow);
+        __builtin_amdgcn_s_barrier();           // everyone's pieces landed; everyone is done reading stage t-1
         asm volatile("" ::: "memory");
-        if (kt + 2 < KT) issue_tile(kt + 2);
+        // refill the stage the barrier just freed.  With a 2-stage ring the data is needed at the very next
+        // barrier, so issue at once; with 3 stages issue behind the first MFMA block so that the fragment
+        // reads, not the DMA address arithmetic, follow the barrier.
+        if (NST == 2 && t + 1 < T && !(ABL & 1)) issue_stage(t + 1);
 
-        const char* st = smem + (kt % NSTAGE) * ST_BYTES;
-        const float* as = reinterpret_cast<const float*>(st + ST_A) + (wave * 16 + li) * BK;
-        const float* bs = reinterpret_cast<const float*>(st + ST_B) + li * BK;
-        const float* gb = reinterpret_cast<const float*>(st + ST_GB);
+        const char* st = smem + (t % NST) * STAGE;
+        const int nstep = 2 * ((t == T - 1) ? last_sub : KS);   // 16-deep k steps in this stage
+        // This wave owns steps kg, kg + KG, ...  Fragment registers are double buffered by hand (reads of the
+        // next own step are issued before the 36 MFMAs of the current one); sched_barrier(0) keeps hipcc from
+        // re-serialising them into read->wait->4 dependent MFMAs per column tile (its minimum-register schedule).
+        Frag f[2];
+        if (kg < nstep) load_frag<LN, NG>(f[0], st, kg, rg, cg, li, kq, swz);
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 16) {
-            const int cl = (kb >> 2) + kq;           // logical 16-B column
-            const int cc = (cl ^ swz) << 2;
-            float4 a = ld4(as + cc);
-            float4 b[NT];
+        for (int j = 0; j < SPW; ++j) {
+            const int i = kg + j * KG;
+            if (i < nstep) {
+                if (j + 1 < SPW && i + KG < nstep) load_frag<LN, NG>(f[(j + 1) & 1], st, i + KG, rg, cg, li, kq, swz);
+                __builtin_amdgcn_sched_barrier(0);
+                Frag& c = f[j & 1];
+                if (LN) {
+                    c.a.x = (c.a.x - mu) * rs * c.g.x + c.be.x;
+                    c.a.y = (c.a.y - mu) * rs * c.g.y + c.be.y;
+                    c.a.z = (c.a.z - mu) * rs * c.g.z + c.be.z;
+                    c.a.w = (c.a.w - mu) * rs * c.g.w + c.be.w;
+                }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[n] = ld4(bs + n * 16 * BK + cc);
-            if (LN) {
-                const float4 g = ld4(gb + 4 * cl), be = ld4(gb + 32 + 4 * cl);
-                a.x = (a.x - mu) * rs * g.x + be.x;
-                a.y = (a.y - mu) * rs * g.y + be.y;
-                a.z = (a.z - mu) * rs * g.z + be.z;
-                a.w = (a.w - mu) * rs * g.w + be.w;
+                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.x, c.b[n].x, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.y, c.b[n].y, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.z, c.b[n].z, acc[n]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.w, c.b[n].w, acc[n]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.x, b[n].x, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.y, b[n].y, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.z, b[n].z, acc[n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = mfma16(a.w, b[n].w, acc[n]);
+            if (NST > 2 && j == 0 && t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
         }
     }
-
-    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + wave * 16 + 4 * kq, n0, li);
+    if (KG > 1) {
+        // k groups hold partial sums of the same output tile: fold groups 1..KG-1 into group 0 through LDS in a
+        // fixed order (deterministic).  All DMA has been waited for, so the ring memory is free.
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (kg > 0) {
+            float* dstp = red + (size_t)(((kg - 1) * NG + cg) * 4 + rg) * (NT * 4 * 64) + lane;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dstp[(n * 4 + r) * 64] = acc[n][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int k = 1; k < KG; ++k) {
+            const float* sp = red + (size_t)(((k - 1) * NG + cg) * 4 + rg) * (NT * 4 * 64) + lane;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][r] += sp[(n * 4 + r) * 64];
+        }
+    }
+    if (ABL & 2) {  // bench-only: keep acc live, store (almost) nothing
+        float sacc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) sacc += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
+        if (sacc == 12345.678f) C[tid] = sacc;
+        return;
+    }
+    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, n0 + cg * BN, li, stats_out,
+                             N / BN);
 }
 
-template <int EPI, bool LN>
-static int launch_dma(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
-                      const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
-                      int K, hipStream_t s) {
-    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0>
+static int launch_ng(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
+                     const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, float eps,
+                     float* stats_out, hipStream_t s) {
+    constexpr int LDS = NST * KS * SubStage<NG>::BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    static_assert((KG - 1) * NG * 4 * NT * 4 * 64 * 4 <= LDS, "k-group reduction does not fit in the ring");
+    const int gm = (M + BM - 1) / BM, gn = (N + BN * NG - 1) / (BN * NG);
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev]) {
-        // 78 KiB of static LDS per workgroup: nothing to opt into, but keep the carve-out maximal
+        if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MPL_E_LAUNCH;
         attr_set[dev] = true;
     }
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_dma_kernel<EPI, LN>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias,
-                       R, ldr, C, ldc, M, N, K, gm, gn);
+    hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL>), dim3(gm * gn), dim3(256 * NG * KG), LDS, s, A,
+                       lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out);
     return hip_check_launch();
 }
 
-template <int EPI, bool LN, int VAR, int ABL>
-static int launch_cfg(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
-                      const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
-                      int K, hipStream_t s) {
-    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
-    ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_kernel<EPI, LN, VAR, ABL>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W, bias, R,
-                       ldr, C, ldc, M, N, K, gm, gn);
-    return hip_check_launch();
+template <int EPI, bool LN>
+static int launch_ng_auto(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
+                          const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+                          int K, float eps, float* stats_out, hipStream_t s) {
+    // widest column grouping that still yields >= 256 workgroups (one per CU); small problems stay at NG = 1
+    const int gm = (M + BM - 1) / BM;
+    static const int force = getenv("MPL_GEMM_NG") ? atoi(getenv("MPL_GEMM_NG")) : 0;   // bench-only
+    static const int kgsel = getenv("MPL_GEMM_KG") ? atoi(getenv("MPL_GEMM_KG")) : 0;    // bench-only
+    int ng = 1;
+    if (N % (BN * 3) == 0 && gm * (N / (BN * 3)) >= 256) ng = 3;
+    if (force) ng = force;
+#define MPL_ARGS2 A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
+    static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;   // bench-only ablations
+    if (abl && EPI == 0 && !LN) {
+        if (ng == 3) return abl == 1 ? launch_ng<0, false, 3, 1, 1, 2, 1>(MPL_ARGS2) : abl == 2 ? launch_ng<0, false, 3, 1, 1, 2, 2>(MPL_ARGS2) : launch_ng<0, false, 3, 1, 1, 2, 3>(MPL_ARGS2);
+        if (ng == 1) return abl == 1 ? launch_ng<0, false, 1, 1, 1, 3, 1>(MPL_ARGS2) : abl == 2 ? launch_ng<0, false, 1, 1, 1, 3, 2>(MPL_ARGS2) : launch_ng<0, false, 1, 1, 1, 3, 3>(MPL_ARGS2);
+    }
+    // Every configuration keeps KG = 1: the k order of each output element is then independent of the launch
+    // geometry, so results do not depend on the batch size (tests: batch split / permutation are bitwise equal).
+    // Measured on MI355X (tools/gemm_ab.py, M = 4096, D = 544): QKV 80 us with either geometry; the 4-wave
+    // workgroup (two per CU, 3-stage ring) wins for N = D and N = 2 D, k-group splitting never paid.
+    if (ng == 3 && kgsel != 9) return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
+    if (kgsel == 2) return launch_ng<EPI, LN, 1, 1, 2, 3>(MPL_ARGS2);      // 1 WG/CU, 2 k-tiles per stage
+    return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);                      // 2 WGs/CU, 1 k-tile per stage
+#undef MPL_ARGS2
 }
 
-int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
-                   const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi,
-                   hipStream_t s) {
+int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
+                   const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
+                   int epi, float* stats_out, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda & 3)) return MPL_E_INVALID;
     const bool ln = ln_w != nullptr;
     if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-    // bench-only knobs (tools/microbench.py): kernel variant and ablation
-    static const int var = getenv("MPL_GEMM_VAR") ? atoi(getenv("MPL_GEMM_VAR")) : MPL_GEMM_DEFAULT_VAR;
-    static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;
-#define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, s
-    if (abl) {
-        switch (abl) {
-            case 1: return launch_cfg<0, false, 1, 1>(MPL_ARGS);
-            case 2: return launch_cfg<0, false, 1, 2>(MPL_ARGS);
-            case 9: return launch_cfg<0, false, 1, 9>(MPL_ARGS);
-            case 13: return launch_cfg<0, false, 1, 13>(MPL_ARGS);
-            case 29: return launch_cfg<0, false, 1, 29>(MPL_ARGS);
-            case 25: return launch_cfg<0, false, 1, 25>(MPL_ARGS);
-            case 17: return launch_cfg<0, false, 1, 17>(MPL_ARGS);
-            case 5: return launch_cfg<0, false, 1, 5>(MPL_ARGS);
-            default: return MPL_E_INVALID;
-        }
-    }
-#define MPL_GEMM_VARS(E, L)                                            \
-    switch (var) {                                                     \
-        case 4: return launch_dma<E, L>(MPL_ARGS);                     \
-        case 0: return launch_cfg<E, L, 0, 0>(MPL_ARGS);               \
-        case 1: return launch_cfg<E, L, 1, 0>(MPL_ARGS);               \
-        case 2: return launch_cfg<E, L, 2, 0>(MPL_ARGS);               \
-        default: return launch_cfg<E, L, 3, 0>(MPL_ARGS);              \
-    }
-#define MPL_GEMM_CASE(E)                 \
-    case E:                              \
-        if (ln) { MPL_GEMM_VARS(E, true) } \
-        else { MPL_GEMM_VARS(E, false) }
+    if (stats_out && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
+#define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
+#define MPL_GEMM_CASE(E)                                                                              \
+    case E:                                                                                           \
+        return ln ? launch_ng_auto<E, true>(MPL_ARGS) : launch_ng_auto<E, false>(MPL_ARGS);
     switch (epi) {
         MPL_GEMM_CASE(MPL_EPI_BIAS)
         MPL_GEMM_CASE(MPL_EPI_BIAS_GELU)
@@ -517,9 +495,8 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
         default:
             return MPL_E_INVALID;
     }
-#undef MPL_GEMM_VARS
-#undef MPL_ARGS
 #undef MPL_GEMM_CASE
+#undef MPL_ARGS
 }
 
 }  // namespace mpl

@@ -67,7 +67,7 @@ def test_ln_linear_matches_torch(M, K, N, epi, ln):
     lb = (torch.randn(K, generator=g) * 0.1).to(DEV)
     res = torch.randn(M, N, generator=g).to(DEV)
     y = torch.full((M, N), float("nan"), device=DEV)
-    stats = torch.empty(M * 2, device=DEV)
+    stats = torch.empty(M * 2 * 16, device=DEV)
     rc = lib.mpl_ln_linear(x.data_ptr(), M, K, lw.data_ptr() if ln else None, lb.data_ptr() if ln else None, 1e-6,
                            W.data_ptr(), b.data_ptr(), N, epi, res.data_ptr() if epi == 2 else None, y.data_ptr(),
                            stats.data_ptr(), _stream())

@@ -18,7 +18,10 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 tag = "var=%s abl=%s" % (os.environ.get("MPL_GEMM_VAR", "default"), os.environ.get("MPL_GEMM_ABL", "0"))
 tot_ms, tot_fl = 0.0, 0.0
 line = []
-for name, K, N, epi in [("qkv", D, 3 * D, 0), ("proj", D, D, 2), ("fc1", D, 2 * D, 1), ("fc2", 2 * D, D, 2)]:
+SHAPES = [("qkv", D, 3 * D, 0), ("proj", D, D, 2), ("fc1", D, 2 * D, 1), ("fc2", 2 * D, D, 2)]
+if os.environ.get("MPL_GEMM_ABL"):
+    SHAPES = [("qkv", D, 3 * D, 0), ("proj*", D, D, 0)]
+for name, K, N, epi in SHAPES:
     A = torch.randn(M, K, generator=g).to(dev)
     W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)

@@ -41,7 +41,7 @@ def main():
     M = a.batch * a.views
     g = torch.Generator().manual_seed(0)
     x = torch.randn(M, D, generator=g).to(dev)
-    stats = torch.empty(2 * M, device=dev)
+    stats = torch.empty(2 * M * 16, device=dev)
     lw, lb = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     print("M=%d D=%d" % (M, D))
     tot = 0.0
