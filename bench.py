@@ -176,8 +176,18 @@ def main():
         total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
         io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
         weight_bytes = sum(p.numel() for p in model.parameters()) * 4
-        roof = dict(bound="mfma", kernel="ln_gemm_kernel", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+        # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed
+        # rocprofv3 PMC passes of the same kernels (profiles/), and only for the profiled workload shape.
+        traffic, traffic_src = None, None
+        try:
+            if a.flagset == "chosen" and a.batch == 1024 and a.views == 4:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))
+                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), tj["source"]
+        except Exception:
+            pass
+        roof = dict(bound="mfma", kernel="ln_gemm_ng_kernel", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                    traffic_source=traffic_src,
                     avg_launch_us=round(avg_launch_ms * 1e3, 2), launches_per_step=launches,
                     flops_per_launch=fl / launches,
                     whole_forward_tflops=round(value / world * total_flop / 1e12, 2),

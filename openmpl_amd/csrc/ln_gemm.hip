@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         wait_vm(allow);
         __builtin_amdgcn_s_barrier();           // everyone's pieces landed; everyone is done reading stage t-1
         asm volatile("" ::: "memory");
-        // refill the stage the barrier just freed.  With a 2-stage ring the data is needed at the very next
-        // barrier, so issue at once; with 3 stages issue behind the first MFMA block so that the fragment
-        // reads, not the DMA address arithmetic, follow the barrier.
+        // refill the stage the barrier just freed.  A 2-stage ring needs the data at the very next barrier: issue at
+        // once.  With 3 stages there is a whole extra stage of slack: issue behind the first fragment reads so
+        // that the DMA address arithmetic runs in the shadow of the LDS latency.
         if (NST == 2 && t + 1 < T && !(ABL & 1)) issue_stage(t + 1);
 
         const char* st = smem + (t % NST) * STAGE;
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
             const int i = kg + j * KG;
             if (i < nstep) {
                 if (j + 1 < SPW && i + KG < nstep) load_frag<LN, NG>(f[(j + 1) & 1], st, i + KG, rg, cg, li, kq, swz);
+                if (NST > 2 && j == 0 && t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 Frag& c = f[j & 1];
                 if (LN) {
@@ -389,7 +390,6 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
                 for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.w, c.b[n].w, acc[n]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (NST > 2 && j == 0 && t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
         }
     }
     if (KG > 1) {
