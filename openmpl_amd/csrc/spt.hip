@@ -19,6 +19,8 @@
 //     {i, i+16, i+32, i+48}, so mean/variance are two xor-shuffles.
 //   * attention (17x17 scores, head dim 4) is VALU work: one thread per (row, head), scores in
 //     registers, softmax without any cross-lane traffic; k/v rows are LDS broadcasts.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mpl {
@@ -31,6 +33,8 @@ constexpr int ROWS = SEQ * SJ;  // 272
 constexpr int MT = ROWS / 16;   // 17 row tiles
 constexpr int XS = 36;          // X row stride (floats)
 constexpr int QS = 100;         // Q row stride (floats)
+constexpr int NTHR = 512;        // 8 waves: two per SIMD
+constexpr int NWAVE = NTHR / 64;
 constexpr int SPT_LDS_BYTES = (ROWS * XS + ROWS * QS) * 4;  // 147968
 
 struct SptParams {
@@ -45,6 +49,7 @@ struct SptParams {
     int B, V, in_ch, n_apps;
     unsigned flags;
     int c3;  // channel count of the pos_3d_* tensors (d or 2d)
+    int abl;  // bench-only ablation mask (MPL_SPT_ABL): 1 no attention, 2 no GELU, 4 no MFMA phases, 8 no epilogue math
     unsigned char sched[MPL_MAX_APPS];  // layer | weighted << 7
 };
 
@@ -85,7 +90,71 @@ __device__ __forceinline__ void ln_frags(const float* X, int m, int li, int kq, 
     a1.z = x1.z * rstd * g1.z + b1.z; a1.w = x1.w * rstd * g1.w + b1.w;
 }
 
-__global__ __launch_bounds__(256, 1) void spt_kernel(const SptParams p) {
+// All MFMA B fragments and LayerNorm / bias vectors of one Block that this lane needs (128 + 30 registers).
+// They are loaded straight from the reference's [out][in] tensors one phase ahead of their use, so the L2
+// latency never sits on the critical path of a phase.
+struct BlockFrags {
+    float4 wq[6][2]; float bq[6];     // attn.qkv: 6 column tiles x (k 0..15 | k 16..31)
+    float4 wp[2][2]; float bp[2];     // attn.proj
+    float4 w1[4][2]; float b1[4];     // mlp.fc1
+    float4 w2[2][4]; float b2[2];     // mlp.fc2 (K = 64: four 16-deep steps)
+    float4 g1a, g1b, e1a, e1b;        // norm1 gamma/beta of this lane's 8 k columns
+    float4 g2a, g2b, e2a, e2b;        // norm2
+};
+
+__device__ __forceinline__ void load_qkv_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
+    F.g1a = ld4(G(bw.ln1_w) + 4 * kq); F.g1b = ld4(G(bw.ln1_w) + 16 + 4 * kq);
+    F.e1a = ld4(G(bw.ln1_b) + 4 * kq); F.e1b = ld4(G(bw.ln1_b) + 16 + 4 * kq);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const gfp wr = G(bw.qkv_w) + (n * 16 + li) * SD + 4 * kq;
+        F.wq[n][0] = ld4(wr);
+        F.wq[n][1] = ld4(wr + 16);
+        F.bq[n] = G(bw.qkv_b)[n * 16 + li];
+    }
+}
+
+__device__ __forceinline__ void load_rest_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const gfp wr = G(bw.proj_w) + (n * 16 + li) * SD + 4 * kq;
+        F.wp[n][0] = ld4(wr);
+        F.wp[n][1] = ld4(wr + 16);
+        F.bp[n] = G(bw.proj_b)[n * 16 + li];
+    }
+    F.g2a = ld4(G(bw.ln2_w) + 4 * kq); F.g2b = ld4(G(bw.ln2_w) + 16 + 4 * kq);
+    F.e2a = ld4(G(bw.ln2_b) + 4 * kq); F.e2b = ld4(G(bw.ln2_b) + 16 + 4 * kq);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const gfp wr = G(bw.fc1_w) + (n * 16 + li) * SD + 4 * kq;
+        F.w1[n][0] = ld4(wr);
+        F.w1[n][1] = ld4(wr + 16);
+        F.b1[n] = G(bw.fc1_b)[n * 16 + li];
+    }
+}
+
+__device__ __forceinline__ void load_fc2_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const gfp wr = G(bw.fc2_w) + (n * 16 + li) * (2 * SD) + 4 * kq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) F.w2[n][q] = ld4(wr + 16 * q);
+        F.b2[n] = G(bw.fc2_b)[n * 16 + li];
+    }
+}
+
+// one 16x16 output tile of a K = 32 GEMM: two independent accumulator chains (k 0..15 / 16..31) so that
+// consecutive MFMAs never wait on the 40-cycle dependent-accumulator latency
+__device__ __forceinline__ f32x4 tile_k32(const float4& a0, const float4& a1, const float4& w0, const float4& w1) {
+    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    c0 = mfma16(a0.x, w0.x, c0); c1 = mfma16(a1.x, w1.x, c1);
+    c0 = mfma16(a0.y, w0.y, c0); c1 = mfma16(a1.y, w1.y, c1);
+    c0 = mfma16(a0.z, w0.z, c0); c1 = mfma16(a1.z, w1.z, c1);
+    c0 = mfma16(a0.w, w0.w, c0); c1 = mfma16(a1.w, w1.w, c1);
+    return c0 + c1;
+}
+
+__global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
     float* Q = smem + ROWS * XS;
@@ -99,8 +168,16 @@ __global__ __launch_bounds__(256, 1) void spt_kernel(const SptParams p) {
     const float* ray = p.rays[view];
     const float* cen = p.centers[view];
 
+    // weights of the first Block application: issue the loads before anything else
+    BlockFrags F;
+    mpl_block_weights bw, bw_next;
+    if (p.n_apps > 0) {
+        bw = set.blocks[p.sched[0] & 0x7f];
+        load_qkv_frags(bw, F, li, kq);
+    }
+
     // ---------------- phase 0: joint embedding (:355-396) ----------------
-    for (int idx = tid; idx < ROWS * SD; idx += 256) {
+    for (int idx = tid; idx < ROWS * SD; idx += NTHR) {
         const int r = idx >> 5, c = idx & 31;
         const int sq = r / SJ, j = r - sq * SJ;
         const int b = b0 + sq;
@@ -131,54 +208,38 @@ __global__ __launch_bounds__(256, 1) void spt_kernel(const SptParams p) {
     __syncthreads();
 
     // ---------------- block applications (:405-410) ----------------
+    // Output tiles (16 rows x 16 columns) of every Linear are dealt to the 8 waves as contiguous ranges of the
+    // row-major tile list; a wave walks its row tiles and tests each column tile against its range (static
+    // indices keep every fragment in registers).
     for (int app = 0; app < p.n_apps; ++app) {
-        const int layer = p.sched[app] & 0x7f;
         const bool weighted = (p.sched[app] & 0x80) != 0;
-        const mpl_block_weights bw = set.blocks[layer];
+        const bool more = app + 1 < p.n_apps;
+        if (more) bw_next = set.blocks[p.sched[app + 1] & 0x7f];   // pointers only; used two phases later
+        // Prefetch schedule (peak ~140 live fragment registers): proj + fc1 weights now, fc2 weights at the proj
+        // phase, the next application's qkv weights at the fc2 phase.
+        load_rest_frags(bw, F, li, kq);
 
-        // ---- QKV = LN1(X) . Wqkv^T + b : 17 row tiles x 2 halves of 3 column tiles -> Q[:, 0:96]
+        // ---- QKV = LN1(X) . Wqkv^T + b : 17 x 6 tiles -> Q[:, 0:96]
         {
-            const float4 g0 = ld4(G(bw.ln1_w) + 4 * kq), g1 = ld4(G(bw.ln1_w) + 16 + 4 * kq);
-            const float4 e0 = ld4(G(bw.ln1_b) + 4 * kq), e1 = ld4(G(bw.ln1_b) + 16 + 4 * kq);
-            float4 wf[6][2];
-            float bias[6];
-#pragma unroll
-            for (int n = 0; n < 6; ++n) {
-                const gfp wr = G(bw.qkv_w) + (n * 16 + li) * SD + 4 * kq;
-                wf[n][0] = ld4(wr);
-                wf[n][1] = ld4(wr + 16);
-                bias[n] = G(bw.qkv_b)[n * 16 + li];
-            }
-            int lo, hi;
-            wave_range(MT * 2, wave, lo, hi);
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            const int lo = (MT * 6 * wave) / NWAVE, hi = (MT * 6 * (wave + 1)) / NWAVE;
+            for (int m = lo / 6; m <= (hi - 1) / 6 && !(p.abl & 4); ++m) {
                 float4 a0, a1;
-                ln_frags(X, m, li, kq, g0, g1, e0, e1, a0, a1);
+                ln_frags(X, m, li, kq, F.g1a, F.g1b, F.e1a, F.e1b, a0, a1);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int u = 2 * m + half;
+                for (int n = 0; n < 6; ++n) {
+                    const int u = m * 6 + n;
                     if (u < lo || u >= hi) continue;
-                    f32x4 acc[3];
+                    const f32x4 c = tile_k32(a0, a1, F.wq[n][0], F.wq[n][1]);
+                    float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t] = mfma16_k16(a0, wf[half * 3 + t][0], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t] = mfma16_k16(a1, wf[half * 3 + t][1], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int n = half * 3 + t;
-                        float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qd[r * QS] = acc[t][r] + bias[n];
-                    }
+                    for (int r = 0; r < 4; ++r) qd[r * QS] = c[r] + F.bq[n];
                 }
             }
         }
         __syncthreads();
 
         // ---- attention: thread per (row, head); 17 scores in registers (:55-64)
-        for (int pr = tid; pr < ROWS * SH; pr += 256) {
+        for (int pr = tid; pr < ROWS * SH && !(p.abl & 1); pr += NTHR) {
             const int r = pr >> 3, h = pr & 7;
             const int sq = r / SJ;
             const float* kb = Q + (sq * SJ) * QS + SD + 4 * h;
@@ -216,110 +277,66 @@ __global__ __launch_bounds__(256, 1) void spt_kernel(const SptParams p) {
         }
         __syncthreads();
 
-        // ---- X += attn_out . Wproj^T + b : 34 tiles, K split over two accumulators
+        // ---- X += attn_out . Wproj^T + b : 17 x 2 tiles
+        load_fc2_frags(bw, F, li, kq);
         {
-            float4 wf[2][2];
-            float bias[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const gfp wr = G(bw.proj_w) + (n * 16 + li) * SD + 4 * kq;
-                wf[n][0] = ld4(wr);
-                wf[n][1] = ld4(wr + 16);
-                bias[n] = G(bw.proj_b)[n * 16 + li];
-            }
-            int lo, hi;
-            wave_range(MT * 2, wave, lo, hi);
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 4); ++m) {
                 const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
                 const float4 a0 = ld4(ar), a1 = ld4(ar + 16);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int u = 2 * m + n;
                     if (u < lo || u >= hi) continue;
-                    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-                    c0 = mfma16_k16(a0, wf[n][0], c0);
-                    c1 = mfma16_k16(a1, wf[n][1], c1);
+                    const f32x4 c = tile_k32(a0, a1, F.wp[n][0], F.wp[n][1]);
                     float* xd = X + (m * 16 + 4 * kq) * XS + n * 16 + li;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xd[r * XS] += (c0[r] + c1[r]) + bias[n];
+                    for (int r = 0; r < 4; ++r) xd[r * XS] += c[r] + F.bp[n];
                 }
             }
         }
         __syncthreads();
 
-        // ---- Hid = gelu(LN2(X) . W1^T + b) : 17 row tiles x 2 halves of 2 column tiles -> Q[:, 0:64]
+        // ---- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles -> Q[:, 0:64]
         {
-            const float4 g0 = ld4(G(bw.ln2_w) + 4 * kq), g1 = ld4(G(bw.ln2_w) + 16 + 4 * kq);
-            const float4 e0 = ld4(G(bw.ln2_b) + 4 * kq), e1 = ld4(G(bw.ln2_b) + 16 + 4 * kq);
-            float4 wf[4][2];
-            float bias[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const gfp wr = G(bw.fc1_w) + (n * 16 + li) * SD + 4 * kq;
-                wf[n][0] = ld4(wr);
-                wf[n][1] = ld4(wr + 16);
-                bias[n] = G(bw.fc1_b)[n * 16 + li];
-            }
-            int lo, hi;
-            wave_range(MT * 2, wave, lo, hi);
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 2; m <= ((hi - 1) >> 2) && !(p.abl & 4); ++m) {
                 float4 a0, a1;
-                ln_frags(X, m, li, kq, g0, g1, e0, e1, a0, a1);
+                ln_frags(X, m, li, kq, F.g2a, F.g2b, F.e2a, F.e2b, a0, a1);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int u = 2 * m + half;
+                for (int n = 0; n < 4; ++n) {
+                    const int u = 4 * m + n;
                     if (u < lo || u >= hi) continue;
-                    f32x4 acc[2];
-                    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc[1] = acc[0];
+                    const f32x4 c = tile_k32(a0, a1, F.w1[n][0], F.w1[n][1]);
+                    float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = mfma16_k16(a0, wf[half * 2 + t][0], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = mfma16_k16(a1, wf[half * 2 + t][1], acc[t]);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int n = half * 2 + t;
-                        float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qd[r * QS] = gelu_erf(acc[t][r] + bias[n]);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        qd[r * QS] = (p.abl & 2) ? (c[r] + F.b1[n]) : gelu_erf(c[r] + F.b1[n]);
                 }
             }
         }
         __syncthreads();
 
-        // ---- X += Hid . W2^T + b : K = 64, 34 tiles, two accumulators (k 0..31 / 32..63)
+        // ---- X += Hid . W2^T + b : K = 64, 17 x 2 tiles
+        if (more) load_qkv_frags(bw_next, F, li, kq);   // qkv fragments are long dead: next application's weights
         {
-            float4 wf[2][4];
-            float bias[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const gfp wr = G(bw.fc2_w) + (n * 16 + li) * (2 * SD) + 4 * kq;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) wf[n][s] = ld4(wr + 16 * s);
-                bias[n] = G(bw.fc2_b)[n * 16 + li];
-            }
-            int lo, hi;
-            wave_range(MT * 2, wave, lo, hi);
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 4); ++m) {
                 const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
                 const float4 a0 = ld4(ar), a1 = ld4(ar + 16), a2 = ld4(ar + 32), a3 = ld4(ar + 48);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int u = 2 * m + n;
                     if (u < lo || u >= hi) continue;
-                    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-                    c0 = mfma16_k16(a0, wf[n][0], c0);
-                    c1 = mfma16_k16(a2, wf[n][2], c1);
-                    c0 = mfma16_k16(a1, wf[n][1], c0);
-                    c1 = mfma16_k16(a3, wf[n][3], c1);
+                    const f32x4 c = tile_k32(a0, a1, F.w2[n][0], F.w2[n][1]) + tile_k32(a2, a3, F.w2[n][2], F.w2[n][3]);
                     float* xd = X + (m * 16 + 4 * kq) * XS + n * 16 + li;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xd[r * XS] += (c0[r] + c1[r]) + bias[n];
+                    for (int r = 0; r < 4; ++r) xd[r * XS] += c[r] + F.b2[n];
                 }
             }
         }
         __syncthreads();
+        bw = bw_next;
     }
 
     // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void spt_kernel(const SptParams p) {
     const bool ray_tok = !(p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);  // token concat (:486-489)
     const int cw = to_rays ? 2 * SD : SD;                 // channels per joint in the output row
     const int Df = SJ * SD * ((p.flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
-    for (int r = tid; r < ROWS; r += 256) {
+    for (int r = tid; r < ROWS; r += NTHR) {
         const int sq = r / SJ, j = r - sq * SJ;
         const int b = b0 + sq;
         if (b >= p.B) continue;
@@ -426,6 +443,8 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     p.B = in->batch; p.V = cfg->num_views; p.in_ch = cfg->in_chans;
     p.flags = f;
     p.c3 = (f & MPL_F_POS3D_TO_RAYS) ? 2 * SD : SD;
+    static const int abl = getenv("MPL_SPT_ABL") ? atoi(getenv("MPL_SPT_ABL")) : 0;
+    p.abl = abl;
     // schedule (:405-410): [blk(x,w)]; if last: blk(x); blk(x)
     int n = 0;
     if (!(f & MPL_F_NO_SPT)) {
@@ -449,7 +468,7 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     }
     const int grid = cfg->num_views * ((in->batch + SEQ - 1) / SEQ);
     ProfScope prof(MPL_K_SPT, s);
-    hipLaunchKernelGGL(spt_kernel, dim3(grid), dim3(256), SPT_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(spt_kernel, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);
     return hip_check_launch();
 }
 
