@@ -354,10 +354,9 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         wait_vm(allow);
         __builtin_amdgcn_s_barrier();           // everyone's pieces landed; everyone is done reading stage t-1
         asm volatile("" ::: "memory");
-        // refill the stage the barrier just freed.  A 2-stage ring needs the data at the very next barrier: issue at
-        // once.  With 3 stages there is a whole extra stage of slack: issue behind the first fragment reads so
-        // that the DMA address arithmetic runs in the shadow of the LDS latency.
-        if (NST == 2 && t + 1 < T && !(ABL & 1)) issue_stage(t + 1);
+        // refill the stage the barrier just freed, at once: measured on MI355X, issuing the DMA here beats hiding
+        // its address arithmetic behind the first fragment reads or the first MFMA block for every ring depth
+        if (t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
 
         const char* st = smem + (t % NST) * STAGE;
         const int nstep = 2 * ((t == T - 1) ? last_sub : KS);   // 16-deep k steps in this stage
@@ -371,7 +370,6 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
             const int i = kg + j * KG;
             if (i < nstep) {
                 if (j + 1 < SPW && i + KG < nstep) load_frag<LN, NG>(f[(j + 1) & 1], st, i + KG, rg, cg, li, kq, swz);
-                if (NST > 2 && j == 0 && t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 Frag& c = f[j & 1];
                 if (LN) {
@@ -470,9 +468,31 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
     // geometry, so results do not depend on the batch size (tests: batch split / permutation are bitwise equal).
     // Measured on MI355X (tools/gemm_ab.py, M = 4096, D = 544): QKV 80 us with either geometry; the 4-wave
     // workgroup (two per CU, 3-stage ring) wins for N = D and N = 2 D, k-group splitting never paid.
-    if (ng == 3 && kgsel != 9) return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
-    if (kgsel == 2) return launch_ng<EPI, LN, 1, 1, 2, 3>(MPL_ARGS2);      // 1 WG/CU, 2 k-tiles per stage
-    return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);                      // 2 WGs/CU, 1 k-tile per stage
+    // bench-only geometry override: MPL_GEMM_CFG = ng*100 + ks*10 + nst
+    static const int cfg = getenv("MPL_GEMM_CFG") ? atoi(getenv("MPL_GEMM_CFG")) : 0;
+    switch (cfg) {
+        case 116: return launch_ng<EPI, LN, 1, 1, 1, 6>(MPL_ARGS2);
+        case 114: return launch_ng<EPI, LN, 1, 1, 1, 4>(MPL_ARGS2);
+        case 113: return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);
+        case 112: return launch_ng<EPI, LN, 1, 1, 1, 2>(MPL_ARGS2);
+        case 123: return launch_ng<EPI, LN, 1, 1, 2, 3>(MPL_ARGS2);
+        case 213: return launch_ng<EPI, LN, 2, 1, 1, 3>(MPL_ARGS2);
+        case 312: return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
+        default: break;
+    }
+    if (ng == 3) return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
+    // 4-wave workgroups: a 2-stage ring (53 kB) lets 3 workgroups share a CU, a 3-stage ring (80 kB) 2.  More
+    // independent workgroups per CU hide each other's barrier bubbles better than a deeper ring does (measured:
+    // proj 32 vs 35 us, fc2 57 vs 61 us at D = 544), unless 3 per CU quantises badly (1024 workgroups = 1.33
+    // rounds of 768 slots): pick the occupancy with the fewer CU-time units, ties go to 3 per CU.
+    const int wgs = gm * ((N + BN - 1) / BN);
+    auto cost = [&](int k) {
+        const int rounds = (wgs + 256 * k - 1) / (256 * k);
+        const int per_cu = (wgs + 255) / 256;
+        return rounds * (per_cu < k ? per_cu : k);
+    };
+    if (cost(3) <= cost(2)) return launch_ng<EPI, LN, 1, 1, 1, 2>(MPL_ARGS2);
+    return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);
 #undef MPL_ARGS2
 }
 
