@@ -68,14 +68,23 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     // epilogues of proj (-> norm2) and fc2 (-> norm1 of the next application).
     float* st_out = (D % 136 == 0) ? w.stats : nullptr;
     bool have_stats = false;
+    // qkv projection and attention run as one kernel when a 64-row tile holds whole sequences and a 136-column
+    // slice whole heads (V in {1,2,4,8,16,32,64}; hd in {68,136}); otherwise as two kernels through `qkv`
+    const bool fused_att = qkv_attention_fusable(n_tok, D, H);
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
-        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                 3 * D, D, MPL_EPI_BIAS, nullptr, s)))
-            return rc;
-        if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
+        if (fused_att) {
+            if ((rc = launch_ln_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, n_tok, H, w.att,
+                                              s)))
+                return rc;
+        } else {
+            if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
+                                     3 * D, D, MPL_EPI_BIAS, nullptr, s)))
+                return rc;
+            if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
+        }
         if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
                                  MPL_EPI_BIAS_RESIDUAL, st_out, s)))
             return rc;

@@ -62,6 +62,10 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStr
 int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
                    const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
                    int epi, float* stats_out, hipStream_t s);
+bool qkv_attention_fusable(int n_tok, int dim, int heads);
+int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
+                            float eps, const float* W, const float* bias, int n_tok, int heads, float* att,
+                            hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out,

@@ -173,6 +173,7 @@ __device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], cons
 // The DMA is issued from inline asm: with the builtin hipcc assumes the LDS write aliases every later ds_read
 // and drains vmcnt(0) in front of it; the asm DMA is invisible to the compiler's counters and is tracked by the
 // explicit counted waits.  LayerNorm is applied when the A fragment is read.
+constexpr int ATT_SCORE_FLOATS = 3584;  // LDS left for attention scores beside the 64 x 412 q|k|v tile in a 2 x 60 kB ring
 constexpr int SUB_A = BM * BK * 4;   // 8192 bytes
 constexpr int SUB_B = BN * BK * 4;   // 17408 bytes per column group
 template <int NG> struct SubStage {
@@ -232,7 +233,11 @@ __device__ __forceinline__ void load_frag(Frag& f, const char* st, int step, int
     }
 }
 
-template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0>
+// ATT (QKV projection only, NG = 3): the three column groups of a workgroup are the q, k and v slices of the SAME
+// 136 attention channels (column base cg * D + tn * 136 instead of three adjacent tiles), so the workgroup owns
+// q, k, v of 136 / hd heads for its 64 rows = 64 / n_tok whole sequences and finishes Attention.forward :55-64
+// in its epilogue (scores, softmax, P.V through LDS): the packed qkv tensor never goes to memory.
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false>
 __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const float* __restrict__ A, int lda,
                                                                        const float* __restrict__ stats,
                                                                        const float* __restrict__ ln_w,
@@ -241,7 +246,9 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
                                                                        const float* __restrict__ bias, const float* R,
                                                                        int ldr, float* C, int ldc, int M, int N, int K,
                                                                        int grid_m, int grid_n, float eps,
-                                                                       float* stats_out) {
+                                                                       float* stats_out, int att_ntok, int att_hd,
+                                                                       float* att_out) {
+    static_assert(!ATT || (NG == 3 && KG == 1 && EPI == MPL_EPI_BIAS), "fused attention needs the q|k|v geometry");
     typedef SubStage<NG> SS;
     constexpr int NW = 4 * NG * KG;                  // waves: 4 row groups x NG column groups x KG k groups
     constexpr int STAGE = KS * SS::BYTES;
@@ -273,7 +280,9 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         }
     }
     const int m0 = tm * BM;
-    const int n0 = tn * (BN * NG);
+    const int n0 = ATT ? tn * BN : tn * (BN * NG);
+    const int Dq = N / 3;                                    // ATT: width of each of q, k, v
+    auto colbase = [&](int g) -> int { return ATT ? g * Dq + n0 : n0 + g * BN; };   // first column of group g
 
     float mu = 0.f, rs = 1.f;
     if (LN) {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         } else if (p < 8 + 17 * NG) {
             const int r = (p - 8) * 8 + (lane >> 3);            // row inside the NG*136-row B slab
             const int rr = r % BN;                              // row inside its column group (swizzle key)
-            int n = n0 + r;
+            int n = colbase(r / BN) + rr;
             n = n < N ? n : N - 1;
             g = W + (size_t)n * K + 4 * ((lane & 7) ^ ((rr >> 1) & 7));
         } else {  // gamma | beta slice (lanes >= 16 re-load the same 256 B: finite filler)
@@ -420,30 +429,103 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         if (sacc == 12345.678f) C[tid] = sacc;
         return;
     }
-    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, n0 + cg * BN, li, stats_out,
-                             N / BN);
+    if (ATT) {
+        // ---- fused attention epilogue.  T[64][412]: q | k | v (+bias) of this workgroup's 136 channels.
+        constexpr int TS = 3 * BN + 4;                      // row stride (floats); +4 breaks the bank alignment
+        float* T = reinterpret_cast<float*>(smem);
+        float* SC = T + BM * TS;                            // scores [S][HP][n_tok][n_tok]
+        __syncthreads();                                    // every wave is done reading the last stage
+        {
+            const int cb = colbase(cg);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c = n * 16 + li;
+                if (c < BN) {
+                    const float bv = bias[cb + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(rg * 16 + 4 * kq + r) * TS + cg * BN + c] = acc[n][r] + bv;
+                }
+            }
+        }
+        __syncthreads();
+        const int nt = att_ntok, hd = att_hd, hd4 = hd >> 2;
+        const int HP = BN / hd, S = BM / nt, nn = nt * nt;
+        const float scale = 1.0f / sqrtf((float)hd);
+        constexpr int NTH = 256 * NG * KG;
+        for (int t = tid; t < S * HP * nn; t += NTH) {
+            const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
+            const float* q = T + (sq * nt + i) * TS + hh * hd;
+            const float* k = T + (sq * nt + j) * TS + BN + hh * hd;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int e = 0; e < hd4; ++e) {
+                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+                s0 = fmaf(a.x, b.x, s0);
+                s1 = fmaf(a.y, b.y, s1);
+                s2 = fmaf(a.z, b.z, s2);
+                s3 = fmaf(a.w, b.w, s3);
+            }
+            SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
+        }
+        __syncthreads();
+        for (int t = tid; t < S * HP * nt; t += NTH) {
+            float* pr = SC + t * nt;
+            float mx = pr[0];
+            for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
+            float l = 0.f;
+            for (int j = 0; j < nt; ++j) {
+                const float e = __expf(pr[j] - mx);
+                pr[j] = e;
+                l += e;
+            }
+            const float inv = 1.0f / l;
+            for (int j = 0; j < nt; ++j) pr[j] *= inv;
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;                          // 34 float4 per output row slice
+        for (int t = tid; t < BM * C4; t += NTH) {
+            const int c = t % C4, row = t / C4;
+            const int sq = row / nt, i = row - sq * nt;
+            const int hh = (4 * c) / hd;
+            const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
+            const float* v = T + (sq * nt) * TS + 2 * BN + 4 * c;
+            float4 o = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < nt; ++j) {
+                const float4 vv = ld4(v + j * TS);
+                const float pj = pr[j];
+                o.x = fmaf(pj, vv.x, o.x);
+                o.y = fmaf(pj, vv.y, o.y);
+                o.z = fmaf(pj, vv.z, o.z);
+                o.w = fmaf(pj, vv.w, o.w);
+            }
+            if (m0 + row < M) st4(att_out + (size_t)(m0 + row) * Dq + n0 + 4 * c, o);
+        }
+        return;
+    }
+    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li, stats_out, N / BN);
 }
 
-template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0>
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false>
 static int launch_ng(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
                      const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, float eps,
-                     float* stats_out, hipStream_t s) {
+                     float* stats_out, hipStream_t s, int att_ntok = 0, int att_hd = 0, float* att_out = nullptr) {
     constexpr int LDS = NST * KS * SubStage<NG>::BYTES;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static_assert((KG - 1) * NG * 4 * NT * 4 * 64 * 4 <= LDS, "k-group reduction does not fit in the ring");
     const int gm = (M + BM - 1) / BM, gn = (N + BN * NG - 1) / (BN * NG);
+    static_assert(!ATT || (BM * (3 * BN + 4) + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL>,
+        if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MPL_E_LAUNCH;
         attr_set[dev] = true;
     }
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL>), dim3(gm * gn), dim3(256 * NG * KG), LDS, s, A,
-                       lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out);
+    hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT>), dim3(gm * gn), dim3(256 * NG * KG), LDS, s,
+                       A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out, att_ntok,
+                       att_hd, att_out);
     return hip_check_launch();
 }
 
@@ -494,6 +576,23 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
     if (cost(3) <= cost(2)) return launch_ng<EPI, LN, 1, 1, 1, 2>(MPL_ARGS2);
     return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);
 #undef MPL_ARGS2
+}
+
+// LN1 + qkv projection + softmax attention in one launch: att[M, D] from x[M, D].  Requirements (else the caller
+// uses the separate kernels): 136 % hd == 0, 64 % n_tok == 0, D % 136 == 0.
+bool qkv_attention_fusable(int n_tok, int dim, int heads) {
+    static const bool off = getenv("MPL_NO_ATT_FUSION") != nullptr;   // bench-only A/B switch
+    if (off || heads <= 0 || dim % heads) return false;
+    const int hd = dim / heads;
+    return dim % BN == 0 && BN % hd == 0 && (hd & 3) == 0 && n_tok >= 1 && BM % n_tok == 0 && n_tok * n_tok * (BN / hd) * (BM / n_tok) <= ATT_SCORE_FLOATS;
+}
+
+int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
+                            float eps, const float* W, const float* bias, int n_tok, int heads, float* att,
+                            hipStream_t s) {
+    if (!qkv_attention_fusable(n_tok, D, heads) || !stats || !ln_w || !ln_b) return MPL_E_INVALID;
+    return launch_ng<MPL_EPI_BIAS, true, 3, 1, 1, 2, 0, true>(x, D, stats, ln_w, ln_b, W, bias, nullptr, 0, nullptr, 0, M,
+                                                               3 * D, D, eps, nullptr, s, n_tok, D / heads, att);
 }
 
 int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
