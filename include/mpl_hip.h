@@ -56,7 +56,7 @@ extern "C" {
 #define MPL_F_NO_SPT (1u << 8)          /* no_transformer_spt */
 #define MPL_F_NO_FPT (1u << 9)          /* no_transformer_fpt */
 #define MPL_F_CONF_IN_FPT (1u << 10)    /* confidence_in_FPT */
-#define MPL_F_KPTOK (1u << 11)          /* FPT_blocks_view_keypoint_tokens */
+#define MPL_F_KPTOK (1u << 11)          /* FPT_blocks_view_keypoint_tokens: FPT blocks of width d over 17*V tokens */
 
 /* epilogues of mpl_ln_linear */
 #define MPL_EPI_BIAS 0          /* y = a W^T + b                       (attn.qkv) */
@@ -154,6 +154,29 @@ int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int hea
 /* Stage 3: strip ray features, View_norm, Conv1d weighted mean over views, head LN + Linear.
  * x (B*V, D_f) -> out (B, 3J).  forward_features :425-446, head :521-523. */
 int mpl_fuse_head(const mpl_config *cfg, const mpl_weights *w, const float *x, int batch, float *out, void *stream);
+
+/* ---- output-side variants (constructor flags linear_weighted_mean, deep_head, head_kadkhod; :277-317, :506-519).
+ * The default tail stays fused in mpl_fuse_head / mpl_forward; these building blocks let the binding compose the
+ * other tails exactly as the reference does. */
+
+/* strip ray features + View_norm + Conv1d weighted mean (:425-446) WITHOUT the head: x (B*V, D_f) -> y (B, J*d). */
+int mpl_view_fuse(const mpl_config *cfg, const mpl_weights *w, const float *x, int batch, float *y, void *stream);
+
+/* strip ray features + View_norm only (:425-439): x (B*V, D_f) -> xn (B, V*J*d), the input of the
+ * linear_weighted_mean Linear (:441-443). */
+int mpl_view_norm(const mpl_config *cfg, const mpl_weights *w, const float *x, int batch, float *xn, void *stream);
+
+/* y[M,K] = LayerNorm(x[M,K]) (head[0] of every head variant, eps 1e-5). */
+int mpl_layernorm(const float *x, int M, int K, const float *gamma, const float *beta, float eps, float *y,
+                  void *stream);
+
+/* y[M,N] = act( bn( [xa | xb] . W^T + bias ) ): nn.Linear on the concatenation of xa (M,Ka) and xb (M,Kb; may be
+ * NULL/0) -- torch.cat([x_prev, x], dim=1) of head_kadkhod :511-513 without materialising it -- followed by an
+ * optional BatchNorm1d in eval mode (running statistics, bn_w == NULL skips it) and an optional ReLU.
+ * W is (N, Ka+Kb) row-major. */
+int mpl_linear(const float *xa, int Ka, const float *xb, int Kb, int M, const float *W, const float *bias, int N,
+               const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var, float bn_eps, int relu,
+               float *y, void *stream);
 
 /* Measurement aid (bench.py roofline leg): between start and stop every kernel launched by this
  * library on ANY stream is bracketed by a hipEvent pair recorded on that same stream.  stop()

@@ -104,7 +104,6 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
 int check_cfg(const mpl_config* cfg) {
     if (!cfg) return MPL_E_INVALID;
     if (cfg->num_views < 1 || cfg->num_views > MPL_MAX_VIEWS || cfg->depth < 0 || cfg->depth > 60) return MPL_E_INVALID;
-    if (cfg->flags & MPL_F_KPTOK) return MPL_E_UNSUPPORTED;  // SURVEY.md 8f rank f1, not built yet
     return MPL_OK;
 }
 
@@ -162,7 +161,10 @@ size_t mpl_block_stack_workspace_bytes(int n_seq, int n_tok, int dim) {
 size_t mpl_forward_workspace_bytes(const mpl_config* cfg, int batch) {
     if (!cfg || batch <= 0) return 0;
     const size_t M = (size_t)batch * cfg->num_views, D = (size_t)mpl_fpt_width(cfg);
-    return align_up(M * D * sizeof(float), 256) + carve_stack_ws(nullptr, M, D).bytes;
+    // joints x views token grid (:496-497): the same xs memory seen as (B, V*J, d)
+    const bool kp = (cfg->flags & MPL_F_KPTOK) != 0;
+    const size_t Ms = kp ? M * cfg->num_joints : M, Ds = kp ? (size_t)cfg->dim : D;
+    return align_up(M * D * sizeof(float), 256) + carve_stack_ws(nullptr, Ms, Ds).bytes;
 }
 
 int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, void* stream) {
@@ -200,7 +202,34 @@ int mpl_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, i
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !out) return MPL_E_INVALID;
-    return launch_fuse_head(cfg, w, x, batch, out, (hipStream_t)stream);
+    return launch_fuse_head(cfg, w, x, batch, out, nullptr, (hipStream_t)stream);
+}
+
+int mpl_view_fuse(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* y, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || !x || !y) return MPL_E_INVALID;
+    return launch_fuse_head(cfg, w, x, batch, nullptr, y, (hipStream_t)stream);
+}
+
+int mpl_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* xn, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || !x || !xn || batch <= 0) return MPL_E_INVALID;
+    return launch_view_norm(cfg, w, x, batch, xn, (hipStream_t)stream);
+}
+
+int mpl_layernorm(const float* x, int M, int K, const float* gamma, const float* beta, float eps, float* y,
+                  void* stream) {
+    if (!x || !gamma || !beta || !y) return MPL_E_INVALID;
+    return launch_layernorm_rows(x, M, K, K, gamma, beta, eps, y, K, (hipStream_t)stream);
+}
+
+int mpl_linear(const float* xa, int Ka, const float* xb, int Kb, int M, const float* W, const float* bias, int N,
+               const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, int relu,
+               float* y, void* stream) {
+    return launch_linear_act(xa, Ka, Ka, xb, Kb, Kb, M, W, Ka + Kb, bias, N, bn_w, bn_b, bn_mean, bn_var, bn_eps, relu, y, N,
+                             (hipStream_t)stream);
 }
 
 int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* out, void* workspace,
@@ -227,9 +256,12 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
             if (l == cfg->depth - 1) sched[n++] = (uint8_t)l;
             sched[n++] = (uint8_t)l;
         }
-        if ((rc = block_stack_impl(xs, B, V, D, cfg->heads, w->fpt_blocks, sched, n, rest, rest_bytes, s))) return rc;
+        const bool kp = (cfg->flags & MPL_F_KPTOK) != 0;
+        if ((rc = block_stack_impl(xs, B, kp ? V * cfg->num_joints : V, kp ? cfg->dim : D, cfg->heads, w->fpt_blocks,
+                                   sched, n, rest, rest_bytes, s)))
+            return rc;
     }
-    return launch_fuse_head(cfg, w, xs, B, out, s);
+    return launch_fuse_head(cfg, w, xs, B, out, nullptr, s);
 }
 
 }  // extern "C"

@@ -68,7 +68,14 @@ int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, co
                             hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
-int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out,
+// y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]
+int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,
                      hipStream_t s);
+int launch_layernorm_rows(const float* x, int M, int K, int ldx, const float* g, const float* b, float eps, float* y,
+                          int ldy, hipStream_t s);
+int launch_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* xn, hipStream_t s);
+int launch_linear_act(const float* xa, int Ka, int lda, const float* xb, int Kb, int ldb, int M, const float* W, int ldw,
+                      const float* bias, int N, const float* bn_w, const float* bn_b, const float* bn_mean,
+                      const float* bn_var, float bn_eps, int relu, float* y, int ldy, hipStream_t s);
 
 }  // namespace mpl

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
                                                          const float* __restrict__ wm_w, const float* __restrict__ wm_b,
                                                          const float* __restrict__ hl_w, const float* __restrict__ hl_b,
                                                          const float* __restrict__ hw, const float* __restrict__ hb,
-                                                         int n_out, float* __restrict__ out) {
+                                                         int n_out, float* __restrict__ out,
+                                                         float* __restrict__ y_out) {
     __shared__ float y[kMaxE];
     __shared__ float vstat[MPL_MAX_VIEWS][2];
     __shared__ float red[4];
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
         y[f] = acc;
         part += acc;
     }
+    if (y_out) {  // caller wants the fused (B, E) feature only (non-default heads): stop before head[0]
+        __syncthreads();
+        for (int f = tid; f < E; f += 256) y_out[(size_t)b * E + f] = y[f];
+        return;
+    }
     // head LayerNorm (eps 1e-5), two-pass over LDS
     const float mean = block_sum(part, red) / (float)E;
     float p2 = 0.f;
@@ -90,12 +96,11 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
     }
 }
 
-int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out,
+int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,
                      hipStream_t s) {
     const int J = cfg->num_joints, d = cfg->dim, V = cfg->num_views;
     const int E = J * d;
     if (E > kMaxE || V > MPL_MAX_VIEWS || batch <= 0) return MPL_E_UNSUPPORTED;
-    if (cfg->flags & MPL_F_KPTOK) return MPL_E_UNSUPPORTED;
     int strip = 0;
     if (cfg->flags & MPL_F_POS3D_TO_RAYS) strip = 1;           // :430-434 (takes precedence, elif order)
     else if (cfg->flags & MPL_F_RAYS_TOKEN) strip = 2;         // :425-429
@@ -103,7 +108,7 @@ int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x
     ProfScope prof(MPL_K_FUSE_HEAD, s);
     hipLaunchKernelGGL(fuse_head_kernel, dim3(batch), dim3(256), 0, s, x, V, Df, E, d, strip, w->view_norm_w,
                        w->view_norm_b, w->wmean_w, w->wmean_b, w->head_ln_w, w->head_ln_b, w->head_w, w->head_b, 3 * J,
-                       out);
+                       out, y_out);
     return hip_check_launch();
 }
 

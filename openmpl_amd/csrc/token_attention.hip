@@ -155,11 +155,83 @@ __global__ __launch_bounds__(256) void token_attention_lds_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Long sequences with a tiny head (the joints x views token grid, FPT_blocks_view_keypoint_tokens :261-266:
+// n_tok = 17 V up to 527 tokens, D = 32, hd = 4): one workgroup per (sequence, head) keeps that head's K and V
+// rows in LDS (n_tok x hd floats each) and every thread owns query rows, streaming the keys twice (max pass,
+// then exp / accumulate pass) -- two-pass softmax like the reference, no score matrix anywhere.
+template <int HD4>
+__global__ __launch_bounds__(256) void token_attention_long_kernel(const float* __restrict__ qkv,
+                                                                    float* __restrict__ out, int n_tok, int D, int H,
+                                                                    float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int HD = 4 * HD4;
+    const int sq = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)sq * n_tok * ld + (size_t)h * HD;
+    float* Ks = sm;
+    float* Vs = sm + (size_t)n_tok * HD;
+    for (int i = threadIdx.x; i < n_tok * HD4; i += 256) {
+        const int r = i / HD4, c = i % HD4;
+        st4(Ks + r * HD + 4 * c, ld4(base + r * ld + D + 4 * c));
+        st4(Vs + r * HD + 4 * c, ld4(base + r * ld + 2 * D + 4 * c));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tok; i += 256) {
+        float4 q[HD4];
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) q[c] = ld4(base + i * ld + 4 * c);
+        auto score = [&](int j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) {
+                const float4 k = ld4(Ks + j * HD + 4 * c);
+                s += fmaf(q[c].x, k.x, q[c].y * k.y) + fmaf(q[c].z, k.z, q[c].w * k.w);
+            }
+            return s * scale;
+        };
+        float mx = -INFINITY;
+        for (int j = 0; j < n_tok; ++j) mx = fmaxf(mx, score(j));
+        float l = 0.f;
+        float4 o[HD4];
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) o[c] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < n_tok; ++j) {
+            const float e = __expf(score(j) - mx);
+            l += e;
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) {
+                const float4 v = ld4(Vs + j * HD + 4 * c);
+                o[c].x = fmaf(e, v.x, o[c].x);
+                o[c].y = fmaf(e, v.y, o[c].y);
+                o[c].z = fmaf(e, v.z, o[c].z);
+                o[c].w = fmaf(e, v.w, o[c].w);
+            }
+        }
+        const float inv = 1.0f / l;
+        float* op = out + ((size_t)sq * n_tok + i) * D + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) st4(op + 4 * c, float4{o[c].x * inv, o[c].y * inv, o[c].z * inv, o[c].w * inv});
+    }
+}
+
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s) {
     if (n_seq <= 0 || n_tok <= 0 || heads <= 0 || dim % heads) return MPL_E_INVALID;
     const int hd = dim / heads;
     if (hd & 3) return MPL_E_UNSUPPORTED;
-    if (n_tok > 32) return MPL_E_UNSUPPORTED;
+    if (n_tok > 32) {
+        if ((hd != 4 && hd != 8) || (size_t)n_tok * hd * 8 > 64 * 1024) return MPL_E_UNSUPPORTED;
+        const float sc = 1.0f / sqrtf((float)hd);
+        ProfScope prof(MPL_K_ATTENTION, s);
+        const size_t lds = (size_t)n_tok * hd * 8;
+        if (hd == 4)
+            hipLaunchKernelGGL((token_attention_long_kernel<1>), dim3(n_seq * heads), dim3(256), lds, s, qkv, out, n_tok, dim,
+                               heads, sc);
+        else
+            hipLaunchKernelGGL((token_attention_long_kernel<2>), dim3(n_seq * heads), dim3(256), lds, s, qkv, out, n_tok, dim,
+                               heads, sc);
+        return hip_check_launch();
+    }
     const float scale = 1.0f / sqrtf((float)hd);
     const int total = n_seq * n_tok * heads;
     ProfScope prof(MPL_K_ATTENTION, s);

@@ -227,12 +227,10 @@ class MultiView_MPL(nn.Module):
             return "HIP kernels are specialised for NUM_JOINTS=17, DIM=32, HEADS=8 (every shipped yaml)"
         if self.num_views > cabi.MPL_MAX_VIEWS:
             return "num_views > %d" % cabi.MPL_MAX_VIEWS
-        if self.FPT_blocks_view_keypoint_tokens:
-            return "FPT_blocks_view_keypoint_tokens (joints x views grid, SURVEY.md 8f rank f1)"
-        if self.linear_weighted_mean:
-            return "linear_weighted_mean"
-        if self.deep_head or self.head_kadkhod:
-            return "deep_head / head_kadkhod output heads"
+        if self.FPT_blocks_view_keypoint_tokens and self.input_rays_as_token:
+            return "FPT_blocks_view_keypoint_tokens with input_rays_as_token (the reference itself fails: LN(32) on 64)"
+        if self.FPT_blocks_view_keypoint_tokens and self.num_joints * self.num_views * (self.embed_dim_ratio // self.num_heads) * 8 > 64 * 1024:
+            return "joints x views grid too long for the LDS-resident K/V of one head"
         if self.add_3D_pos_encoding_to_rays and not self.input_rays_as_token:
             return "add_3D_pos_encoding_to_rays without input_rays_as_token (the reference itself fails, :483)"
         if self.add_3D_pos_encoding_to_rays and self.add_3D_pos_encoding_in_Spatial:
@@ -297,8 +295,9 @@ class MultiView_MPL(nn.Module):
             out += [self.ray_to_embedding.weight, self.ray_to_embedding.bias]
         if self.confidence_in_FPT:
             out += [self.confidence_to_embedding_FPT.weight, self.confidence_to_embedding_FPT.bias]
-        if not (self.deep_head or self.head_kadkhod):
-            out += [self.head[0].weight, self.head[0].bias, self.head[1].weight, self.head[1].bias]
+        # heads: parameters and (BatchNorm) running statistics, in module order
+        out += [t for t in self.head.parameters()]
+        out += [b for n, b in self.head.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
         return out
 
     def _marshal(self, device: torch.device):
@@ -355,7 +354,7 @@ class MultiView_MPL(nn.Module):
         if not (self.deep_head or self.head_kadkhod):
             w.head_ln_w, w.head_ln_b = _ptr(self.head[0].weight), _ptr(self.head[0].bias)
             w.head_w, w.head_b = _ptr(self.head[1].weight), _ptr(self.head[1].bias)
-        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks), cfg=self._config())
+        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks), cfg=self._config(), fpt_blocks=fpt)
         self._hip_cache[device.index] = ent
         return ent
 
@@ -412,16 +411,93 @@ class MultiView_MPL(nn.Module):
                 inp.poses[v] = poses[v].data_ptr()
                 inp.rays[v] = _ptr(rays[v])
                 inp.centers[v] = _ptr(centers[v])
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if self.linear_weighted_mean or self.deep_head or self.head_kadkhod:
+                return self._forward_staged(lib, ent, inp, B, dev, stream)
             ws_bytes = lib.mpl_forward_workspace_bytes(C.byref(cfg), B)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             out = torch.empty((B, self.num_joints, 3), dtype=torch.float32, device=dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
             rc = lib.mpl_forward(C.byref(cfg), C.byref(ent["weights"]), C.byref(inp), out.data_ptr(), ws.data_ptr(),
                                  ws_bytes, stream)
             cabi.check(rc, "mpl_forward")
             # ws / out are allocated and consumed on the current stream, so the caching allocator's
             # stream-ordered reuse keeps them alive for the enqueued kernels without a record_stream.
         return out
+
+
+    # ------------------------------------------------------------------ non-default tails (reference :441-443, :506-519)
+    def _forward_staged(self, lib, ent, inp, B, dev, stream):
+        """linear_weighted_mean / deep_head / head_kadkhod: the same SPT and FPT kernels as mpl_forward, then the
+        tail composed from the C-ABI building blocks (mpl_view_norm / mpl_view_fuse / mpl_layernorm / mpl_linear)."""
+        cfg, w = ent["cfg"], ent["weights"]
+        J, V, E = self.num_joints, self.num_views, self.num_joints * self.embed_dim_ratio
+        Df = lib.mpl_fpt_width(C.byref(cfg))
+        f32 = dict(dtype=torch.float32, device=dev)
+        xs = torch.empty((B * V, Df), **f32)
+        cabi.check(lib.mpl_spt_tokens(C.byref(cfg), C.byref(w), C.byref(inp), xs.data_ptr(), stream), "mpl_spt_tokens")
+        if len(self.blocks) > 0:
+            kp = self.FPT_blocks_view_keypoint_tokens
+            n_tok, dim = (V * J, self.embed_dim_ratio) if kp else (V, Df)
+            order = [l for l in range(self.depth)] + [self.depth - 1]          # last block twice (:420-423)
+            sched = (C.c_uint8 * len(order))(*order)
+            ws_bytes = lib.mpl_block_stack_workspace_bytes(B, n_tok, dim)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            cabi.check(lib.mpl_block_stack(xs.data_ptr(), B, n_tok, dim, self.num_heads, ent["fpt_blocks"], sched,
+                                           len(order), ws.data_ptr(), ws_bytes, stream), "mpl_block_stack")
+        y = torch.empty((B, E), **f32)
+        if self.linear_weighted_mean:                                           # :441-443
+            xn = torch.empty((B, V * E), **f32)
+            cabi.check(lib.mpl_view_norm(C.byref(cfg), C.byref(w), xs.data_ptr(), B, xn.data_ptr(), stream), "mpl_view_norm")
+            self._lin(lib, stream, xn, None, self.weighted_mean, None, False, y)
+        else:                                                                   # :445
+            cabi.check(lib.mpl_view_fuse(C.byref(cfg), C.byref(w), xs.data_ptr(), B, y.data_ptr(), stream), "mpl_view_fuse")
+
+        def ln(x, mod):
+            o = torch.empty_like(x)
+            cabi.check(lib.mpl_layernorm(x.data_ptr(), x.shape[0], x.shape[1], mod.weight.data_ptr(), mod.bias.data_ptr(),
+                                         float(mod.eps), o.data_ptr(), stream), "mpl_layernorm")
+            return o
+
+        def lin(xa, xb, mod, bn=None, relu=False):
+            o = torch.empty((B, mod.out_features), **f32)
+            self._lin(lib, stream, xa, xb, mod, bn, relu, o)
+            return o
+
+        if self.head_kadkhod:                                                   # :506-516
+            def stage(seq, prev):
+                first = seq[0]
+                if prev is None:                                                # Sequential(LN, Linear, BN, ReLU)
+                    h = lin(ln(y, first[0]), None, first[1], first[2], True)
+                else:                                                           # Sequential(Linear, BN, ReLU) on cat([prev, x])
+                    h = lin(prev, y, first[0], first[1], True)
+                h = lin(h, None, seq[1][0], seq[1][1], True)
+                h = lin(h, None, seq[2][0], seq[2][1], True)
+                return lin(h, None, seq[3])
+            x1 = stage(self.head[0], None)
+            x2 = stage(self.head[1], x1)
+            x3 = stage(self.head[2], x2)
+            return x3.view(B, -1, 3), [x1.view(B, -1, 3), x2.view(B, -1, 3)]
+        if self.deep_head:                                                      # :517-519
+            hd = self.head
+            h = lin(ln(y, hd[0]), None, hd[1], hd[2], True)
+            h = lin(h, None, hd[4], hd[5], True)
+            h = lin(h, None, hd[7], hd[8], True)
+            return lin(h, None, hd[10]).view(B, -1, 3)
+        return lin(ln(y, self.head[0]), None, self.head[1]).view(B, -1, 3)     # default head after linear_weighted_mean
+
+    @staticmethod
+    def _lin(lib, stream, xa, xb, mod, bn, relu, out):
+        ka = xa.shape[1]
+        kb = 0 if xb is None else xb.shape[1]
+        if ka + kb != mod.in_features:
+            raise RuntimeError("linear layer expects %d inputs, got %d" % (mod.in_features, ka + kb))
+        cabi.check(lib.mpl_linear(xa.data_ptr(), ka, None if xb is None else xb.data_ptr(), kb, xa.shape[0],
+                                  mod.weight.data_ptr(), mod.bias.data_ptr(), mod.out_features,
+                                  None if bn is None else bn.weight.data_ptr(), None if bn is None else bn.bias.data_ptr(),
+                                  None if bn is None else bn.running_mean.data_ptr(),
+                                  None if bn is None else bn.running_var.data_ptr(),
+                                  1e-5 if bn is None else float(bn.eps), 1 if relu else 0, out.data_ptr(), stream),
+                   "mpl_linear")
 
 
 class MultiView_MPL_G(nn.Module):

@@ -95,7 +95,7 @@ def test_no_cpu_fallback_and_loud_errors():
     m.train()
     with pytest.raises(RuntimeError, match="inference forward only"):
         m(x)
-    k = MultiView_MPL(num_views=2, depth=1, FPT_blocks_view_keypoint_tokens=True).eval()
+    k = MultiView_MPL(num_views=2, depth=1, FPT_blocks_view_keypoint_tokens=True, input_rays_as_token=True).eval()
     with pytest.raises(NotImplementedError):
         k(x)
     with pytest.raises(RuntimeError, match="parameter container"):
