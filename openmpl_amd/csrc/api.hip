@@ -2,6 +2,8 @@
 // One mpl_forward call enqueues the whole forward on the caller's stream; nothing synchronises.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 #include <vector>
 
 using namespace mpl;
@@ -190,7 +192,10 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
         int rc = launch_row_stats(x, M, K, K, stats, s);
         if (rc) return rc;
     }
-    return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue, nullptr, s);
+    // bench-only: with MPL_GEMM_ABL=4 (tools/gemm_phase.py) the scratch pointer receives per-wave phase timings
+    static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
+    return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue,
+                          (timing && !ln_w) ? stats : nullptr, s);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {

@@ -197,6 +197,25 @@ __device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
         : "memory");
 }
 
+// Fast form for the A / W pieces: address = 64-bit SGPR base (advanced by the k offset once per stage) + 32-bit
+// per-lane VGPR offset that never changes, so a piece costs three instructions.  M0 is saved / restored once
+// per group by the caller (dma_m0_save / dma_m0_restore).
+__device__ __forceinline__ void dma16_fast(unsigned voff, const float* sbase, unsigned lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ unsigned dma_m0_save() {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+    return keep;
+}
+__device__ __forceinline__ void dma_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
+
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vm(int n) {
 #define MPL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -252,13 +271,12 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
     typedef SubStage<NG> SS;
     constexpr int NW = 4 * NG * KG;                  // waves: 4 row groups x NG column groups x KG k groups
     constexpr int STAGE = KS * SS::BYTES;
-    constexpr int P_SUB = LN ? SS::PIECES : SS::PIECES - 1;
-    constexpr int P_STAGE = KS * P_SUB;              // DMA pieces per full stage
-    constexpr int SLOTS = (P_STAGE + NW - 1) / NW;   // pieces per wave per stage (max)
     constexpr int SPW = (2 * KS) / KG;               // 16-deep k steps per wave per full stage
     static_assert(SPW * KG == 2 * KS, "k groups must divide the steps of a stage");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
+    const unsigned long long t_entry = (ABL & 4) ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_real = (ABL & 4) ? __builtin_amdgcn_s_memrealtime() : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,46 +319,66 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         }
     }
 
-    // ---- DMA piece table of this wave: stage piece q = ks * P_SUB + p  ->  wave q % NW, slot q / NW
-    const float* src[SLOTS];
-    unsigned dst[SLOTS];
+    // ---- DMA piece table of this wave.  Per k-tile: 8 A pieces, 17*NG W pieces, (LN) one gamma/beta piece, dealt
+    // so that the slot TYPE is a compile-time property (no per-piece control flow):
+    //   A slot a   : piece a*NW + wave                      (a < A_PER; valid when < 8)
+    //   W slot b   : piece b*NW + wave of the W slab        (b < W_FULL, always valid)
+    //   W extra    : piece W_FULL*NW + wave                 (only waves < W_REM)
+    //   gamma/beta : last wave only (generic 64-bit-address form: two unrelated base pointers in one wave)
+    // A / W pieces use the fast form: wave-uniform 64-bit base in SGPRs + constant per-lane 32-bit byte offset.
+    constexpr int A_PER = (8 + NW - 1) / NW;
+    constexpr int W_FULL = (17 * NG) / NW;
+    constexpr int W_REM = (17 * NG) % NW;
+    unsigned voA[A_PER], voW[W_FULL + 1];
 #pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-        const int q = sl * NW + wave;
-        const int ks = q / P_SUB, p = q - ks * P_SUB;
-        const float* g;
-        if (p < 8) {
-            const int r = p * 8 + (lane >> 3);
-            int m = m0 + r;
-            m = m < M ? m : M - 1;
-            g = A + (size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
-        } else if (p < 8 + 17 * NG) {
-            const int r = (p - 8) * 8 + (lane >> 3);            // row inside the NG*136-row B slab
-            const int rr = r % BN;                              // row inside its column group (swizzle key)
-            int n = colbase(r / BN) + rr;
-            n = n < N ? n : N - 1;
-            g = W + (size_t)n * K + 4 * ((lane & 7) ^ ((rr >> 1) & 7));
-        } else {  // gamma | beta slice (lanes >= 16 re-load the same 256 B: finite filler)
-            g = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);
-        }
-        src[sl] = g + ks * BK;
-        dst[sl] = (unsigned)(ks * SS::BYTES + p * 1024);
+    for (int a = 0; a < A_PER; ++a) {
+        const int r = (a * NW + wave) * 8 + (lane >> 3);
+        int m = m0 + r;
+        m = m < M ? m : M - 1;
+        voA[a] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+        asm volatile("" : "+v"(voA[a]));   // opaque: keep it in a register instead of re-deriving it every stage
     }
+#pragma unroll
+    for (int b = 0; b < W_FULL + 1; ++b) {
+        int pw = b * NW + wave;
+        pw = pw < 17 * NG ? pw : 17 * NG - 1;
+        const int r = pw * 8 + (lane >> 3);                 // row inside the NG*136-row B slab
+        const int rr = r % BN;                              // row inside its column group (swizzle key)
+        int n = colbase(r / BN) + rr;
+        n = n < N ? n : N - 1;
+        voW[b] = (unsigned)(((size_t)n * K + 4 * ((lane & 7) ^ ((rr >> 1) & 7))) * sizeof(float));
+        asm volatile("" : "+v"(voW[b]));
+    }
+    const float* gb_src = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);   // lanes >= 16 re-load the same 256 B
+    const bool a_on = A_PER * NW <= 8 || wave < 8 - (A_PER - 1) * NW;     // last A slot valid for this wave?
+    const bool w_extra = wave < W_REM;
+    const bool gb_on = LN && wave == NW - 1;
+    const int per_sub = (A_PER - 1) + (a_on ? 1 : 0) + W_FULL + (w_extra ? 1 : 0) + (gb_on ? 1 : 0);
     const int KT = K / BK;                      // k-tiles
     const int T = (KT + KS - 1) / KS;           // stages
     const int last_sub = KT - (T - 1) * KS;     // valid sub-tiles of the last stage
     auto pieces_of = [&](int t) -> int {        // pieces this wave issues for stage t (wave-uniform)
-        const int tot = (t == T - 1 ? last_sub : KS) * P_SUB;
-        return tot > wave ? (tot - wave + NW - 1) / NW : 0;
+        return (t == T - 1 ? last_sub : KS) * per_sub;
     };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto issue_stage = [&](int t) {
-        const unsigned st = lds0 + (unsigned)((t % NST) * STAGE);
-        const int k0 = t * KS * BK;
-        const int np = pieces_of(t);
+        const unsigned keep = dma_m0_save();
+        const int nsub = (t == T - 1) ? last_sub : KS;
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl)
-            if (sl < np) dma16(src[sl] + k0, st + dst[sl]);
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < nsub) {
+                const unsigned st = lds0 + (unsigned)((t % NST) * STAGE + ks * SS::BYTES);
+                const int k0 = (t * KS + ks) * BK;
+#pragma unroll
+                for (int a = 0; a < A_PER; ++a)
+                    if (a < A_PER - 1 || a_on) dma16_fast(voA[a], A + k0, st + (unsigned)((a * NW + wave) * 1024));
+#pragma unroll
+                for (int b = 0; b < W_FULL; ++b) dma16_fast(voW[b], W + k0, st + (unsigned)((8 + b * NW + wave) * 1024));
+                if (w_extra) dma16_fast(voW[W_FULL], W + k0, st + (unsigned)((8 + W_FULL * NW + wave) * 1024));
+                if (gb_on) dma16(gb_src + k0, st + (unsigned)SS::GB);
+            }
+        }
+        dma_m0_restore(keep);
     };
 
     f32x4 acc[NT];
@@ -353,7 +391,11 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         if (t < T) issue_stage(t);
 
     const int swz = (li >> 1) & 7;
+    // bench-only phase timing (ABL & 4): shader-clock cycles summed over the stages of this wave
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, acc_wait = 0, acc_bar = 0, acc_issue = 0, acc_comp = 0;
+    const unsigned long long t_begin = (ABL & 4) ? __builtin_amdgcn_s_memtime() : 0;
     for (int t = 0; t < T; ++t) {
+        if (ABL & 4) tk0 = __builtin_amdgcn_s_memtime();
         // stage t has landed for this wave once only the pieces of stages t+1 .. t+NST-2 are outstanding
         int allow = 0;
 #pragma unroll
@@ -361,11 +403,14 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
             if (t + j < T) allow += pieces_of(t + j);
         if (ABL & 1) allow = 0;
         wait_vm(allow);
+        if (ABL & 4) tk1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();           // everyone's pieces landed; everyone is done reading stage t-1
         asm volatile("" ::: "memory");
+        if (ABL & 4) tk2 = __builtin_amdgcn_s_memtime();
         // refill the stage the barrier just freed, at once: measured on MI355X, issuing the DMA here beats hiding
         // its address arithmetic behind the first fragment reads or the first MFMA block for every ring depth
         if (t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
+        if (ABL & 4) tk3 = __builtin_amdgcn_s_memtime();
 
         const char* st = smem + (t % NST) * STAGE;
         const int nstep = 2 * ((t == T - 1) ? last_sub : KS);   // 16-deep k steps in this stage
@@ -398,7 +443,13 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (ABL & 4) {
+            const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
+            acc_wait += tk1 - tk0; acc_bar += tk2 - tk1; acc_issue += tk3 - tk2; acc_comp += tk4 - tk3;
+        }
     }
+    unsigned long long t_loop_end = 0;
+    if (ABL & 4) t_loop_end = __builtin_amdgcn_s_memtime();
     if (KG > 1) {
         // k groups hold partial sums of the same output tile: fold groups 1..KG-1 into group 0 through LDS in a
         // fixed order (deterministic).  All DMA has been waited for, so the ring memory is free.
@@ -501,7 +552,19 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         }
         return;
     }
-    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li, stats_out, N / BN);
+    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li,
+                             (ABL & 4) ? nullptr : stats_out, N / BN);
+    if (ABL & 4) {   // bench-only: per-wave phase cycles into the (otherwise unused) stats_out buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            float* o = stats_out + (size_t)(blockIdx.x * NW + wave) * 12;
+            o[0] = (float)acc_wait; o[1] = (float)acc_bar; o[2] = (float)acc_issue; o[3] = (float)acc_comp;
+            o[4] = (float)(t_loop_end - t_begin); o[5] = (float)T; o[6] = (float)(t_begin - t_entry);
+            o[7] = (float)(t_end - t_loop_end); o[8] = (float)(t_real & 0xFFFFFF); o[9] = (float)(t_end - t_entry);
+            o[10] = 0.f; o[11] = 0.f;
+        }
+    }
 }
 
 template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false>
@@ -542,6 +605,10 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
     if (force) ng = force;
 #define MPL_ARGS2 A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
     static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;   // bench-only ablations
+    if (abl == 4 && !LN) {
+        if (ng == 3) return launch_ng<EPI, false, 3, 1, 1, 2, 4>(MPL_ARGS2);
+        return launch_ng<EPI, false, 1, 1, 1, 2, 4>(MPL_ARGS2);
+    }
     if (abl && EPI == 0 && !LN) {
         if (ng == 3) return abl == 1 ? launch_ng<0, false, 3, 1, 1, 2, 1>(MPL_ARGS2) : abl == 2 ? launch_ng<0, false, 3, 1, 1, 2, 2>(MPL_ARGS2) : launch_ng<0, false, 3, 1, 1, 2, 3>(MPL_ARGS2);
         if (ng == 1) return abl == 1 ? launch_ng<0, false, 1, 1, 1, 3, 1>(MPL_ARGS2) : abl == 2 ? launch_ng<0, false, 1, 1, 1, 3, 2>(MPL_ARGS2) : launch_ng<0, false, 1, 1, 1, 3, 3>(MPL_ARGS2);
@@ -560,6 +627,10 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
         case 123: return launch_ng<EPI, LN, 1, 1, 2, 3>(MPL_ARGS2);
         case 213: return launch_ng<EPI, LN, 2, 1, 1, 3>(MPL_ARGS2);
         case 312: return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
+        case 2123: return launch_ng<EPI, LN, 1, 2, 2, 3>(MPL_ARGS2);
+        case 2112: return launch_ng<EPI, LN, 1, 2, 1, 2>(MPL_ARGS2);
+        case 2113: return launch_ng<EPI, LN, 1, 2, 1, 3>(MPL_ARGS2);
+        case 2114: return launch_ng<EPI, LN, 1, 2, 1, 4>(MPL_ARGS2);
         default: break;
     }
     if (ng == 3) return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
@@ -602,7 +673,8 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
     const bool ln = ln_w != nullptr;
     if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-    if (stats_out && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
+    static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
+    if (stats_out && !timing && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
 #define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
 #define MPL_GEMM_CASE(E)                                                                              \
     case E:                                                                                           \
