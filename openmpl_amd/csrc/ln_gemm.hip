@@ -89,22 +89,35 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStr
 // Epilogue shared by both GEMM kernels.  acc[n][r] = D[row0 + r][n0 + 16 n + li].  All loads (bias, residual)
 // are issued before the first store: vmcnt counts stores too, so a load queued behind stores would wait for
 // them to drain.
+// Residual values of this lane's 36 outputs, loaded with clamped (always valid) addresses so that exactly
+// NT * 4 load instructions are issued: the k loop prefetches them two stages before the epilogue and has to
+// account for them in its counted vmcnt waits.
+constexpr int RES_LOADS = NT * 4;
+__device__ __forceinline__ void load_residual(float (&rv)[NT][4], const float* R, int ldr, int M, int N, int row0,
+                                              int n0, int li) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int col = n0 + n * 16 + li;
+        col = col < N ? col : N - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = row0 + r;
+            row = row < M ? row : M - 1;
+            rv[n][r] = R[(size_t)row * ldr + col];
+        }
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], const float* __restrict__ bias,
-                                                    const float* R, int ldr, float* C, int ldc, int M, int N,
+                                                    const float (&rv)[NT][4], float* C, int ldc, int M, int N,
                                                     int row0, int n0, int li, float* stats_out, int stats_ns) {
     const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
     float bv[NT];
-    float rv[NT][4];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n0 + n * 16 + li;
-        const bool on = col < n_end;
-        bv[n] = on ? bias[col] : 0.f;
-        if (EPI == MPL_EPI_BIAS_RESIDUAL) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rv[n][r] = (on && row0 + r < M) ? R[(size_t)(row0 + r) * ldr + col] : 0.f;
-        }
+        bv[n] = col < n_end ? bias[col] : 0.f;
     }
     float v[NT][4];
 #pragma unroll
@@ -220,9 +233,9 @@ __device__ __forceinline__ void dma_m0_restore(unsigned keep) { asm volatile("s_
 __device__ __forceinline__ void wait_vm(int n) {
 #define MPL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (n) {
-        MPL_W(0) MPL_W(1) MPL_W(2) MPL_W(3) MPL_W(4) MPL_W(5) MPL_W(6) MPL_W(7) MPL_W(8) MPL_W(9) MPL_W(10)
-        MPL_W(11) MPL_W(12) MPL_W(13) MPL_W(14) MPL_W(15) MPL_W(16) MPL_W(17) MPL_W(18) MPL_W(19) MPL_W(20)
-        MPL_W(21) MPL_W(22) MPL_W(23) MPL_W(24) MPL_W(25) MPL_W(26) MPL_W(27) MPL_W(28)
+        MPL_W(0) MPL_W(1) MPL_W(2) MPL_W(3) MPL_W(4) MPL_W(5) MPL_W(6) MPL_W(7) MPL_W(8) MPL_W(9) MPL_W(10) MPL_W(11) MPL_W(12) MPL_W(13) MPL_W(14) MPL_W(15) MPL_W(16) MPL_W(17) MPL_W(18) MPL_W(19) MPL_W(20)
+        MPL_W(21) MPL_W(22) MPL_W(23) MPL_W(24) MPL_W(25) MPL_W(26) MPL_W(27) MPL_W(28) MPL_W(29) MPL_W(30) MPL_W(31) MPL_W(32) MPL_W(33) MPL_W(34) MPL_W(35) MPL_W(36) MPL_W(37) MPL_W(38) MPL_W(39) MPL_W(40) MPL_W(41)
+        MPL_W(42) MPL_W(43) MPL_W(44) MPL_W(45) MPL_W(46) MPL_W(47) MPL_W(48) MPL_W(49) MPL_W(50) MPL_W(51) MPL_W(52) MPL_W(53) MPL_W(54) MPL_W(55) MPL_W(56) MPL_W(57) MPL_W(58) MPL_W(59) MPL_W(60) MPL_W(61) MPL_W(62)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef MPL_W
@@ -390,6 +403,8 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
     for (int t = 0; t < NST - 1; ++t)
         if (t < T) issue_stage(t);
 
+    float rv[NT][4];                            // residual (EPI_BIAS_RESIDUAL), prefetched inside the k loop
+    const int t_res = T >= 2 ? T - 2 : 0;      // stage during which the residual loads are issued
     const int swz = (li >> 1) & 7;
     // bench-only phase timing (ABL & 4): shader-clock cycles summed over the stages of this wave
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, acc_wait = 0, acc_bar = 0, acc_issue = 0, acc_comp = 0;
@@ -401,6 +416,7 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
 #pragma unroll
         for (int j = 1; j <= NST - 2; ++j)
             if (t + j < T) allow += pieces_of(t + j);
+        if (EPI == MPL_EPI_BIAS_RESIDUAL && t > t_res) allow += RES_LOADS;   // younger than every DMA piece
         if (ABL & 1) allow = 0;
         wait_vm(allow);
         if (ABL & 4) tk1 = __builtin_amdgcn_s_memtime();
@@ -410,6 +426,9 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         // refill the stage the barrier just freed, at once: measured on MI355X, issuing the DMA here beats hiding
         // its address arithmetic behind the first fragment reads or the first MFMA block for every ring depth
         if (t + NST - 1 < T && !(ABL & 1)) issue_stage(t + NST - 1);
+        // the epilogue's residual operand: issue its loads now, two stages of MFMA work ahead of their use
+        if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res)
+            load_residual(rv, R, ldr, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li);
         if (ABL & 4) tk3 = __builtin_amdgcn_s_memtime();
 
         const char* st = smem + (t % NST) * STAGE;
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(256 * NG * KG, 1) void ln_gemm_ng_kernel(const floa
         }
         return;
     }
-    store_tile_epilogue<EPI>(acc, bias, R, ldr, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li,
+    store_tile_epilogue<EPI>(acc, bias, rv, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li,
                              (ABL & 4) ? nullptr : stats_out, N / BN);
     if (ABL & 4) {   // bench-only: per-wave phase cycles into the (otherwise unused) stats_out buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
