@@ -178,6 +178,29 @@ int mpl_linear(const float *xa, int Ka, const float *xb, int Kb, int M, const fl
                const float *bn_w, const float *bn_b, const float *bn_mean, const float *bn_var, float bn_eps, int relu,
                float *y, void *stream);
 
+/* ---- input preparation (the step right before the path): raw per-view detections ->
+ * the tensors mpl_forward consumes.  Replaces, per sample and view, normalize_screen_coordinates
+ * (joints_dataset_mpl.py:817-820), the camera normalisation of __getitem__ (:615-623), create_3d_ray_coords (:872-904),
+ * cam_center (:646) and the [x, y, conf] concat (:772).
+ *   joints_px (B,V,J,2) pixel coordinates, conf (B,V,J) or NULL (-> 1), device;
+ *   cams_dev device (V,16) float64: fx fy cx cy | R row-major (world->camera) | t (camera centre in world coords);
+ *   img_w/img_h = NETWORK.IMAGE_SIZE; normalize_inputs = DATASET.INPUTS_NORMALIZED, normalize_cameras =
+ *   DATASET.NORMALIZE_CAMERAS;  poses/rays/centers: host arrays of V device pointers to (B,J,3),(B,J,3),(B,1,3). */
+int mpl_prepare_inputs(const float *joints_px, const float *conf, const double *cams_dev, int batch, int views,
+                       int joints, float img_w, float img_h, int normalize_inputs, int normalize_cameras,
+                       float *const *poses, float *const *rays, float *const *centers, void *stream);
+
+/* ---- output-side epilogue (the step right after the path): what validate() does on the host
+ * with `output.clone().cpu().numpy()` -- room de-normalisation x*scale+offset (function_mpl.py:476-488, host float[3]
+ * arrays, NULL = identity) and the MPJPE family: loss.py:39-57 / :110-124 (mean Euclidean error, optional (B,J)
+ * weights, per-axis mean |error|, on the RAW tensors) and evaluate.py:91-125 (per-joint absolute and root-relative
+ * PJPE with np.nansum semantics, per-axis distances with np.nanmean semantics, on the de-normalised tensors).
+ * result (device, mpl_pose_metrics_size(J) floats): [0] loss, [1..3] loss per axis, [4..4+J) pjpe_abs, [4+J] mpjpe_abs,
+ * [5+J..5+2J) pjpe_rel, [5+2J] mpjpe_rel, then dist (J x 3), dist_mean (3). */
+int mpl_pose_metrics_size(int joints);
+int mpl_pose_metrics(const float *output, const float *target, const float *weight, int batch, int joints,
+                     const float *scale3, const float *offset3, float *result, void *stream);
+
 /* Measurement aid (bench.py roofline leg): between start and stop every kernel launched by this
  * library on ANY stream is bracketed by a hipEvent pair recorded on that same stream.  stop()
  * synchronises the events and returns, per kernel kind, the summed device time (ms) and the launch

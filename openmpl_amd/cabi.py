@@ -72,7 +72,8 @@ class Inputs(C.Structure):
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
            "mpl_ln_linear", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
-           "mpl_layernorm", "mpl_linear", "mpl_profile_start", "mpl_profile_stop")
+           "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_prepare_inputs", "mpl_profile_start",
+           "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
 
 _lib = None
@@ -133,6 +134,13 @@ def load():
         lib.mpl_linear.restype = C.c_int
         lib.mpl_linear.argtypes = [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp,
                                    C.c_float, C.c_int, _fp, _fp]
+        lib.mpl_pose_metrics_size.restype = C.c_int
+        lib.mpl_pose_metrics_size.argtypes = [C.c_int]
+        lib.mpl_pose_metrics.restype = C.c_int
+        lib.mpl_pose_metrics.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _fp]
+        lib.mpl_prepare_inputs.restype = C.c_int
+        lib.mpl_prepare_inputs.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                           C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), _fp]
         lib.mpl_profile_start.restype = C.c_int
         lib.mpl_profile_start.argtypes = []
         lib.mpl_profile_stop.restype = C.c_int

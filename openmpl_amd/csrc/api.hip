@@ -237,6 +237,20 @@ int mpl_linear(const float* xa, int Ka, const float* xb, int Kb, int M, const fl
                              (hipStream_t)stream);
 }
 
+int mpl_prepare_inputs(const float* joints_px, const float* conf, const double* cams_dev, int batch, int views, int joints,
+                       float img_w, float img_h, int normalize_inputs, int normalize_cameras, float* const* poses,
+                       float* const* rays, float* const* centers, void* stream) {
+    return launch_prepare_inputs(joints_px, conf, cams_dev, batch, views, joints, img_w, img_h, normalize_inputs,
+                                 normalize_cameras, poses, rays, centers, (hipStream_t)stream);
+}
+
+int mpl_pose_metrics_size(int joints) { return 4 + 2 * (joints + 1) + 3 * joints + 3; }
+
+int mpl_pose_metrics(const float* output, const float* target, const float* weight, int batch, int joints,
+                     const float* scale3, const float* offset3, float* result, void* stream) {
+    return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, result, (hipStream_t)stream);
+}
+
 int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* out, void* workspace,
                 size_t workspace_bytes, void* stream) {
     int rc = check_cfg(cfg);

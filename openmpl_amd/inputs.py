@@ -1,0 +1,51 @@
+"""Device-side replacement of the per-sample input preparation of OpenMPL's datasets.
+
+Reference: lib/dataset/joints_dataset_mpl.py:615-623, :646, :762-774, :817-820, :872-904.  From raw detections
+(B,V,J,2) [+ confidences (B,V,J)] and one calibration per view it produces exactly what the model call
+`model(input, centers=centers, rays=rays)` (function_mpl.py:350) takes.  One HIP kernel through the C ABI; no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import cabi
+
+
+def pack_cameras(cameras, device) -> torch.Tensor:
+    """cameras: sequence of dicts with fx, fy, cx, cy, R (3x3 world->camera), t (camera centre, 3) -> device (V,16) f64."""
+    rows = [np.concatenate([[float(c["fx"]), float(c["fy"]), float(c["cx"]), float(c["cy"])],
+                            np.asarray(c["R"], np.float64).reshape(-1), np.asarray(c["t"], np.float64).reshape(-1)])
+            for c in cameras]
+    return torch.from_numpy(np.stack(rows)).to(device)
+
+
+def prepare_inputs(joints_px: torch.Tensor, conf: Optional[torch.Tensor], cams: torch.Tensor, image_size: Tuple[float, float],
+                   normalize_inputs: bool = True, normalize_cameras: bool = True
+                   ) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[torch.Tensor]]:
+    """joints_px (B,V,J,2) float32 GPU, conf (B,V,J) or None, cams (V,16) float64 GPU (pack_cameras).
+    Returns (poses, rays, centers): lists of V tensors (B,J,3), (B,J,3), (B,1,3)."""
+    if joints_px.device.type != "cuda":
+        raise RuntimeError("prepare_inputs has no CPU path: tensors must live on a GPU")
+    if joints_px.ndim != 4 or joints_px.shape[-1] != 2 or joints_px.dtype != torch.float32:
+        raise RuntimeError("joints_px must be float32 (B,V,J,2)")
+    B, V, J, _ = joints_px.shape
+    if tuple(cams.shape) != (V, 16) or cams.dtype != torch.float64 or cams.device != joints_px.device:
+        raise RuntimeError("cams must be float64 (V,16) on the same device (see pack_cameras)")
+    dev = joints_px.device
+    lib = cabi.load()
+    joints_px = joints_px.contiguous()
+    if conf is not None:
+        conf = conf.reshape(B, V, J).to(torch.float32).contiguous()
+    mk = lambda *s: [torch.empty(s, dtype=torch.float32, device=dev) for _ in range(V)]
+    poses, rays, centers = mk(B, J, 3), mk(B, J, 3), mk(B, 1, 3)
+    arr = lambda lst: (cabi._fp * V)(*[t.data_ptr() for t in lst])
+    with torch.cuda.device(dev):
+        rc = lib.mpl_prepare_inputs(joints_px.data_ptr(), None if conf is None else conf.data_ptr(), cams.data_ptr(), B, V, J,
+                                    float(image_size[0]), float(image_size[1]), int(normalize_inputs), int(normalize_cameras),
+                                    arr(poses), arr(rays), arr(centers), torch.cuda.current_stream().cuda_stream)
+    cabi.check(rc, "mpl_prepare_inputs")
+    return poses, rays, centers
