@@ -63,11 +63,6 @@ __device__ __forceinline__ float4 ld4(gfp p) {
     return make_float4(t.x, t.y, t.z, t.w);
 }
 
-__device__ __forceinline__ void wave_range(int total, int wave, int& lo, int& hi) {
-    lo = (total * wave) >> 2;
-    hi = (total * (wave + 1)) >> 2;
-}
-
 // LayerNorm'ed A fragments of row tile m for a K = 32 GEMM: a0 covers k = 4kq..4kq+3, a1 k = 16+4kq..
 __device__ __forceinline__ void ln_frags(const float* X, int m, int li, int kq, const float4& g0, const float4& g1,
                                          const float4& b0, const float4& b1, float4& a0, float4& a1) {

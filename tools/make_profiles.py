@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 outputs of tools/gpu_session11.sh (under gpurun_out/) into the tracked profiles/ files.
+"""Turn the rocprofv3 outputs of tools/gpu_profile_session.sh (under gpurun_out/) into the tracked profiles/ files.
     python tools/make_profiles.py <round tag, e.g. r01> <session id, e.g. 11>"""
 import collections, csv, json, os, shutil, sys
 tag, sid = sys.argv[1], sys.argv[2]
