@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 1
+#define MPL_HIP_ABI_VERSION 2
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -73,6 +73,11 @@ typedef struct mpl_block_weights {
     const float *ln2_w, *ln2_b;
     const float *fc1_w, *fc1_b;
     const float *fc2_w, *fc2_b;
+    /* Optional bf16 copies ([out][in], round-to-nearest-even, see mpl_convert_bf16) of the four Linear weights.
+     * When all four are non-NULL in a block handed to mpl_block_stack / mpl_forward (FPT blocks only), that block's
+     * GEMMs run on the bf16 matrix cores (bf16 operands, fp32 accumulate; LayerNorm, softmax, GELU, residual and
+     * stored activations stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
+    const uint16_t *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;
 } mpl_block_weights;
 
 /* Per-view (or shared) spatial parameter set, multiview_mpl.py:159-195, :236-249. */
@@ -147,6 +152,9 @@ int mpl_block_stack(float *x, int n_seq, int n_tok, int dim, int heads, const mp
 int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *ln_b, float eps, const float *W,
                   const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
                   void *stream);
+
+/* dst[i] = bf16(src[i]) (round to nearest even): builds the optional *_w16 operands of mpl_block_weights. */
+int mpl_convert_bf16(const float *src, uint16_t *dst, size_t n, void *stream);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

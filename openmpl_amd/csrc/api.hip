@@ -72,9 +72,12 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     bool have_stats = false;
     // qkv projection and attention run as one kernel when a 64-row tile holds whole sequences and a 136-column
     // slice whole heads (V in {1,2,4,8,16,32,64}; hd in {68,136}); otherwise as two kernels through `qkv`
-    const bool fused_att = qkv_attention_fusable(n_tok, D, H);
+    const bool fusable = qkv_attention_fusable(n_tok, D, H);
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
+        // bf16 matrix-core path for this block when the binding supplied bf16 weight copies
+        const bool bf = b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16;
+        const bool fused_att = fusable && !bf;
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         if (fused_att) {
@@ -83,20 +86,20 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
                 return rc;
         } else {
             if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                     3 * D, D, MPL_EPI_BIAS, nullptr, s)))
+                                     3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr)))
                 return rc;
             if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
         }
         if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
-                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)))
+                                 MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr)))
             return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
         if (!st_out && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         if ((rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
-                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s)))
+                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr)))
             return rc;
         if ((rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
-                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s)))
+                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr)))
             return rc;
         have_stats = st_out != nullptr;
     }
@@ -196,6 +199,10 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
     static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
     return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue,
                           (timing && !ln_w) ? stats : nullptr, s);
+}
+
+int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+    return launch_convert_bf16(src, dst, n, (hipStream_t)stream);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {

@@ -61,7 +61,9 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStr
 // the rows it produced, so the next LN-GEMM needs no statistics pass.
 int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
                    const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
-                   int epi, float* stats_out, hipStream_t s);
+                   int epi, float* stats_out, hipStream_t s, const unsigned short* W16 = nullptr);
+// fp32 -> bf16 (RNE) copy of a weight tensor for the bf16 matrix-core path
+int launch_convert_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t s);
 bool qkv_attention_fusable(int n_tok, int dim, int heads);
 int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
                             float eps, const float* W, const float* bias, int n_tok, int heads, float* att,

@@ -59,8 +59,16 @@ def resolve_flags(flags: Optional[dict]) -> dict:
     return f
 
 
+_BF16_PREFIXES = ()   # set by forward(fpt_matmul_bf16=True): Linear layers whose operands are rounded to bf16
+
+
 def _lin(x, sd, prefix):
-    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+    w = sd[prefix + ".weight"]
+    if _BF16_PREFIXES and prefix.startswith(_BF16_PREFIXES):
+        # emulation of the bf16 matrix-core path: operands rounded to bf16 (RNE), products and sums in >= fp32
+        x = x.to(torch.bfloat16).to(x.dtype)
+        w = w.to(torch.bfloat16).to(w.dtype)
+    return F.linear(x, w, sd[prefix + ".bias"])
 
 
 def _ln(x, sd, prefix, eps):
@@ -221,12 +229,24 @@ def head(x, sd, f):
 
 def forward(sd: Dict[str, torch.Tensor], flags: Optional[dict], poses: Sequence[torch.Tensor],
             rays: Sequence[torch.Tensor], centers: Sequence[torch.Tensor],
-            dtype: torch.dtype = torch.float32, taps: Optional[dict] = None):
+            dtype: torch.dtype = torch.float32, taps: Optional[dict] = None, fpt_matmul_bf16: bool = False):
     """MultiView_MPL.forward, multiview_mpl.py:450-525.
 
     ``sd`` may carry the ``features.`` prefix of MultiView_MPL_G (multiview_mpl.py:552).
     Returns (B,J,3) -- or ((B,J,3), [x1,x2]) for the kadkhod head.
+
+    ``fpt_matmul_bf16`` emulates MultiView_MPL.set_matmul_precision("bf16"): the four Linear layers of every FPT
+    block see bf16-rounded operands (fp32-or-better accumulation), everything else is unchanged.
     """
+    global _BF16_PREFIXES
+    _BF16_PREFIXES = ("blocks.",) if fpt_matmul_bf16 else ()
+    try:
+        return _forward(sd, flags, poses, rays, centers, dtype, taps)
+    finally:
+        _BF16_PREFIXES = ()
+
+
+def _forward(sd, flags, poses, rays, centers, dtype, taps):
     f = resolve_flags(flags)
     sd = {(k[len("features."):] if k.startswith("features.") else k): v.to(dtype) if v.is_floating_point() else v
           for k, v in sd.items()}

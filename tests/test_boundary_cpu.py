@@ -106,7 +106,7 @@ def test_shared_library_exports_every_symbol_declared_in_header():
     path = mpl_build.build()
     lib = ctypes.CDLL(path)
     header = open(os.path.join(ROOT, "include", "mpl_hip.h")).read()
-    declared = set(re.findall(r"\b(mpl_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mpl_[a-z_0-9]+)\s*\(", header))
     declared -= {"mpl_hip_error_string"} - {"mpl_hip_error_string"}
     assert declared == set(cabi.EXPORTS)
     for name in declared:
@@ -126,7 +126,7 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == want
     cfg.flags |= cabi.F_RAYS_TOKEN
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
-    assert ctypes.sizeof(cabi.BlockWeights) == 96 and ctypes.sizeof(cabi.SptSet) == 48
+    assert ctypes.sizeof(cabi.BlockWeights) == 128 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
 
 

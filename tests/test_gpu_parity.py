@@ -274,3 +274,31 @@ def test_gpu_input_validation():
             m([x.cpu() for x in P], rays=R, centers=Cn)
         out = m([x.expand(2, *x.shape)[0] for x in P], rays=None, centers=None)   # rays unused by CHOSEN
     assert torch.isfinite(out).all()
+
+
+# ----------------------------------------------------------------------------- bf16 matrix-core path (configs[2])
+@pytest.mark.parametrize("name,B", [("chosen_v8_b4_l2", 256), ("full_v8_b4_l2", 64), ("chosen_v4_b8_l12", 64)])
+def test_bf16_matmul_path(name, B):
+    """BASELINE.json configs[2] (CMU Panoptic, V=8, bf16): FPT GEMMs on the bf16 matrix cores.  Tight check against
+    the oracle's bf16-operand emulation (same rounding points, fp64 accumulation); loose check + reported delta against
+    the fp32 reference semantics (bf16 is reported, not gated at 1e-4)."""
+    m, g = _model(name)
+    m.set_matmul_precision("bf16")
+    V = g["flags"]["num_views"]
+    p, r, c = detrng.make_inputs(B, V, seed=77)
+    P, R, Cn = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    with torch.no_grad():
+        out = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn]).cpu()
+    sd = golden_state_dict(name, g)
+    emu = mpl_oracle.forward(sd, g["flags"], P, R, Cn, dtype=torch.float64, fpt_matmul_bf16=True)
+    ref = mpl_oracle.forward(sd, g["flags"], P, R, Cn, dtype=torch.float64)
+    mx, nw = mpl_oracle.rel_errors(out, emu)
+    dx, dn = mpl_oracle.rel_errors(out, ref)
+    print("%s bf16: vs bf16-emulation oracle %.2e/%.2e ; vs fp64 reference semantics %.2e/%.2e ; MPJPE-vs-ref %.3e"
+          % (name, mx, nw, dx, dn, mpl_oracle.mpjpe(out, ref)))
+    assert mx < 2e-3 and nw < 2e-3, "bf16 path deviates from its own emulation: %.2e %.2e" % (mx, nw)
+    assert dx < 5e-2 and dn < 5e-2
+    m.set_matmul_precision("fp32")
+    with torch.no_grad():
+        out32 = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn]).cpu()
+    _assert_close(out32, ref, name + " back to fp32")

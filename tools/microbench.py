@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--precision", default="fp32")
     a = ap.parse_args()
     lib = cabi.load()
     dev = "cuda:0"
@@ -79,6 +80,7 @@ def main():
     m = MultiView_MPL(**flags)
     detrng.fill_module_(m, seed=11)
     m = m.to(dev).eval()
+    m.set_matmul_precision(a.precision)
     p, r, c = detrng.make_inputs(a.batch, a.views, seed=1)
     P = [torch.from_numpy(t).to(dev) for t in p]
     R_ = [torch.from_numpy(t).to(dev) for t in r]
