@@ -233,6 +233,25 @@ def main():
             extra["full_flagset_poses_per_s"] = round(v2, 1)
             extra["full_flagset_tflops"] = round(v2 * mpl_oracle.flop_count(f2) / 1e12, 2)
             del m2
+            # BASELINE.json configs[2]: CMU Panoptic shape V=8, batch 1024, bf16 matrix cores (yaml depth 2), with the
+            # fp32 run of the same shape and the bf16 deviation from the fp32 reference semantics (reported, not gated)
+            m3, f3 = build_model("chosen", 8, 2, dev)
+            b3 = [make_batch(a.batch, 8, dev, seed=2000, step=s) for s in range(2)]
+            n3 = max(10, a.steps // 2)
+            v32 = a.batch * n3 / timed_steps(m3, b3, n3, 3, None, None)
+            m3.set_matmul_precision("bf16")
+            v16 = a.batch * n3 / timed_steps(m3, b3, n3, 3, None, None)
+            P3, R3, C3 = b3[0]
+            with torch.no_grad():
+                o16 = m3([x[:64].contiguous() for x in P3], rays=[x[:64].contiguous() for x in R3],
+                         centers=[x[:64].contiguous() for x in C3]).cpu()
+            sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
+            r3 = mpl_oracle.forward(sd3, f3, [x[:64].cpu() for x in P3], [x[:64].cpu() for x in R3], [x[:64].cpu() for x in C3])
+            mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
+            extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1),
+                                      "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
+                                      "bf16_mpjpe_vs_ref": float("%.3e" % mpl_oracle.mpjpe(o16, r3))}
+            del m3
 
         result = {
             "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) fp32" % (a.views, a.batch),
