@@ -109,7 +109,7 @@ __device__ __forceinline__ void load_qkv_frags(const mpl_block_weights& bw, Bloc
     }
 }
 
-__device__ __forceinline__ void load_rest_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
+__device__ __forceinline__ void load_proj_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const gfp wr = G(bw.proj_w) + (n * 16 + li) * SD + 4 * kq;
@@ -117,6 +117,9 @@ __device__ __forceinline__ void load_rest_frags(const mpl_block_weights& bw, Blo
         F.wp[n][1] = ld4(wr + 16);
         F.bp[n] = G(bw.proj_b)[n * 16 + li];
     }
+}
+
+__device__ __forceinline__ void load_fc1_frags(const mpl_block_weights& bw, BlockFrags& F, int li, int kq) {
     F.g2a = ld4(G(bw.ln2_w) + 4 * kq); F.g2b = ld4(G(bw.ln2_w) + 16 + 4 * kq);
     F.e2a = ld4(G(bw.ln2_b) + 4 * kq); F.e2b = ld4(G(bw.ln2_b) + 16 + 4 * kq);
 #pragma unroll
@@ -137,6 +140,17 @@ __device__ __forceinline__ void load_fc2_frags(const mpl_block_weights& bw, Bloc
         F.b2[n] = G(bw.fc2_b)[n * 16 + li];
     }
 }
+
+// "Touch" prefetched fragments: an empty asm that reads them makes hipcc place their s_waitcnt HERE.  Every phase
+// first touches the fragments it is about to use (they were loaded at least one phase earlier, so the wait is
+// free) and only then issues the next prefetch -- otherwise the compiler's vmcnt(0) in front of the first MFMA
+// would also wait for the loads issued a moment ago and expose the full L2 latency every phase.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void touch(const float4& a) {
+    const v4f v = {a.x, a.y, a.z, a.w};
+    asm volatile("" ::"v"(v));
+}
+__device__ __forceinline__ void touch(float a) { asm volatile("" ::"v"(a)); }
 
 // one 16x16 output tile of a K = 32 GEMM: two independent accumulator chains (k 0..15 / 16..31) so that
 // consecutive MFMAs never wait on the 40-cycle dependent-accumulator latency
@@ -206,13 +220,25 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
     // Output tiles (16 rows x 16 columns) of every Linear are dealt to the 8 waves as contiguous ranges of the
     // row-major tile list; a wave walks its row tiles and tests each column tile against its range (static
     // indices keep every fragment in registers).
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tlast = (p.abl & 16) ? __builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int k) {
+        if (p.abl & 16) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            ph[k] += now - tlast;
+            tlast = now;
+        }
+    };
     for (int app = 0; app < p.n_apps; ++app) {
         const bool weighted = (p.sched[app] & 0x80) != 0;
         const bool more = app + 1 < p.n_apps;
         if (more) bw_next = set.blocks[p.sched[app + 1] & 0x7f];   // pointers only; used two phases later
-        // Prefetch schedule (peak ~140 live fragment registers): proj + fc1 weights now, fc2 weights at the proj
-        // phase, the next application's qkv weights at the fc2 phase.
-        load_rest_frags(bw, F, li, kq);
+        // Prefetch schedule: every phase first touches its own fragments, then issues the loads of the NEXT phase
+        // (proj weights during qkv, fc1 during proj, fc2 during fc1, the next application's qkv during fc2), so each
+        // group has a whole phase to arrive and at most two groups are live at a time.
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { touch(F.wq[n][0]); touch(F.wq[n][1]); touch(F.bq[n]); }
+        touch(F.g1a); touch(F.g1b); touch(F.e1a); touch(F.e1b);
+        load_proj_frags(bw, F, li, kq);
 
         // ---- QKV = LN1(X) . Wqkv^T + b : 17 x 6 tiles -> Q[:, 0:96]
         {
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             }
         }
         __syncthreads();
+        stamp(0);
 
         // ---- attention: thread per (row, head); 17 scores in registers (:55-64)
         for (int pr = tid; pr < ROWS * SH && !(p.abl & 1); pr += NTHR) {
@@ -271,9 +298,12 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             st4(Q + r * QS + 4 * h, o);  // overwrite q (only this thread ever reads it)
         }
         __syncthreads();
+        stamp(1);
 
         // ---- X += attn_out . Wproj^T + b : 17 x 2 tiles
-        load_fc2_frags(bw, F, li, kq);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { touch(F.wp[n][0]); touch(F.wp[n][1]); touch(F.bp[n]); }
+        load_fc1_frags(bw, F, li, kq);
         {
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 4); ++m) {
@@ -291,8 +321,13 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             }
         }
         __syncthreads();
+        stamp(2);
 
         // ---- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles -> Q[:, 0:64]
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { touch(F.w1[n][0]); touch(F.w1[n][1]); touch(F.b1[n]); }
+        touch(F.g2a); touch(F.g2b); touch(F.e2a); touch(F.e2b);
+        load_fc2_frags(bw, F, li, kq);
         {
             const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
             for (int m = lo >> 2; m <= ((hi - 1) >> 2) && !(p.abl & 4); ++m) {
@@ -311,8 +346,15 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             }
         }
         __syncthreads();
+        stamp(3);
 
         // ---- X += Hid . W2^T + b : K = 64, 17 x 2 tiles
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) touch(F.w2[n][q]);
+            touch(F.b2[n]);
+        }
         if (more) load_qkv_frags(bw_next, F, li, kq);   // qkv fragments are long dead: next application's weights
         {
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
@@ -331,9 +373,16 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             }
         }
         __syncthreads();
+        stamp(4);
         bw = bw_next;
     }
 
+    if ((p.abl & 16) && lane == 0 && blockIdx.x < 32) {
+        float* o = p.xs + (size_t)(blockIdx.x * NWAVE + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = (float)ph[k];
+        return;
+    }
+    if (p.abl & 16) return;
     // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
     const bool to_rays = (p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);   // feature concat (:469-471)
     const bool ray_tok = !(p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);  // token concat (:486-489)
