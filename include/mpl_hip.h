@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 2
+#define MPL_HIP_ABI_VERSION 3
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -78,6 +78,12 @@ typedef struct mpl_block_weights {
      * GEMMs run on the bf16 matrix cores (bf16 operands, fp32 accumulate; LayerNorm, softmax, GELU, residual and
      * stored activations stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
     const uint16_t *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;
+    /* Optional split operands (mpl_split_bf16x3) of the four Linear weights.  When all four are non-NULL (and the
+     * *_w16 are NULL) the block's GEMMs run as fp32 arithmetic on the bf16 matrix cores: every fp32 operand is the
+     * exact sum of three bf16 numbers and each product is accumulated in fp32 from its six significant partial
+     * products -- at least as accurate as an fp32 multiply (csrc/x3_gemm.hip), 2.7x less matrix-pipe time than the
+     * native fp32 MFMA.  Shapes must satisfy mpl_split_bf16x3_bytes() != 0, else leave them NULL. */
+    const uint16_t *qkv_w3, *proj_w3, *fc1_w3, *fc2_w3;
 } mpl_block_weights;
 
 /* Per-view (or shared) spatial parameter set, multiview_mpl.py:159-195, :236-249. */
@@ -155,6 +161,16 @@ int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *
 
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the optional *_w16 operands of mpl_block_weights. */
 int mpl_convert_bf16(const float *src, uint16_t *dst, size_t n, void *stream);
+
+/* Split operand of an nn.Linear weight W[N][K] for the fp32-on-bf16-matrix-core GEMMs: three bf16 parts
+ * (hi + mid + lo == w exactly) in MFMA fragment order.  mpl_split_bf16x3_bytes() is the size of `dst` in bytes, or 0
+ * when the shape is not supported (N must be a multiple of 136, K of 32, K >= 64). */
+size_t mpl_split_bf16x3_bytes(int N, int K);
+int mpl_split_bf16x3(const float *W, int N, int K, uint16_t *dst, void *stream);
+/* mpl_ln_linear with the split operand W3 in place of W (same epilogues; `stats` as there).  fp32 in, fp32 out. */
+int mpl_ln_linear_x3(const float *x, int M, int K, const float *ln_w, const float *ln_b, float eps, const uint16_t *W3,
+                     const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
+                     void *stream);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

@@ -14,7 +14,7 @@ from . import build as _build
 
 MPL_MAX_VIEWS = 32
 MPL_MAX_APPS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # flag bits (mpl_hip.h MPL_F_*)
 F_MULTI_SPT = 1 << 0
@@ -38,7 +38,8 @@ _fp = C.c_void_p  # device float* carried as an integer address
 class BlockWeights(C.Structure):
     _fields_ = [(n, _fp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                                   "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16")]
+                                   "qkv_w16", "proj_w16", "fc1_w16", "fc2_w16",
+                                   "qkv_w3", "proj_w3", "fc1_w3", "fc2_w3")]
 
 
 class SptSet(C.Structure):
@@ -72,7 +73,7 @@ class Inputs(C.Structure):
 
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
-           "mpl_ln_linear", "mpl_convert_bf16", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
+           "mpl_ln_linear", "mpl_convert_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_ln_linear_x3", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
            "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
@@ -124,6 +125,13 @@ def load():
                                       _fp, _fp, _fp]
         lib.mpl_convert_bf16.restype = C.c_int
         lib.mpl_convert_bf16.argtypes = [_fp, _fp, C.c_size_t, _fp]
+        lib.mpl_split_bf16x3_bytes.restype = C.c_size_t
+        lib.mpl_split_bf16x3_bytes.argtypes = [C.c_int, C.c_int]
+        lib.mpl_split_bf16x3.restype = C.c_int
+        lib.mpl_split_bf16x3.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp]
+        lib.mpl_ln_linear_x3.restype = C.c_int
+        lib.mpl_ln_linear_x3.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int, C.c_int, _fp,
+                                         _fp, _fp, _fp]
         lib.mpl_token_attention.restype = C.c_int
         lib.mpl_token_attention.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]
         lib.mpl_fuse_head.restype = C.c_int

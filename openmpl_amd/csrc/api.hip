@@ -75,32 +75,43 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     const bool fusable = qkv_attention_fusable(n_tok, D, H);
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        // bf16 matrix-core path for this block when the binding supplied bf16 weight copies
+        // bf16 matrix-core path for this block when the binding supplied bf16 weight copies; fp32-on-bf16-cores
+        // (split operands) when it supplied those
         const bool bf = b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16;
+        const bool x3 = !bf && b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3;
+        if (x3 && (x3_operand_bytes(3 * D, D) == 0 || x3_operand_bytes(D, 2 * D) == 0 || D < 64)) return MPL_E_INVALID;
         const bool fused_att = fusable && !bf;
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         if (fused_att) {
-            if ((rc = launch_ln_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, n_tok, H, w.att,
-                                              s)))
-                return rc;
+            rc = x3 ? launch_x3_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w3, b.qkv_b, n_tok, H, w.att, s)
+                    : launch_ln_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, n_tok, H, w.att, s);
+            if (rc) return rc;
         } else {
-            if ((rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                     3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr)))
-                return rc;
+            rc = x3 ? launch_x3_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w3, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
+                                     3 * D, D, MPL_EPI_BIAS, nullptr, s)
+                    : launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
+                                     3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr);
+            if (rc) return rc;
             if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
         }
-        if ((rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
-                                 MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr)))
-            return rc;
+        rc = x3 ? launch_x3_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w3, b.proj_b, x, D, x, D, M, D, D,
+                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)
+                : launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
+                                 MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr);
+        if (rc) return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
         if (!st_out && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
-        if ((rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
-                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr)))
-            return rc;
-        if ((rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
-                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr)))
-            return rc;
+        rc = x3 ? launch_x3_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w3, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
+                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s)
+                : launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
+                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr);
+        if (rc) return rc;
+        rc = x3 ? launch_x3_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w3, b.fc2_b, x, D, x, D, M, D, 2 * D,
+                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)
+                : launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
+                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr);
+        if (rc) return rc;
         have_stats = st_out != nullptr;
     }
     return MPL_OK;
@@ -199,6 +210,26 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
     static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
     return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue,
                           (timing && !ln_w) ? stats : nullptr, s);
+}
+
+size_t mpl_split_bf16x3_bytes(int N, int K) { return K >= 64 ? x3_operand_bytes(N, K) : 0; }
+
+int mpl_split_bf16x3(const float* W, int N, int K, uint16_t* dst, void* stream) {
+    if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
+    return launch_split_bf16x3(W, N, K, dst, (hipStream_t)stream);
+}
+
+int mpl_ln_linear_x3(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const uint16_t* W3,
+                     const float* bias, int N, int epilogue, const float* residual, float* y, float* stats,
+                     void* stream) {
+    if (!x || !W3 || !bias || !y || mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (ln_w) {
+        if (!stats) return MPL_E_INVALID;
+        int rc = launch_row_stats(x, M, K, K, stats, s);
+        if (rc) return rc;
+    }
+    return launch_x3_gemm(x, K, stats, ln_w, ln_b, eps, W3, bias, residual, N, y, N, M, N, K, epilogue, nullptr, s);
 }
 
 int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {

@@ -68,6 +68,15 @@ bool qkv_attention_fusable(int n_tok, int dim, int heads);
 int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
                             float eps, const float* W, const float* bias, int n_tok, int heads, float* att,
                             hipStream_t s);
+// fp32 GEMMs on the bf16 matrix cores (3-way bf16 operand split), x3_gemm.hip
+size_t x3_operand_bytes(int N, int K);
+int launch_split_bf16x3(const float* W, int N, int K, unsigned short* dst, hipStream_t s);
+int launch_x3_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
+                   const unsigned short* W3, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+                   int K, int epi, float* stats_out, hipStream_t s);
+int launch_x3_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
+                            float eps, const unsigned short* W3, const float* bias, int n_tok, int heads, float* att,
+                            hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
 // y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]

@@ -15,39 +15,10 @@
 // lane fetches its four k values with ONE 128-bit LDS read.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "gemm_common.hpp"
 
 
 namespace mpl {
-
-constexpr int BM = 64;
-constexpr int BN = 136;
-constexpr int BNP = 144;  // 9 MFMA column tiles
-constexpr int NT = 9;
-constexpr int BK = 32;
-
-// ------------------------------------------------------------------------------------------
-// LayerNorm statistics travel as per-slice partials so that the GEMMs that PRODUCE a row tile by tile can emit
-// them from their epilogue (no extra pass over x, no atomics):  stats[(m * NS + s) * 2 + {0,1}] = {mean_s, M2_s}
-// of columns [s*SL, (s+1)*SL) of row m, SL = 136 when K is a multiple of 136 (the GEMM column-tile width), else
-// K (one slice).  The consumer combines them with Chan's parallel formula:
-//   mean = avg_s(mean_s),  M2 = sum_s M2_s + SL * sum_s (mean_s - mean)^2,  rstd = 1/sqrt(M2 / K + eps).
-// Two-pass inside a slice + exact combination across slices: no E[x^2]-E[x]^2 cancellation anywhere.
-inline int ln_slice_len(int K) { return (K % BN == 0) ? BN : K; }
-
-__device__ __forceinline__ void ln_combine(const float* __restrict__ st, int ns, int sl, int K, float eps, float& mu,
-                                           float& rs) {
-    float msum = 0.f;
-    for (int i = 0; i < ns; ++i) msum += st[2 * i];
-    const float mean = msum / (float)ns;
-    float m2 = 0.f;
-    for (int i = 0; i < ns; ++i) {
-        const float d = st[2 * i] - mean;
-        m2 += st[2 * i + 1] + (float)sl * d * d;
-    }
-    mu = mean;
-    rs = 1.0f / sqrtf(m2 / (float)K + eps);
-}
 
 // one wave per row; used for rows that no GEMM epilogue produced (the SPT output, stand-alone mpl_ln_linear)
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int M, int K, int ldx, int sl,
@@ -86,86 +57,6 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStr
     return hip_check_launch();
 }
 
-// Epilogue shared by both GEMM kernels.  acc[n][r] = D[row0 + r][n0 + 16 n + li].  All loads (bias, residual)
-// are issued before the first store: vmcnt counts stores too, so a load queued behind stores would wait for
-// them to drain.
-// Residual values of this lane's 36 outputs, loaded with clamped (always valid) addresses so that exactly
-// NT * 4 load instructions are issued: the k loop prefetches them two stages before the epilogue and has to
-// account for them in its counted vmcnt waits.
-constexpr int RES_LOADS = NT * 4;
-__device__ __forceinline__ void load_residual(float (&rv)[NT][4], const float* R, int ldr, int M, int N, int row0,
-                                              int n0, int li) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        int col = n0 + n * 16 + li;
-        col = col < N ? col : N - 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = row0 + r;
-            row = row < M ? row : M - 1;
-            rv[n][r] = R[(size_t)row * ldr + col];
-        }
-    }
-}
-
-template <int EPI>
-__device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], const float* __restrict__ bias,
-                                                    const float (&rv)[NT][4], float* C, int ldc, int M, int N,
-                                                    int row0, int n0, int li, float* stats_out, int stats_ns) {
-    const int n_end = (n0 + BN < N) ? (n0 + BN) : N;
-    float bv[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n0 + n * 16 + li;
-        bv[n] = col < n_end ? bias[col] : 0.f;
-    }
-    float v[NT][4];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n0 + n * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = acc[n][r] + bv[n];
-            if (EPI == MPL_EPI_BIAS_GELU) t = gelu_erf(t);
-            if (EPI == MPL_EPI_BIAS_RESIDUAL) t += rv[n][r];
-            v[n][r] = t;
-            if (col < n_end && row0 + r < M) C[(size_t)(row0 + r) * ldc + col] = t;
-        }
-    }
-    if (EPI == MPL_EPI_BIAS_RESIDUAL && stats_out) {
-        // LayerNorm partials of this 136-column slice for the rows of this wave (the tile is a full slice:
-        // the host only passes stats_out when N is a multiple of 136).  A row's 136 values sit in the 16 lanes
-        // of one kq group (8 full column tiles + lanes li < 8 of the 9th).
-        const bool tail = li < 8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = tail ? v[8][r] : 0.f;
-#pragma unroll
-            for (int n = 0; n < 8; ++n) s += v[n][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-            const float mean = s * (1.0f / (float)BN);
-            float q = 0.f;
-            if (tail) {
-                const float d = v[8][r] - mean;
-                q = d * d;
-            }
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const float d = v[n][r] - mean;
-                q = fmaf(d, d, q);
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
-            if (li == 0 && row0 + r < M) {
-                float* so = stats_out + ((size_t)(row0 + r) * stats_ns + n0 / BN) * 2;
-                so[0] = mean;
-                so[1] = q;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // DMA-staged, multi-group kernel (the product path).
 //
@@ -186,61 +77,6 @@ __device__ __forceinline__ void store_tile_epilogue(const f32x4 (&acc)[NT], cons
 // The DMA is issued from inline asm: with the builtin hipcc assumes the LDS write aliases every later ds_read
 // and drains vmcnt(0) in front of it; the asm DMA is invisible to the compiler's counters and is tracked by the
 // explicit counted waits.  LayerNorm is applied when the A fragment is read.
-constexpr int ATT_SCORE_FLOATS = 3584;  // LDS left for attention scores beside the 64 x 412 q|k|v tile in a 2 x 60 kB ring
-constexpr int SUB_A = BM * BK * 4;   // 8192 bytes
-constexpr int SUB_B = BN * BK * 4;   // 17408 bytes per column group
-template <int NG> struct SubStage {
-    static constexpr int GB = SUB_A + NG * SUB_B;       // gamma/beta piece offset
-    static constexpr int BYTES = GB + 1024;
-    static constexpr int PIECES = 8 + 17 * NG + 1;      // incl. the gamma/beta piece
-};
-
-// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
-// M0 is saved/restored inside the statement (the compiler does not preserve it around asm).
-__device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_dst)
-        : "memory");
-}
-
-// Fast form for the A / W pieces: address = 64-bit SGPR base (advanced by the k offset once per stage) + 32-bit
-// per-lane VGPR offset that never changes, so a piece costs three instructions.  M0 is saved / restored once
-// per group by the caller (dma_m0_save / dma_m0_restore).
-__device__ __forceinline__ void dma16_fast(unsigned voff, const float* sbase, unsigned lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1"
-        :
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-__device__ __forceinline__ unsigned dma_m0_save() {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-    return keep;
-}
-__device__ __forceinline__ void dma_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
-
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vm(int n) {
-#define MPL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n) {
-        MPL_W(0) MPL_W(1) MPL_W(2) MPL_W(3) MPL_W(4) MPL_W(5) MPL_W(6) MPL_W(7) MPL_W(8) MPL_W(9) MPL_W(10) MPL_W(11) MPL_W(12) MPL_W(13) MPL_W(14) MPL_W(15) MPL_W(16) MPL_W(17) MPL_W(18) MPL_W(19) MPL_W(20)
-        MPL_W(21) MPL_W(22) MPL_W(23) MPL_W(24) MPL_W(25) MPL_W(26) MPL_W(27) MPL_W(28) MPL_W(29) MPL_W(30) MPL_W(31) MPL_W(32) MPL_W(33) MPL_W(34) MPL_W(35) MPL_W(36) MPL_W(37) MPL_W(38) MPL_W(39) MPL_W(40) MPL_W(41)
-        MPL_W(42) MPL_W(43) MPL_W(44) MPL_W(45) MPL_W(46) MPL_W(47) MPL_W(48) MPL_W(49) MPL_W(50) MPL_W(51) MPL_W(52) MPL_W(53) MPL_W(54) MPL_W(55) MPL_W(56) MPL_W(57) MPL_W(58) MPL_W(59) MPL_W(60) MPL_W(61) MPL_W(62)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef MPL_W
-}
-
 struct Frag {
     float4 a, g, be;
     float4 b[NT];
@@ -272,7 +108,9 @@ __device__ __forceinline__ void load_frag(Frag& f, const char* st, int step, int
 // LDW: one extra "loader" wave per workgroup issues every DMA piece and owns the counted vmcnt waits; the compute
 // waves then execute nothing but barrier -> fragment reads -> MFMA (a DMA piece costs ~40 issue cycles, 7 of them
 // per k-tile were 10 % of a compute wave's critical path).
-template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false, bool LDW = false>
+// PF (with LDW, NST = 3, KS = KG = 1): the loader keeps TWO stages landed at every barrier, so a compute wave reads
+// the first fragment of stage t+1 under the last MFMA block of stage t: no ds_read latency behind the barrier.
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false, bool LDW = false, bool PF = false>
 __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_kernel(const float* __restrict__ A, int lda,
                                                                        const float* __restrict__ stats,
                                                                        const float* __restrict__ ln_w,
@@ -284,6 +122,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
                                                                        float* stats_out, int att_ntok, int att_hd,
                                                                        float* att_out) {
     static_assert(!ATT || (NG == 3 && KG == 1 && EPI == MPL_EPI_BIAS), "fused attention needs the q|k|v geometry");
+    static_assert(!PF || (LDW && NST == 3 && KS == 1 && KG == 1), "fragment prefetch needs the loader wave and a 3-stage ring");
     typedef SubStage<NG> SS;
     constexpr int NW = 4 * NG * KG;                  // compute waves: 4 row groups x NG column groups x KG k groups
     constexpr int NTHREADS = 64 * NW + (LDW ? 64 : 0);
@@ -451,6 +290,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
 #pragma unroll
             for (int j = 1; j <= NST - 2; ++j)
                 if (t + j < T) allow += l_pieces(t + j);
+            if (PF) allow = 0;                              // stages t and t+1 are both landed at barrier t
             wait_vm(allow);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -472,6 +312,23 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
     // bench-only phase timing (ABL & 4): shader-clock cycles summed over the stages of this wave
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, acc_wait = 0, acc_bar = 0, acc_issue = 0, acc_comp = 0;
     const unsigned long long t_begin = (ABL & 4) ? __builtin_amdgcn_s_memtime() : 0;
+    auto mma_step = [&](Frag& c) {              // LayerNorm the A fragment in registers, then 4 x NT MFMAs
+        if (LN) {
+            c.a.x = (c.a.x - mu) * rs * c.g.x + c.be.x;
+            c.a.y = (c.a.y - mu) * rs * c.g.y + c.be.y;
+            c.a.z = (c.a.z - mu) * rs * c.g.z + c.be.z;
+            c.a.w = (c.a.w - mu) * rs * c.g.w + c.be.w;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.x, c.b[n].x, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.y, c.b[n].y, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.z, c.b[n].z, acc[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.w, c.b[n].w, acc[n]);
+    };
+    Frag pf[2];                                  // PF: fragment registers that live across the stage barrier
     for (int t = 0; t < T; ++t) {
         if (ABL & 4) tk0 = __builtin_amdgcn_s_memtime();
         // stage t has landed for this wave once only the pieces of stages t+1 .. t+NST-2 are outstanding
@@ -495,6 +352,20 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
         if (ABL & 4) tk3 = __builtin_amdgcn_s_memtime();
 
         const char* st = smem + (t % NST) * STAGE;
+        if (PF) {
+            // two 16-deep k steps per stage; pf[0] of stage t was read under the last MFMA block of stage t-1
+            if (t == 0) load_frag<LN, NG>(pf[0], st, 0, rg, cg, li, kq, swz);
+            load_frag<LN, NG>(pf[1], st, 1, rg, cg, li, kq, swz);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(pf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            // unconditional (the last one reads a stale slot and is dropped): a branch here makes hipcc merge the
+            // two lgkmcnt states conservatively and wait for THESE reads before the MFMAs of pf[1] below
+            load_frag<LN, NG>(pf[0], smem + ((t + 1) % NST) * STAGE, 0, rg, cg, li, kq, swz);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(pf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         const int nstep = 2 * ((t == T - 1) ? last_sub : KS);   // 16-deep k steps in this stage
         // This wave owns steps kg, kg + KG, ...  Fragment registers are double buffered by hand (reads of the
         // next own step are issued before the 36 MFMAs of the current one); sched_barrier(0) keeps hipcc from
@@ -507,23 +378,10 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
             if (i < nstep) {
                 if (j + 1 < SPW && i + KG < nstep) load_frag<LN, NG>(f[(j + 1) & 1], st, i + KG, rg, cg, li, kq, swz);
                 __builtin_amdgcn_sched_barrier(0);
-                Frag& c = f[j & 1];
-                if (LN) {
-                    c.a.x = (c.a.x - mu) * rs * c.g.x + c.be.x;
-                    c.a.y = (c.a.y - mu) * rs * c.g.y + c.be.y;
-                    c.a.z = (c.a.z - mu) * rs * c.g.z + c.be.z;
-                    c.a.w = (c.a.w - mu) * rs * c.g.w + c.be.w;
-                }
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.x, c.b[n].x, acc[n]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.y, c.b[n].y, acc[n]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.z, c.b[n].z, acc[n]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = mfma16(c.a.w, c.b[n].w, acc[n]);
+                mma_step(f[j & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         if (ABL & 4) {
             const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
@@ -564,7 +422,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
     }
     if (ATT) {
         // ---- fused attention epilogue.  T[64][412]: q | k | v (+bias) of this workgroup's 136 channels.
-        constexpr int TS = 3 * BN + 4;                      // row stride (floats); +4 breaks the bank alignment
+        constexpr int TS = ATT_TS;
         float* T = reinterpret_cast<float*>(smem);
         float* SC = T + BM * TS;                            // scores [S][HP][n_tok][n_tok]
         __syncthreads();                                    // every wave is done reading the last stage
@@ -580,58 +438,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
                 }
             }
         }
-        __syncthreads();
-        const int nt = att_ntok, hd = att_hd, hd4 = hd >> 2;
-        const int HP = BN / hd, S = BM / nt, nn = nt * nt;
-        const float scale = 1.0f / sqrtf((float)hd);
-        constexpr int NTH = 64 * NW;   // compute waves only (the loader wave just matches the barriers)
-        for (int t = tid; t < S * HP * nn; t += NTH) {
-            const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
-            const float* q = T + (sq * nt + i) * TS + hh * hd;
-            const float* k = T + (sq * nt + j) * TS + BN + hh * hd;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int e = 0; e < hd4; ++e) {
-                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
-                s0 = fmaf(a.x, b.x, s0);
-                s1 = fmaf(a.y, b.y, s1);
-                s2 = fmaf(a.z, b.z, s2);
-                s3 = fmaf(a.w, b.w, s3);
-            }
-            SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
-        }
-        __syncthreads();
-        for (int t = tid; t < S * HP * nt; t += NTH) {
-            float* pr = SC + t * nt;
-            float mx = pr[0];
-            for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
-            float l = 0.f;
-            for (int j = 0; j < nt; ++j) {
-                const float e = __expf(pr[j] - mx);
-                pr[j] = e;
-                l += e;
-            }
-            const float inv = 1.0f / l;
-            for (int j = 0; j < nt; ++j) pr[j] *= inv;
-        }
-        __syncthreads();
-        constexpr int C4 = BN / 4;                          // 34 float4 per output row slice
-        for (int t = tid; t < BM * C4; t += NTH) {
-            const int c = t % C4, row = t / C4;
-            const int sq = row / nt, i = row - sq * nt;
-            const int hh = (4 * c) / hd;
-            const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
-            const float* v = T + (sq * nt) * TS + 2 * BN + 4 * c;
-            float4 o = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < nt; ++j) {
-                const float4 vv = ld4(v + j * TS);
-                const float pj = pr[j];
-                o.x = fmaf(pj, vv.x, o.x);
-                o.y = fmaf(pj, vv.y, o.y);
-                o.z = fmaf(pj, vv.z, o.z);
-                o.w = fmaf(pj, vv.w, o.w);
-            }
-            if (m0 + row < M) st4(att_out + (size_t)(m0 + row) * Dq + n0 + 4 * c, o);
-        }
+        attention_on_tile(T, SC, tid, 64 * NW, att_ntok, att_hd, att_out, m0, n0, M, Dq);
         return;
     }
     store_tile_epilogue<EPI>(acc, bias, rv, C, ldc, M, N, m0 + rg * 16 + 4 * kq, colbase(cg), li,
@@ -649,7 +456,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
     }
 }
 
-template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false, bool LDW = false>
+template <int EPI, bool LN, int NG, int KG, int KS, int NST, int ABL = 0, bool ATT = false, bool LDW = false, bool PF = false>
 static int launch_ng(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
                      const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, float eps,
                      float* stats_out, hipStream_t s, int att_ntok = 0, int att_hd = 0, float* att_out = nullptr) {
@@ -662,16 +469,248 @@ static int launch_ng(const float* A, int lda, const float* stats, const float* l
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW>,
+        if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW, PF>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MPL_E_LAUNCH;
         attr_set[dev] = true;
     }
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW>), dim3(gm * gn),
+    hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW, PF>), dim3(gm * gn),
                        dim3(256 * NG * KG + (LDW ? 64 : 0)), LDS, s,
                        A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out, att_ntok,
                        att_hd, att_out);
+    return hip_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Column-split variant for launches with at most ONE workgroup per CU (N = D at B V <= 4096 rows: proj, fc2).
+// A 4-wave workgroup alone on a CU runs one wave per SIMD, and a single wave cannot overlap its own fragment reads
+// with its MFMAs (tools/loop_probe.hip: 105 TFLOP/s with one wave per SIMD against 125-139 with two or three).
+// Here the same 64 x 136 tile is computed by EIGHT waves: wave w and wave w + 4 (same SIMD) share row group w & 3
+// and take column tiles 0..4 and 5..8 of the 9, so every SIMD keeps the same 72 MFMAs per k-tile but from two
+// independent instruction streams.  A ninth wave issues all DMA (see LDW above).  The k order of every output
+// element is unchanged, and the epilogue applies the 4-wave kernel's own operations in its order (the second half hands
+// its final values over through LDS for the LayerNorm partials), so results are bitwise identical to ln_gemm_ng_kernel -- batch-size invariance is preserved.
+template <int NTW>
+struct FragW {
+    float4 a, g, be;
+    float4 b[NTW];
+};
+template <bool LN, int NTW>
+__device__ __forceinline__ void load_frag_w(FragW<NTW>& f, const char* sb, int half, int rg, int tile0, int li, int kq, int swz) {
+    typedef SubStage<1> SS;
+    const int cl = (half << 2) + kq;
+    const int cc = (cl ^ swz) << 2;
+    const float* as = reinterpret_cast<const float*>(sb) + (rg * 16 + li) * BK;
+    const float* bs = reinterpret_cast<const float*>(sb + SUB_A) + (tile0 * 16 + li) * BK;
+    f.a = ld4(as + cc);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) f.b[n] = ld4(bs + n * 16 * BK + cc);
+    if (LN) {
+        const float* gb = reinterpret_cast<const float*>(sb + SS::GB);
+        f.g = ld4(gb + 4 * cl);
+        f.be = ld4(gb + 32 + 4 * cl);
+    }
+}
+template <bool LN, int NTW>
+__device__ __forceinline__ void mma_step_w(FragW<NTW>& c, f32x4 (&acc)[NTW], float mu, float rs) {
+    if (LN) {
+        c.a.x = (c.a.x - mu) * rs * c.g.x + c.be.x;
+        c.a.y = (c.a.y - mu) * rs * c.g.y + c.be.y;
+        c.a.z = (c.a.z - mu) * rs * c.g.z + c.be.z;
+        c.a.w = (c.a.w - mu) * rs * c.g.w + c.be.w;
+    }
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = mfma16(c.a.x, c.b[n].x, acc[n]);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = mfma16(c.a.y, c.b[n].y, acc[n]);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = mfma16(c.a.z, c.b[n].z, acc[n]);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = mfma16(c.a.w, c.b[n].w, acc[n]);
+}
+// k loop of one compute wave over its NTW column tiles starting at tile0; the residual loads of those tiles are
+// issued two stages before the epilogue
+template <int EPI, bool LN, int NST, int NTW>
+__device__ __forceinline__ void cs_k_loop(f32x4 (&acc)[NTW], float (&rv)[NTW][4], const char* smem, int T, int rg, int tile0,
+                                          int li, int kq, float mu, float rs, const float* R, int ldr, int M, int N,
+                                          int row0, int n0) {
+    constexpr int STAGE = SubStage<1>::BYTES;
+    const int swz = (li >> 1) & 7;
+    const int t_res = T >= 2 ? T - 2 : 0;
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_s_barrier();           // the loader saw stage t land; everyone is done reading stage t-1
+        asm volatile("" ::: "memory");
+        if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res) load_residual_w<NTW>(rv, R, ldr, M, N, row0, n0 + tile0 * 16, li);
+        const char* st = smem + (t % NST) * STAGE;
+        FragW<NTW> f0, f1;
+        load_frag_w<LN, NTW>(f0, st, 0, rg, tile0, li, kq, swz);
+        load_frag_w<LN, NTW>(f1, st, 1, rg, tile0, li, kq, swz);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step_w<LN, NTW>(f0, acc, mu, rs);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step_w<LN, NTW>(f1, acc, mu, rs);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int CS_T0 = 5;                         // column tiles of the first half (waves 0..3); the rest go to waves 4..7
+constexpr int CS_XFER = 4 * (NT - CS_T0) * 64 * 16;   // accumulator hand-over area behind the ring (16 KiB)
+
+template <int EPI, bool LN, int NST>
+__global__ __launch_bounds__(576, 1) void ln_gemm_cs_kernel(const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             const float* R, int ldr, float* C, int ldc, int M, int N,
+                                                             int K, int grid_m, int grid_n, float eps, float* stats_out) {
+    typedef SubStage<1> SS;
+    constexpr int STAGE = SS::BYTES;
+    constexpr int NTHREADS = 576;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7 compute, 8 loader
+    const int rg = wave & 3, half = (wave >> 2) & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        if ((grid_m & 7) == 0) {  // XCD-aware, as in ln_gemm_ng_kernel
+            const int per = grid_m >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            tm = xcd * per + (i % per);
+            tn = i / per;
+        } else {
+            tm = b % grid_m;
+            tn = b / grid_m;
+        }
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    float mu = 0.f, rs = 1.f;
+    if (LN && wave < 8) {
+        int m = m0 + rg * 16 + li;
+        m = m < M ? m : M - 1;
+        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
+        ln_combine(stats + (size_t)m * ns * 2, ns, sl, K, eps, mu, rs);
+        asm volatile("" : "+v"(mu), "+v"(rs));
+    }
+    if (!LN) {
+        for (int i = tid; i < NST * 256; i += NTHREADS)
+            reinterpret_cast<float*>(smem + (i >> 8) * STAGE + SS::GB)[i & 255] = 0.f;
+        __syncthreads();
+    }
+    const int T = K / BK;
+    if (wave == 8) {
+        // ---------------- loader wave: 8 A pieces + 17 W pieces (+ gamma/beta) per k-tile
+        unsigned lA[8], lW[17];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = p * 8 + (lane >> 3);
+            int m = m0 + r;
+            m = m < M ? m : M - 1;
+            lA[p] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+            asm volatile("" : "+v"(lA[p]));
+        }
+#pragma unroll
+        for (int p = 0; p < 17; ++p) {
+            const int r = p * 8 + (lane >> 3);
+            int n = n0 + r;
+            n = n < N ? n : N - 1;
+            lW[p] = (unsigned)(((size_t)n * K + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+            asm volatile("" : "+v"(lW[p]));
+        }
+        const float* gb_src = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        constexpr int PIECES = 8 + 17 + (LN ? 1 : 0);
+        auto l_issue = [&](int t) {
+            const unsigned keep = dma_m0_save();
+            const unsigned st = lds0 + (unsigned)((t % NST) * STAGE);
+            const int k0 = t * BK;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) dma16_fast(lA[p], A + k0, st + (unsigned)(p * 1024));
+#pragma unroll
+            for (int p = 0; p < 17; ++p) dma16_fast(lW[p], W + k0, st + (unsigned)((8 + p) * 1024));
+            if (LN) dma16(gb_src + k0, st + (unsigned)SS::GB);
+            dma_m0_restore(keep);
+        };
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t)
+            if (t < T) l_issue(t);
+        for (int t = 0; t < T; ++t) {
+            int allow = 0;
+#pragma unroll
+            for (int j = 1; j <= NST - 2; ++j)
+                if (t + j < T) allow += PIECES;
+            wait_vm(allow);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NST - 1 < T) l_issue(t + NST - 1);
+        }
+        __builtin_amdgcn_s_barrier();            // matches the accumulator hand-over barrier below
+        return;
+    }
+
+    const int row0 = m0 + rg * 16 + 4 * kq;
+    float4* xfer = reinterpret_cast<float4*>(smem + NST * STAGE);
+    constexpr int NT1 = NT - CS_T0;
+    const bool want_stats = EPI == MPL_EPI_BIAS_RESIDUAL && stats_out != nullptr;
+    if (half) {
+        f32x4 acc[NT1];
+#pragma unroll
+        for (int n = 0; n < NT1; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float rv[NT1][4], v[NT1][4];
+        cs_k_loop<EPI, LN, NST, NT1>(acc, rv, smem, T, rg, CS_T0, li, kq, mu, rs, R, ldr, M, N, row0, n0);
+        tile_values_store<EPI, NT1>(acc, bias, rv, C, ldc, M, N, row0, n0, n0 + CS_T0 * 16, li, v);
+        if (want_stats) {
+#pragma unroll
+            for (int n = 0; n < NT1; ++n) xfer[(rg * NT1 + n) * 64 + lane] = float4{v[n][0], v[n][1], v[n][2], v[n][3]};
+        }
+        __syncthreads();
+        return;
+    }
+    f32x4 acc[CS_T0];
+#pragma unroll
+    for (int n = 0; n < CS_T0; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rv[CS_T0][4], v0[CS_T0][4];
+    cs_k_loop<EPI, LN, NST, CS_T0>(acc, rv, smem, T, rg, 0, li, kq, mu, rs, R, ldr, M, N, row0, n0);
+    tile_values_store<EPI, CS_T0>(acc, bias, rv, C, ldc, M, N, row0, n0, n0, li, v0);
+    __syncthreads();
+    if (want_stats) {   // the other half's final values: the slice statistics are reduced in the 4-wave kernel's order
+        float v[NT][4];
+#pragma unroll
+        for (int n = 0; n < CS_T0; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[n][r] = v0[n][r];
+#pragma unroll
+        for (int n = 0; n < NT1; ++n) {
+            const float4 x = xfer[(rg * NT1 + n) * 64 + lane];
+            v[CS_T0 + n][0] = x.x; v[CS_T0 + n][1] = x.y; v[CS_T0 + n][2] = x.z; v[CS_T0 + n][3] = x.w;
+        }
+        slice_stats_store(v, stats_out, N / BN, M, row0, n0, li);
+    }
+}
+
+template <int EPI, bool LN, int NST>
+static int launch_cs(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, const float* W,
+                     const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, float eps,
+                     float* stats_out, hipStream_t s) {
+    constexpr int LDS = NST * SubStage<1>::BYTES + CS_XFER;
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)ln_gemm_cs_kernel<EPI, LN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS) != hipSuccess)
+            return MPL_E_LAUNCH;
+        attr_set[dev] = true;
+    }
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL((ln_gemm_cs_kernel<EPI, LN, NST>), dim3(gm * gn), dim3(576), LDS, s, A, lda, stats, ln_w, ln_b, W,
+                       bias, R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out);
     return hip_check_launch();
 }
 
@@ -713,6 +752,9 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
         case 9112: return launch_ng<EPI, LN, 1, 1, 1, 2, 0, false, true>(MPL_ARGS2);   // loader-wave variants
         case 9113: return launch_ng<EPI, LN, 1, 1, 1, 3, 0, false, true>(MPL_ARGS2);
         case 9312: return launch_ng<EPI, LN, 3, 1, 1, 2, 0, false, true>(MPL_ARGS2);
+        case 7112: return launch_cs<EPI, LN, 2>(MPL_ARGS2);                              // column-split variants
+        case 7113: return launch_cs<EPI, LN, 3>(MPL_ARGS2);
+        case 8113: return launch_ng<EPI, LN, 1, 1, 1, 3, 0, false, true, true>(MPL_ARGS2);   // + fragment prefetch
         default: break;
     }
     if (ng == 3) return launch_ng<EPI, LN, 3, 1, 1, 2>(MPL_ARGS2);
@@ -726,8 +768,13 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
         const int per_cu = (wgs + 255) / 256;
         return rounds * (per_cu < k ? per_cu : k);
     };
-    // a lone workgroup per CU has nobody to hide its DMA issue behind: give it a loader wave (measured: proj
-    // 31.4 -> 29.9 us, fc2 56.2 -> 53.1 us; neutral or slightly negative once two workgroups share the CU)
+    // One workgroup per CU (or two of the register-light non-residual variants): the 8-wave column-split kernel
+    // with its loader wave.  Measured on MI355X at M = 4096, D = 544 against the best 4-wave configuration:
+    // proj 29.1 -> 27.1 us, fc2 52.2 -> 48.7 us, fc1 (512 workgroups, two per CU) 56.0 -> 52.0 us; with more
+    // workgroups per CU the 4-wave kernels below win (D = 1088: fc1 186 vs 210 us).  Bitwise identical results.
+    static const int nocs = getenv("MPL_GEMM_NOCS") ? atoi(getenv("MPL_GEMM_NOCS")) : 0;   // bench-only A/B switch
+    if (!(nocs & 1) && wgs <= 256) return launch_cs<EPI, LN, 2>(MPL_ARGS2);
+    if (!(nocs & 2) && EPI != MPL_EPI_BIAS_RESIDUAL && wgs <= 512) return launch_cs<EPI, LN, 2>(MPL_ARGS2);
     if (wgs <= 256) return launch_ng<EPI, LN, 1, 1, 1, 2, 0, false, true>(MPL_ARGS2);
     if (cost(3) <= cost(2)) return launch_ng<EPI, LN, 1, 1, 1, 2>(MPL_ARGS2);
     return launch_ng<EPI, LN, 1, 1, 1, 3>(MPL_ARGS2);

@@ -242,13 +242,20 @@ class MultiView_MPL(nn.Module):
         """"fp32" (default, 1e-6 from the reference) or "bf16": the FPT block GEMMs run on the bf16 matrix cores
         (bf16 operands, fp32 accumulate; everything else stays fp32) -- BASELINE.json configs[2].  The bf16 weight
         copies are derived data, rebuilt whenever a parameter's storage or version changes."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("matmul precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "fp32_mfma", "bf16"):
+            raise ValueError("matmul precision must be 'fp32', 'fp32_mfma' or 'bf16'")
         if precision == "bf16" and self.FPT_blocks_view_keypoint_tokens:
             raise NotImplementedError("bf16 matrix-core path covers the view-token FPT blocks (K a multiple of 32 and 8)")
         self.matmul_precision = precision
         self._hip_cache = {}
         return self
+
+    def _x3_supported(self) -> bool:
+        """The split-operand GEMMs need the FPT width to be a multiple of 136 (544, 1088: every view-token model)."""
+        if self.no_transformer_fpt or len(self.blocks) == 0:
+            return False
+        d = self.blocks[0].attn.qkv.weight.shape[1]
+        return d % 136 == 0 and d >= 64
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _apply(self, fn, *a, **k):
@@ -319,8 +326,9 @@ class MultiView_MPL(nn.Module):
         plist = self._param_list()
         key = tuple(map(torch.Tensor.data_ptr, plist))
         bf16 = self.matmul_precision == "bf16"
-        if bf16:    # derived copies go stale on in-place updates too
-            key = key + ("bf16",) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b)[2:12:2])
+        x3 = self.matmul_precision == "fp32" and self._x3_supported()
+        if bf16 or x3:    # derived copies go stale on in-place updates too
+            key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b)[2:12:2])
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent
@@ -363,6 +371,16 @@ class MultiView_MPL(nn.Module):
                                                     torch.cuda.current_stream(device).cuda_stream), "mpl_convert_bf16")
                     w16_keep.append(c16)
                     ptrs.append(c16.data_ptr())
+            elif x3:
+                lib = cabi.load()
+                ptrs += [0, 0, 0, 0]
+                for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight):
+                    n, k = t.shape
+                    c3 = torch.empty(lib.mpl_split_bf16x3_bytes(n, k), dtype=torch.uint8, device=device)
+                    cabi.check(lib.mpl_split_bf16x3(t.data_ptr(), n, k, c3.data_ptr(),
+                                                    torch.cuda.current_stream(device).cuda_stream), "mpl_split_bf16x3")
+                    w16_keep.append(c3)
+                    ptrs.append(c3.data_ptr())
             fpt[l] = cabi.BlockWeights(*ptrs)
         w = cabi.Weights()
         w.spt_sets = base

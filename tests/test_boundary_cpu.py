@@ -126,7 +126,7 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == want
     cfg.flags |= cabi.F_RAYS_TOKEN
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
-    assert ctypes.sizeof(cabi.BlockWeights) == 128 and ctypes.sizeof(cabi.SptSet) == 48
+    assert ctypes.sizeof(cabi.BlockWeights) == 160 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
 
 

@@ -67,7 +67,21 @@ __global__ __launch_bounds__(64 * WAVES, 1) void probe(const float* g, float* ou
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (MODE >= 2) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-        if (MODE >= 1) {
+        if (MODE == 4 || MODE == 5) {   // P1 / P2 with the fragment reads interleaved into the MFMA stream (1 read : 3 MFMA)
+            if (MODE == 5) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+            load_frag(f[1], as, bs, ((4 + kq) ^ swz) << 2);
+            block36(f[0], acc);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(f[0], as, bs, (kq ^ swz) << 2);
+            block36(f[1], acc);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (MODE >= 1) {
             if (MODE >= 2) load_frag(f[0], as, bs, (kq ^ swz) << 2);
             load_frag(f[1], as, bs, ((4 + kq) ^ swz) << 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -110,6 +124,10 @@ int main() {
     run<1, 4>(g, out, "P1 +ds_read frags");
     run<2, 4>(g, out, "P2 +barrier");
     run<3, 4>(g, out, "P3 +DMA ring");
+    run<4, 4>(g, out, "P4 ds_read interleaved");
+    run<5, 4>(g, out, "P5 interleaved + barrier (PF)");
+    run<4, 8>(g, out, "P4 ds_read interleaved");
+    run<5, 8>(g, out, "P5 interleaved + barrier (PF)");
     run<0, 8>(g, out, "P0 regs only");
     run<1, 8>(g, out, "P1 +ds_read frags");
     run<2, 8>(g, out, "P2 +barrier");
