@@ -229,7 +229,9 @@ int mpl_ln_linear_x3(const float* x, int M, int K, const float* ln_w, const floa
         int rc = launch_row_stats(x, M, K, K, stats, s);
         if (rc) return rc;
     }
-    return launch_x3_gemm(x, K, stats, ln_w, ln_b, eps, W3, bias, residual, N, y, N, M, N, K, epilogue, nullptr, s);
+    static const bool dbg = getenv("MPL_X3_DBG") != nullptr;   // bench-only: phase timings land in `stats`
+    return launch_x3_gemm(x, K, stats, ln_w, ln_b, eps, W3, bias, residual, N, y, N, M, N, K, epilogue,
+                          (dbg && !ln_w && epilogue == MPL_EPI_BIAS_RESIDUAL) ? stats : nullptr, s);
 }
 
 int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {

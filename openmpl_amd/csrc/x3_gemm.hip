@@ -42,17 +42,20 @@ constexpr int X3_GB = SUB_A + X3_W;         // gamma/beta piece
 constexpr int X3_STAGE = X3_GB + 1024;      // 36864
 constexpr int X3_T0 = 5;                    // column tiles of waves 0..3; waves 4..7 take the other NT - 5
 
-// 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32)
+// 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32).  Written
+// stage by stage over the 8 elements so that the four packed chains interleave instead of stalling on each other.
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    float r[8], r2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        const float r = x[i] - (float)h;
-        const __bf16 m = (__bf16)r;
-        hi[i] = h;
-        mid[i] = m;
-        lo[i] = (__bf16)(r - (float)m);
-    }
+    for (int i = 0; i < 8; ++i) hi[i] = (__bf16)x[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i] - (float)hi[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mid[i] = (__bf16)r[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2[i] = r[i] - (float)mid[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = (__bf16)r2[i];
 }
 
 size_t x3_operand_bytes(int N, int K) {
@@ -113,11 +116,13 @@ struct X3Args {
     float* stats_out;
     int att_ntok, att_hd;
     float* att_out;
+    int abl;                                     // bench-only ablation mask (MPL_X3_ABL): 1 no ring refill
 };
 
 // Everything a compute wave does, for its NTW column tiles starting at tile `tile0`.
-template <int EPI, bool LN, int NPASS, int NST, int NTW>
+template <int EPI, bool LN, int NPASS, int NST, int NTW, bool DBG = false>
 __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, int wave, int tile0) {
+    const unsigned long long t_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
@@ -150,8 +155,9 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         asm volatile("" : "+v"(mu), "+v"(rs));   // consume the loads before the k loop (see ln_gemm.hip)
     }
 
-    // ---- DMA slots of this wave: A piece `wave` (8 rows), W pieces wave, wave + 8, wave + 16 (+ 24 + wave for
-    // waves 0..2), gamma/beta from wave 7
+    // ---- DMA slots of this wave: A piece `wave` (8 rows); a run of ADJACENT W pieces (waves 0..2: four starting at
+    // 4 w, waves 3..7: three starting at 3 w + 3) -- source and destination are both contiguous, so one M0 write
+    // serves the run and the pieces differ only by the instruction's immediate offset; gamma/beta from wave 7.
     unsigned voA;
     {
         const int r = wave * 8 + (lane >> 3);
@@ -160,32 +166,52 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         voA = (unsigned)(((size_t)m * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 5))) * sizeof(float));
         asm volatile("" : "+v"(voA));
     }
-    unsigned voW = (unsigned)(lane * 16);
+    const bool w_four = wave < 3;
+    const int w_first = w_four ? 4 * wave : 3 * wave + 3;
+    unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     asm volatile("" : "+v"(voW));
     const float* gb_src = ((lane & 8) ? a.ln_b : a.ln_w) + 4 * (lane & 7);
-    const bool w_extra = wave < 3;
     const bool gb_on = LN && wave == 7;
-    const int per_st = 4 + (w_extra ? 1 : 0) + (gb_on ? 1 : 0);
+    constexpr int MIN_PIECES = 4;                // every wave issues at least A + 3 W pieces per stage
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue_stage = [&](int t) {
-        const int pass = NPASS == 1 ? 0 : t / KT;
-        const int kt = t - pass * KT;
-        const int grp = colbase(pass) / BN;
-        const char* wsrc = a.W3 + ((size_t)grp * KT + kt) * X3_W;
-        const unsigned st = lds0 + (unsigned)((t % NST) * X3_STAGE);
+    // running state of the NEXT stage to issue (stages are issued strictly in order)
+    int is_t = 0, is_kt = 0, is_pass = 0;
+    unsigned is_slot = 0;                        // byte offset of its ring slot
+    const char* is_w = a.W3 + (size_t)(colbase(0) / BN) * KT * X3_W;
+    const float* is_a = a.A;
+    auto issue_next = [&]() {
+        const unsigned st = lds0 + is_slot;
         const unsigned keep = dma_m0_save();
-        dma16_fast(voA, a.A + kt * BK, st + (unsigned)(wave * 1024));
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            dma16_fast(voW, reinterpret_cast<const float*>(wsrc + (wave + 8 * j) * 1024),
-                       st + (unsigned)(SUB_A + (wave + 8 * j) * 1024));
-        if (w_extra) dma16_fast(voW, reinterpret_cast<const float*>(wsrc + (24 + wave) * 1024), st + (unsigned)(SUB_A + (24 + wave) * 1024));
-        if (gb_on) dma16(gb_src + kt * BK, st + (unsigned)X3_GB);
+        dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:2048"
+            :
+            : "v"(voW), "s"(is_w), "s"(st + (unsigned)(SUB_A + w_first * 1024))
+            : "memory");
+        if (w_four) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(is_w) : "memory");
+        if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
         dma_m0_restore(keep);
+        ++is_t;
+        is_slot += X3_STAGE;
+        if (is_slot == NST * X3_STAGE) is_slot = 0;
+        is_a += BK;
+        is_w += X3_W;
+        if (NPASS > 1 && ++is_kt == KT) {        // next pass: k restarts, W moves to the next of q | k | v
+            is_kt = 0;
+            ++is_pass;
+            is_a = a.A;
+            is_w = a.W3 + (size_t)(colbase(is_pass) / BN) * KT * X3_W;
+        } else if (NPASS == 1) {
+            ++is_kt;
+        }
     };
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-        if (t < T) issue_stage(t);
+    for (int t = 0; t < NST; ++t)
+        if (t < T) issue_next();
 
     f32x4 acc[NPASS][NTW];
 #pragma unroll
@@ -196,66 +222,189 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     const int row0 = m0 + rg * 16 + 4 * kq;
     const int t_res = T - 2;
     const int key = (li >> 1) & 5;
-    const int RES = NTW * 4;
+    constexpr int NB0 = (NTW + 1) / 2, NB1 = NTW - NB0;   // column tiles of the two B batches (3+2 or 2+2)
 
+    // Software pipeline.  The barrier sits in the MIDDLE of an iteration: by then a wave has read everything of
+    // stage t into registers, so the barrier both frees slot t % NST for the DMA of stage t + NST and publishes
+    // stage t + 1, whose A fragment (LayerNorm + 3-way split: ~50 VALU ops) is prepared while the matrix pipe works
+    // on the second B batch of stage t (sched_group_barrier: one MFMA, then four VALU ops, repeated).  The last
+    // iteration prepares a stage that does not exist (stale LDS, results unused): no special cases in the body.
+    bf16x8 A0[3], A1[3];                         // split A fragment (hi, mid, lo): current / next, ping-pong
+    bf16x8 b0h[NB0], b0m[NB0], b0l[NB0];         // B batch 0 of the current stage
+    auto read_a = [&](unsigned slot, float (&x)[8], float (&gg)[8], float (&ee)[8]) {
+        const char* st = smem + slot;
+        // A fragment of 16x16x32: lane (i, kq) holds A[i][8 kq .. 8 kq + 7] = logical 16-B columns 2kq, 2kq+1
+        const float* as = reinterpret_cast<const float*>(st) + (rg * 16 + li) * BK;
+        const float4 a0 = ld4(as + (((2 * kq) ^ key) << 2)), a1 = ld4(as + (((2 * kq + 1) ^ key) << 2));
+        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+        if (LN) {
+            const float* gb = reinterpret_cast<const float*>(st + X3_GB);
+            const float4 g0 = ld4(gb + 8 * kq), g1 = ld4(gb + 8 * kq + 4), e0 = ld4(gb + 32 + 8 * kq), e1 = ld4(gb + 36 + 8 * kq);
+            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+            ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
+        }
+    };
+    auto norm_split = [&](float (&x)[8], const float (&gg)[8], const float (&ee)[8], bf16x8 (&o)[3]) {
+        if (LN) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = (x[i] - mu) * rs * gg[i] + ee[i];
+        }
+        split3(x, o[0], o[1], o[2]);
+    };
+    auto b_base = [&](unsigned slot) -> const bf16x8* {
+        return reinterpret_cast<const bf16x8*>(smem + slot + SUB_A) + tile0 * 3 * 64 + lane;
+    };
+    auto read_b0 = [&](unsigned slot) {
+        const bf16x8* bs = b_base(slot);
+#pragma unroll
+        for (int n = 0; n < NB0; ++n) { b0h[n] = bs[(n * 3 + 0) * 64]; b0m[n] = bs[(n * 3 + 1) * 64]; b0l[n] = bs[(n * 3 + 2) * 64]; }
+    };
+    {   // prologue: stage 0 landed for everyone
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float x[8], gg[8], ee[8];
+        read_a(0, x, gg, ee);
+        read_b0(0);
+        norm_split(x, gg, ee, A0);
+    }
+    unsigned slot_c = 0;                         // ring slot (byte offset) of the current stage
+    auto slot_after = [](unsigned sl) -> unsigned { return sl + X3_STAGE == NST * X3_STAGE ? 0u : sl + X3_STAGE; };
+#define MPL_X3(AP, BP, NN, OFF)                   \
+    _Pragma("unroll") for (int n = 0; n < NN; ++n) \
+        accp[OFF + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AP, BP[n], accp[OFF + n], 0, 0, 0);
+    // one stage: MFMAs of stage t from `cur`, split fragment of stage t + 1 into `nxt`
+    unsigned long long dbg[5] = {0, 0, 0, 0, 0};
+    const unsigned long long t_loop = DBG ? __builtin_amdgcn_s_memtime() : 0;
+    auto now = [] {
+        const unsigned long long v = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return v;
+    };
+    auto stage = [&](int t, f32x4 (&accp)[NTW], const bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (DBG) s0 = now();
+        const unsigned slot_n = slot_after(slot_c);
+        bf16x8 b1h[NB1], b1m[NB1], b1l[NB1];
+        {
+            const bf16x8* bs = b_base(slot_c) + NB0 * 3 * 64;
+#pragma unroll
+            for (int n = 0; n < NB1; ++n) { b1h[n] = bs[(n * 3 + 0) * 64]; b1m[n] = bs[(n * 3 + 1) * 64]; b1l[n] = bs[(n * 3 + 2) * 64]; }
+        }
+        MPL_X3(cur[2], b0h, NB0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        // refill the slot the previous barrier freed (stage t-1+NST) under the matrix pipe's shadow: the batch-0
+        // MFMAs have no VALU work to pair with, the DMA issue is scalar + 4..6 VMEM instructions
+        if (t >= 1 && is_t < T && !(a.abl & 1)) issue_next();
+        __builtin_amdgcn_sched_barrier(0);
+        MPL_X3(cur[0], b0l, NB0, 0)
+        MPL_X3(cur[1], b0m, NB0, 0)
+        MPL_X3(cur[1], b0h, NB0, 0)
+        MPL_X3(cur[0], b0m, NB0, 0)
+        MPL_X3(cur[0], b0h, NB0, 0)
+        if (DBG) s1 = now();
+        // own pieces of stage t+1 landed: with a full ring, NST-2 later stages (>= MIN_PIECES pieces each) may stay
+        // in flight; near the end (and for NST = 2) simply drain.  Batch-1 reads have returned.
+        if (NST > 2 && t + NST - 1 < T) wait_vm((NST - 2) * MIN_PIECES);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (DBG) s2 = now();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (DBG) s3 = now();
+        if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res)
+            load_residual_w<NTW>(rv, a.R, a.ldr, M, N, row0, n0 + tile0 * 16, li);
+        float x[8], gg[8], ee[8];
+        read_a(slot_n, x, gg, ee);
+        if (!LN) read_b0(slot_n);
+        // Hand-interleaved: the 6 * NB1 MFMAs of batch 1 alternate with the split of the next A fragment, one MFMA
+        // (16 cycles of matrix pipe) per ~4 VALU ops; sched_barrier(0) pins the order hipcc would otherwise undo
+        // (it groups all VALU first and lets the wave sit on the ds_read latency with the matrix pipe idle).
+        unsigned wh[4], wm[4], wl[4];            // packed bf16 pairs of the next fragment
+        float r0[4], r1[4];
+        constexpr int NM = 6 * NB1;              // MFMAs to place
+        int mi = 0;
+        auto mfma_next = [&]() {                 // the mi-th MFMA of batch 1 in the canonical product order
+            if (mi < NM) {
+                const int prod = mi / NB1, n = mi % NB1;
+                const bf16x8& ap = cur[prod == 0 ? 2 : (prod == 2 || prod == 3) ? 1 : 0];
+                const bf16x8& bp = (prod == 0 || prod == 3 || prod == 5) ? b1h[n] : (prod == 1) ? b1l[n] : b1m[n];
+                accp[NB0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, bp, accp[NB0 + n], 0, 0, 0);
+                ++mi;
+            }
+        };
+        auto pack = [](float lo_, float hi_) -> unsigned {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 v = {(__bf16)lo_, (__bf16)hi_};
+            return __builtin_bit_cast(unsigned, v);
+        };
+        auto lo_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w << 16); };
+        auto hi_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w & 0xffff0000u); };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_next();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_next();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {            // hi part + first residual of pair j
+            float x0 = x[2 * j], x1 = x[2 * j + 1];
+            if (LN) {
+                x0 = (x0 - mu) * rs * gg[2 * j] + ee[2 * j];
+                x1 = (x1 - mu) * rs * gg[2 * j + 1] + ee[2 * j + 1];
+            }
+            wh[j] = pack(x0, x1);
+            r0[j] = x0 - lo_f(wh[j]);
+            r1[j] = x1 - hi_f(wh[j]);
+            mfma_next();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {            // mid part + second residual
+            wm[j] = pack(r0[j], r1[j]);
+            r0[j] -= lo_f(wm[j]);
+            r1[j] -= hi_f(wm[j]);
+            mfma_next();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {         // lo part
+            wl[j] = pack(r0[j], r1[j]);
+            wl[j + 1] = pack(r0[j + 1], r1[j + 1]);
+            mfma_next();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NM; ++k) mfma_next();   // whatever is left (mi is a compile-time value here)
+        __builtin_amdgcn_sched_barrier(0);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        nxt[0] = __builtin_bit_cast(bf16x8, (u32x4){wh[0], wh[1], wh[2], wh[3]});
+        nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
+        nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
+        // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
+        if (LN) read_b0(slot_n);
+        slot_c = slot_n;
+        if (DBG) {
+            const unsigned long long s4 = now();
+            dbg[0] += s1 - s0; dbg[1] += s2 - s1; dbg[2] += s3 - s2; dbg[3] += s4 - s3; dbg[4] += 1;
+        }
+    };
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        for (int kt = 0; kt < KT; ++kt) {
-            const int t = pass * KT + kt;
-            int ahead = T - 1 - t;
-            ahead = ahead < NST - 2 ? ahead : NST - 2;
-            int allow = ahead * per_st;
-            if (EPI == MPL_EPI_BIAS_RESIDUAL && t > t_res) allow += RES;   // younger than every DMA piece
-            wait_vm(allow);
-            __builtin_amdgcn_s_barrier();       // everyone's pieces of stage t landed; everyone is done with t-1
-            asm volatile("" ::: "memory");
-            if (t + NST - 1 < T) issue_stage(t + NST - 1);
-            if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res)
-                load_residual_w<NTW>(rv, a.R, a.ldr, M, N, row0, n0 + tile0 * 16, li);
-
-            const char* st = smem + (t % NST) * X3_STAGE;
-            // A fragment of 16x16x32: lane (i, kq) holds A[i][8 kq .. 8 kq + 7] = logical 16-B columns 2kq, 2kq+1
-            const float* as = reinterpret_cast<const float*>(st) + (rg * 16 + li) * BK;
-            const float4 a0 = ld4(as + (((2 * kq) ^ key) << 2)), a1 = ld4(as + (((2 * kq + 1) ^ key) << 2));
-            float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            if (LN) {
-                const float* gb = reinterpret_cast<const float*>(st + X3_GB);
-                const float4 g0 = ld4(gb + 8 * kq), g1 = ld4(gb + 8 * kq + 4), e0 = ld4(gb + 32 + 8 * kq), e1 = ld4(gb + 36 + 8 * kq);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const int tb = pass * KT;
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(tb + kt, acc[pass], A0, A1);
+            stage(tb + kt + 1, acc[pass], A1, A0);
+        }
+        if (kt < KT) {
+            stage(tb + kt, acc[pass], A0, A1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = (x[i] - mu) * rs * gg[i] + ee[i];
-            }
-            bf16x8 ah, am, al;
-            split3(x, ah, am, al);
-            const bf16x8* bs = reinterpret_cast<const bf16x8*>(st + SUB_A) + tile0 * 3 * 64 + lane;
-            // B fragments in two batches (3 tiles, then the rest): 36 instead of 60 live registers, so that the
-            // residual variants also fit the 128-register budget of two workgroups per CU
-#define MPL_X3(AP, BP, N0, N1)                       \
-    _Pragma("unroll") for (int n = N0; n < N1; ++n) \
-        acc[pass][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AP, BP[n - N0], acc[pass][n], 0, 0, 0);
-#define MPL_X3_BATCH(N0, N1)                                  \
-    {                                                         \
-        bf16x8 bh[3], bm[3], bl[3];                           \
-        _Pragma("unroll") for (int n = N0; n < N1; ++n) {     \
-            bh[n - N0] = bs[(n * 3 + 0) * 64];                \
-            bm[n - N0] = bs[(n * 3 + 1) * 64];                \
-            bl[n - N0] = bs[(n * 3 + 2) * 64];                \
-        }                                                     \
-        MPL_X3(al, bh, N0, N1)                                \
-        MPL_X3(ah, bl, N0, N1)                                \
-        MPL_X3(am, bm, N0, N1)                                \
-        MPL_X3(am, bh, N0, N1)                                \
-        MPL_X3(ah, bm, N0, N1)                                \
-        MPL_X3(ah, bh, N0, N1)                                \
-    }
-            MPL_X3_BATCH(0, 3)
-            MPL_X3_BATCH(3, NTW)
-#undef MPL_X3_BATCH
-#undef MPL_X3
+            for (int i = 0; i < 3; ++i) A0[i] = A1[i];
         }
     }
+#undef MPL_X3
 
+    const unsigned long long t_epi = DBG ? now() : 0;
     if (NPASS == 3) {
         // ---- fused attention epilogue.  T[64][412]: q | k | v (+bias) of this workgroup's 136 channels.
         float* Tt = reinterpret_cast<float*>(smem);
@@ -280,6 +429,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
 
     float v[NTW][4];
     tile_values_store<EPI, NTW>(acc[0], a.bias, rv, a.C, a.ldc, M, N, row0, n0, n0 + tile0 * 16, li, v);
+    const unsigned long long t_st = DBG ? now() : 0;
     if (EPI == MPL_EPI_BIAS_RESIDUAL && a.stats_out) {
         // LayerNorm partials of the 136-column slice: the second half hands its final values to the first through
         // the stage slot nobody reads any more (stage T-2: every wave passed barrier T-1), and the first half
@@ -305,15 +455,32 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             slice_stats_store(vv, a.stats_out, N / BN, M, row0, n0, li);
         }
     }
+    if (DBG) {   // bench-only: per-wave phase cycles into the (otherwise unused) att_out pointer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = now();
+        if (lane == 0) {
+            float* o = a.att_out + (size_t)(blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 5; ++i) o[i] = (float)dbg[i];
+            o[5] = (float)(t_loop - t_entry);
+            o[6] = (float)(t_epi - t_loop);
+            o[7] = (float)(t_st - t_epi);
+            o[8] = (float)(t_end - t_st);
+        }
+    }
 }
 
-template <int EPI, bool LN, int NPASS, int NST>
+template <int EPI, bool LN, int NPASS, int NST, bool DBG = false>
 __global__ __launch_bounds__(512, (NPASS == 1 && EPI != MPL_EPI_BIAS_RESIDUAL) ? 4 : 2) void x3_gemm_kernel(const X3Args a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave < 4) x3_body<EPI, LN, NPASS, NST, X3_T0>(a, smem, tid, wave, 0);
-    else x3_body<EPI, LN, NPASS, NST, NT - X3_T0>(a, smem, tid, wave, X3_T0);
+    if (wave < 4) x3_body<EPI, LN, NPASS, NST, X3_T0, DBG>(a, smem, tid, wave, 0);
+    else x3_body<EPI, LN, NPASS, NST, NT - X3_T0, DBG>(a, smem, tid, wave, X3_T0);
+}
+
+static int x3_abl() {
+    static const int v = getenv("MPL_X3_ABL") ? atoi(getenv("MPL_X3_ABL")) : 0;
+    return v;
 }
 
 template <int EPI, bool LN, int NPASS, int NST>
@@ -342,6 +509,18 @@ static int launch_x3_auto(const X3Args& a, hipStream_t s) {
     const int wgs = a.grid_m * a.grid_n;
     int nst = wgs > 256 ? 2 : 3;
     if (force) nst = force;
+    static const bool dbg = getenv("MPL_X3_DBG") != nullptr;   // bench-only phase timing into stats_out
+    if (dbg && EPI == MPL_EPI_BIAS_RESIDUAL && !LN && a.stats_out) {
+        X3Args b = a;
+        b.att_out = a.stats_out;      // timing dump
+        b.stats_out = nullptr;
+        ProfScope prof(MPL_K_GEMM, s);
+        hipFuncSetAttribute((const void*)x3_gemm_kernel<MPL_EPI_BIAS_RESIDUAL, false, 1, 3, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE);
+        hipLaunchKernelGGL((x3_gemm_kernel<MPL_EPI_BIAS_RESIDUAL, false, 1, 3, true>), dim3(a.grid_m * a.grid_n), dim3(512),
+                           3 * X3_STAGE, s, b);
+        return hip_check_launch();
+    }
     switch (nst) {
         case 2: return launch_x3<EPI, LN, 1, 2>(a, s);
         case 4: return launch_x3<EPI, LN, 1, 4>(a, s);
@@ -358,7 +537,7 @@ int launch_x3_gemm(const float* A, int lda, const float* stats, const float* ln_
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
     if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
     X3Args a{A, lda, stats, ln_w, ln_b, reinterpret_cast<const char*>(W3), bias, R, ldr, C, ldc, M, N, K,
-             (M + BM - 1) / BM, N / BN, eps, stats_out, 0, 0, nullptr};
+             (M + BM - 1) / BM, N / BN, eps, stats_out, 0, 0, nullptr, x3_abl()};
 #define MPL_X3_CASE(E) \
     case E:            \
         return ln ? launch_x3_auto<E, true>(a, s) : launch_x3_auto<E, false>(a, s);
@@ -380,7 +559,7 @@ int launch_x3_qkv_attention(const float* x, int M, int D, const float* stats, co
         x3_operand_bytes(3 * D, D) == 0)
         return MPL_E_INVALID;
     X3Args a{x, D, stats, ln_w, ln_b, reinterpret_cast<const char*>(W3), bias, nullptr, 0, nullptr, 0, M, 3 * D, D,
-             (M + BM - 1) / BM, D / BN, eps, nullptr, n_tok, D / heads, att};
+             (M + BM - 1) / BM, D / BN, eps, nullptr, n_tok, D / heads, att, x3_abl()};
     return launch_x3<MPL_EPI_BIAS, true, 3, 4>(a, s);
 }
 
