@@ -12,9 +12,12 @@ poses that are already resident in HBM when the timed region starts; with N rank
 step, the MI355X equivalent of the reference's DataParallel gather (valid_mpl.py:178).
 
 Rank 0 prints ONE JSON line: value = whole-job poses/s, plus
-  roofline     -- dominant kernel (ln_gemm_kernel, the fp32-MFMA GEMMs of the FPT blocks): algorithmic
-                  FLOPs per launch / mean launch duration measured live with HIP events on the launch stream
-                  (mpl_profile_start/stop) against the 157.3 TFLOP/s fp32 matrix peak
+  roofline     -- dominant kernel (the GEMMs of the FPT blocks): algorithmic fp32 FLOPs per launch / mean launch
+                  duration measured live with HIP events on the launch stream (mpl_profile_start/stop) against the
+                  157.3 TFLOP/s fp32 matrix peak.  The default fp32 path computes those GEMMs on the bf16 matrix
+                  cores from exactly split operands (csrc/x3_gemm.hip: fp32 in, fp32 out, at least fp32-accurate
+                  products, fp32 accumulation), so `matrix_pipe` also prices the executed bf16 MFMA work against
+                  the 2.5 PFLOP/s bf16 peak; --precision fp32_mfma runs the native fp32 MFMA kernels instead.
   cpu_baseline -- the oracle (a port of the reference's CPU PyTorch path) timed on this box's host cores.
 """
 from __future__ import annotations
@@ -30,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
 CHOSEN = dict(pose_3d_emb_learnable=True)
@@ -48,6 +52,8 @@ def parse():
     ap.add_argument("--flagset", choices=("chosen", "full"), default="chosen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FULL-flag-set measurement")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_mfma"],
+                    help="fp32: split-operand GEMMs on the bf16 matrix cores (default); fp32_mfma: native fp32 MFMA")
     return ap.parse_args()
 
 
@@ -142,6 +148,8 @@ def main():
         dist = dist_mod
 
     model, flags = build_model(a.flagset, a.views, a.depth, dev)
+    model.set_matmul_precision(a.precision)
+    split = a.precision == "fp32" and model._x3_supported()
     # a few distinct resident batches so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
     gather_buf = world * a.batch if dist is not None else None   # global batch size of the gathered result
@@ -182,10 +190,24 @@ def main():
         try:
             if a.flagset == "chosen" and a.batch == 1024 and a.views == 4:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))
+                if tj.get("kernel") != ("x3_gemm_kernel" if split else "ln_gemm_ng_kernel"):
+                    raise KeyError("profile is for the other GEMM kernel")
                 traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), tj["source"]
         except Exception:
             pass
-        roof = dict(bound="mfma", kernel="ln_gemm_ng_kernel", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+        # executed matrix-pipe work of the split path: 6 bf16 products per fp32 product on 144-column (9 x 16) tiles
+        pipe = None
+        if split:
+            ex = achieved * 6.0 * 144.0 / 136.0
+            pipe = dict(instruction="v_mfma_f32_16x16x32_bf16", executed=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                        note="6 bf16 partial products per fp32 product (3-way exact operand split), 9 MFMA column "
+                             "tiles per 136 output columns")
+        roof = dict(bound="mfma", kernel="x3_gemm_kernel" if split else "ln_gemm_ng_kernel",
+                    arithmetic=("fp32 operands split exactly into 3 bf16 terms, 6 significant partial products per "
+                                "product on the bf16 matrix cores, fp32 accumulation (error vs fp64 <= native fp32)")
+                    if split else "native fp32 MFMA (v_mfma_f32_16x16x4_f32)",
+                    achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, matrix_pipe=pipe,
                     unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                     traffic_source=traffic_src,
                     avg_launch_us=round(avg_launch_ms * 1e3, 2), launches_per_step=launches,
@@ -226,6 +248,22 @@ def main():
 
         extra = {}
         if not a.no_extra and world == 1 and a.flagset == "chosen":
+            # the other fp32 engine on the same workload, and all of them against an fp64 evaluation of the reference
+            # semantics: the split-operand path must not be less accurate than fp32 arithmetic
+            other = "fp32_mfma" if a.precision == "fp32" else "fp32"
+            model.set_matmul_precision(other)
+            n_o = max(10, a.steps // 2)
+            v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3, None, None)
+            with torch.no_grad():
+                got_o = model([x[:nb].contiguous() for x in P], rays=[x[:nb].contiguous() for x in R],
+                              centers=[x[:nb].contiguous() for x in C]).cpu()
+            model.set_matmul_precision(a.precision)
+            ref64 = mpl_oracle.forward(sd, flags, [x[:nb].cpu() for x in P], [x[:nb].cpu() for x in R],
+                                       [x[:nb].cpu() for x in C], dtype=torch.float64)
+            e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
+            extra[other + "_poses_per_s"] = round(v_o, 1)
+            extra["max_scaled_err_vs_fp64"] = {"hip_" + a.precision: e(got), "hip_" + other: e(got_o),
+                                               "reference_fp32_cpu": e(ref)}
             # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
             m2, f2 = build_model("full", a.views, a.depth, dev)
             dt2 = timed_steps(m2, batches, max(5, a.steps // 4), 3, None, None)

@@ -239,9 +239,14 @@ class MultiView_MPL(nn.Module):
         return None
 
     def set_matmul_precision(self, precision: str):
-        """"fp32" (default, 1e-6 from the reference) or "bf16": the FPT block GEMMs run on the bf16 matrix cores
-        (bf16 operands, fp32 accumulate; everything else stays fp32) -- BASELINE.json configs[2].  The bf16 weight
-        copies are derived data, rebuilt whenever a parameter's storage or version changes."""
+        """Arithmetic of the FPT block GEMMs (everything else is fp32 always):
+        "fp32" (default) -- fp32 in, fp32 out, fp32 accumulation; where the FPT width is a multiple of 136 (every
+            view-token model) the products are formed on the bf16 matrix cores from operands split exactly into three
+            bf16 terms (csrc/x3_gemm.hip: at least as accurate as an fp32 multiply, 2.7x less matrix-pipe time on
+            gfx950); other widths (KPTOK, D = 32) use the native fp32 MFMA kernels;
+        "fp32_mfma" -- native fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere;
+        "bf16" -- bf16 operands (one rounding to bf16), fp32 accumulate: BASELINE.json configs[2].
+        The split / bf16 weight copies are derived data, rebuilt whenever a parameter's storage or version changes."""
         if precision not in ("fp32", "fp32_mfma", "bf16"):
             raise ValueError("matmul precision must be 'fp32', 'fp32_mfma' or 'bf16'")
         if precision == "bf16" and self.FPT_blocks_view_keypoint_tokens:

@@ -128,6 +128,10 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
     assert ctypes.sizeof(cabi.BlockWeights) == 160 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
+    # split operands of the fp32-on-bf16-cores GEMMs: 27 KiB per (136-column group, 32-deep k-tile); 0 = unsupported
+    assert lib.mpl_split_bf16x3_bytes(1632, 544) == 12 * 17 * 27 * 1024
+    assert lib.mpl_split_bf16x3_bytes(544, 1088) == 4 * 34 * 27 * 1024
+    assert lib.mpl_split_bf16x3_bytes(96, 32) == 0 and lib.mpl_split_bf16x3_bytes(544, 48) == 0
 
 
 def test_detrng_is_stable():

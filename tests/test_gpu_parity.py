@@ -302,3 +302,106 @@ def test_bf16_matmul_path(name, B):
     with torch.no_grad():
         out32 = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn]).cpu()
     _assert_close(out32, ref, name + " back to fp32")
+
+
+# ----------------------------------------------------------------------------- fp32 on the bf16 matrix cores (split operands)
+def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
+    a = A.double()
+    if ln:
+        a = F.layer_norm(a, (A.shape[1],), gam.double(), bet.double(), 1e-6)
+    y = a @ W.double().T + b.double()
+    if epi == cabi.EPI_BIAS_GELU:
+        y = 0.5 * y * (1.0 + torch.erf(y * 2 ** -0.5))
+    if epi == cabi.EPI_BIAS_RESIDUAL:
+        y = y + R.double()
+    return y
+
+
+@pytest.mark.parametrize("M,K,N,epi,ln", [
+    (4096, 544, 1632, cabi.EPI_BIAS, True),
+    (4096, 544, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (1000, 544, 1088, cabi.EPI_BIAS_GELU, True),
+    (77, 1088, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (3, 544, 544, cabi.EPI_BIAS, False),
+    (130, 1088, 3264, cabi.EPI_BIAS, True),
+    (640, 64, 136, cabi.EPI_BIAS_GELU, False),
+])
+def test_split_operand_linear_is_fp32_accurate(M, K, N, epi, ln):
+    """mpl_split_bf16x3 + mpl_ln_linear_x3 against an fp64 evaluation: the split-operand GEMM must be as accurate as
+    fp32 arithmetic -- its error may not exceed the native fp32 MFMA kernel's by more than rounding noise."""
+    lib = cabi.load()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    ref = _fp64_linear(A, W, b, R, gam, bet, epi, ln)
+    Ad, Wd, bd, Rd, gd, bed = (t.to(DEV) for t in (A, W, b, R, gam, bet))
+    nbytes = lib.mpl_split_bf16x3_bytes(N, K)
+    assert nbytes == (N // 136) * (K // 32) * 27 * 1024
+    W3 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), N, K, W3.data_ptr(), _stream()), "mpl_split_bf16x3")
+    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
+    errs = {}
+    for tag in ("x3", "mfma"):
+        Y = torch.full((M, N), float("nan"), device=DEV)
+        args = (Ad.data_ptr(), M, K, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-6)
+        tail = (bd.data_ptr(), N, epi, Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None, Y.data_ptr(),
+                so.data_ptr() if ln else None, _stream())
+        rc = lib.mpl_ln_linear_x3(*args, W3.data_ptr(), *tail) if tag == "x3" else lib.mpl_ln_linear(*args, Wd.data_ptr(), *tail)
+        cabi.check(rc, tag)
+        torch.cuda.synchronize()
+        errs[tag] = mpl_oracle.rel_errors(Y.cpu(), ref)
+    print("M=%d K=%d N=%d: split %.2e/%.2e  fp32 MFMA %.2e/%.2e" % ((M, K, N) + errs["x3"] + errs["mfma"]))
+    assert errs["x3"][0] <= 3e-6 and errs["x3"][1] <= 1e-6
+    assert errs["x3"][1] <= 1.5 * errs["mfma"][1] + 1e-8, "split-operand GEMM is less accurate than the fp32 MFMA GEMM"
+
+
+def test_split_operand_shapes_are_validated():
+    lib = cabi.load()
+    assert lib.mpl_split_bf16x3_bytes(544, 544) == 4 * 17 * 27 * 1024
+    for n, k in ((100, 544), (544, 40), (136, 32), (0, 64), (544, -32)):
+        assert lib.mpl_split_bf16x3_bytes(n, k) == 0
+    x = torch.zeros(64, 544, device=DEV)
+    cabi_rc = lib.mpl_split_bf16x3(x.data_ptr(), 100, 544, x.data_ptr(), _stream())
+    assert cabi_rc != 0
+
+
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2", "chosen_v8_b4_l2", "chosen_v5_b19_l2", "kptok_v3_b3_l2", "no_fpt_v3_b3_l2"])
+def test_native_fp32_mfma_path_matches_golden(name):
+    """set_matmul_precision("fp32_mfma"): the native fp32 matrix-instruction kernels stay covered now that "fp32"
+    routes the FPT GEMMs through the split-operand kernels where the width allows."""
+    if name not in SUPPORTED:
+        pytest.skip("case not in the golden set")
+    m, g = _model(name)
+    m.set_matmul_precision("fp32_mfma")
+    P, R, Cn = golden_inputs(g, DEV)
+    with torch.no_grad():
+        out = m(P, rays=R, centers=Cn)
+    _assert_close(out, torch.from_numpy(g["out"]), name + " fp32_mfma")
+    assert not m._hip_cache[0]["keep"][4], "native path must not build split operands"
+    m.set_matmul_precision("fp32")
+    with torch.no_grad():
+        out3 = m(P, rays=R, centers=Cn)
+    _assert_close(out3, torch.from_numpy(g["out"]), name + " fp32 (split operands where supported)")
+    assert bool(m._hip_cache[0]["keep"][4]) == m._x3_supported()
+
+
+def test_fp32_paths_agree_and_are_both_batch_invariant():
+    """The two fp32 engines differ only by rounding noise, and each is bitwise independent of the batch size."""
+    m, g = _model("chosen_v4_b8_l12")
+    P, R, Cn = _big_inputs(1024, 4, 5)
+    ref = None
+    outs = {}
+    for prec in ("fp32", "fp32_mfma"):
+        m.set_matmul_precision(prec)
+        with torch.no_grad():
+            full = m(P, rays=R, centers=Cn)
+            part = m([x[100:400].contiguous() for x in P], rays=[x[100:400].contiguous() for x in R],
+                     centers=[x[100:400].contiguous() for x in Cn])
+        assert torch.equal(full[100:400], part), prec + ": batch slice changed results"
+        outs[prec] = full
+    mx, nw = mpl_oracle.rel_errors(outs["fp32"].cpu(), outs["fp32_mfma"].cpu())
+    assert mx < 5e-6 and nw < 5e-6, (mx, nw)
+    with pytest.raises(ValueError):
+        m.set_matmul_precision("tf32")

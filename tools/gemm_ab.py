@@ -1,5 +1,6 @@
 """Time the FPT GEMM shapes alone (no LN prologue kernel), for A/B runs of kernel variants:
     MPL_GEMM_VAR=v MPL_GEMM_ABL=a python tools/gemm_ab.py [D] [M]
+MPL_GEMM_X3=1 selects the split-operand kernels (x3_gemm.hip) instead of the fp32 MFMA ones.
 """
 import os
 import sys
@@ -27,8 +28,14 @@ for name, K, N, epi in SHAPES:
     b = torch.randn(N, generator=g).to(dev)
     R = torch.randn(M, N, generator=g).to(dev)
     Y = torch.empty(M, N, device=dev)
-    fn = lambda: lib.mpl_ln_linear(A.data_ptr(), M, K, None, None, 0.0, W.data_ptr(), b.data_ptr(), N, epi,
-                                   R.data_ptr() if epi == 2 else None, Y.data_ptr(), None, st())
+    if os.environ.get("MPL_GEMM_X3"):      # split-operand GEMM (fp32 on the bf16 matrix cores)
+        W3 = torch.empty(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=dev)
+        cabi.check(lib.mpl_split_bf16x3(W.data_ptr(), N, K, W3.data_ptr(), st()), "split")
+        fn = lambda: lib.mpl_ln_linear_x3(A.data_ptr(), M, K, None, None, 0.0, W3.data_ptr(), b.data_ptr(), N, epi,
+                                          R.data_ptr() if epi == 2 else None, Y.data_ptr(), None, st())
+    else:
+        fn = lambda: lib.mpl_ln_linear(A.data_ptr(), M, K, None, None, 0.0, W.data_ptr(), b.data_ptr(), N, epi,
+                                       R.data_ptr() if epi == 2 else None, Y.data_ptr(), None, st())
     for _ in range(5):
         fn()
     torch.cuda.synchronize()

@@ -9,11 +9,12 @@ out = open("profiles/%s_gemm_pmc_summary.txt" % tag, "w")
 def P(*a): print(*a, file=out)
 P("rocprofv3 PMC passes (each its own run, --kernel-trace only) over `python tools/gemm_ab.py 544` = the four FPT GEMM shapes")
 P("at M=4096, D=544 (65 launches each), and over `python tools/spt_ab.py` for the fused SPT kernel.")
-P("kernel = mpl::ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT>; values are per-launch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs.")
+P("kernel = mpl::x3_gemm_kernel<EPI, LN, NPASS, NST, DBG> (MPL_GEMM_X3=1: the split-operand GEMMs of the default fp32 path);")
+P("values are per-launch averages; GRBM_GUI_ACTIVE is summed over the 8 XCDs.")
 fetch, write = {}, {}
-for p, desc, filt in [("a", "SQ pass", "ln_gemm"), ("b", "LDS / L2 pass", "ln_gemm"),
-                      ("c", "FETCH_SIZE pass (kB; doubled below for the traffic figure, MI355X_MICROARCH.md HBM section)", "ln_gemm"),
-                      ("d", "WRITE_SIZE pass (kB)", "ln_gemm"), ("e", "fused SPT kernel", "spt_kernel")]:
+for p, desc, filt in [("a", "SQ pass", "x3_gemm"), ("b", "LDS / L2 pass", "x3_gemm"),
+                      ("c", "FETCH_SIZE pass (kB; doubled below for the traffic figure, MI355X_MICROARCH.md HBM section)", "x3_gemm"),
+                      ("d", "WRITE_SIZE pass (kB)", "x3_gemm"), ("e", "fused SPT kernel", "spt_kernel")]:
     path = "%s/pmc%s%s/p_counter_collection.csv" % (G, sid, p)
     if not os.path.exists(path):
         continue
@@ -36,8 +37,13 @@ out.close()
 if fetch and write:
     fb = sum(v * n for v, n in fetch.values()) / sum(n for _, n in fetch.values()) * 2 * 1024
     wb = sum(v * n for v, n in write.values()) / sum(n for _, n in write.values()) * 1024
-    json.dump({"kernel": "ln_gemm_ng_kernel", "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
-               "traffic_bytes_per_launch": fb + wb, "algorithmic_bytes_per_launch": 33.5e6,
+    # algorithmic bytes of the four launches of a block at M=4096, D=544: A (fp32) + split W (3 bf16 parts on 144 of
+    # 136 columns) + C (+ residual read for proj / fc2)
+    M_, D_ = 4096, 544
+    alg = [M_ * k * 4 + n * k * 6 * 144 / 136 + M_ * n * 4 * (2 if res else 1)
+           for k, n, res in ((D_, 3 * D_, 0), (D_, D_, 1), (D_, 2 * D_, 0), (2 * D_, D_, 1))]
+    json.dump({"kernel": "x3_gemm_kernel", "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+               "traffic_bytes_per_launch": fb + wb, "algorithmic_bytes_per_launch": sum(alg) / 4,
                "source": "profiles/%s_gemm_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_ab.py, FETCH_SIZE x2 gfx950 correction; stand-alone GEMMs, i.e. the QKV launch still writes its packed output here)" % tag},
               open("profiles/%s_gemm_traffic.json" % tag, "w"), indent=1)
     print("traffic MB", fb / 1e6, wb / 1e6)
