@@ -41,6 +41,10 @@ constexpr int X3_W = 27 * 1024;             // W bytes per k-tile of a 136-colum
 constexpr int X3_GB = SUB_A + X3_W;         // gamma/beta piece
 constexpr int X3_STAGE = X3_GB + 1024;      // 36864
 constexpr int X3_T0 = 5;                    // column tiles of waves 0..3; waves 4..7 take the other NT - 5
+// Run the second wave of every SIMD half a stage out of phase (see `stage` in x3_body).  Measured on MI355X at
+// M = 4096, D = 544: 444-446 k poses/s with, 450-455 k without -- the phases do not overlap better, the lagging wave
+// just holds more registers across the barrier.  Kept for experiments, off in the product build.
+constexpr bool X3_DEPHASE = false;
 
 // 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32).  Written
 // stage by stage over the 8 elements so that the four packed chains interleave instead of stalling on each other.
@@ -120,7 +124,7 @@ struct X3Args {
 };
 
 // Everything a compute wave does, for its NTW column tiles starting at tile `tile0`.
-template <int EPI, bool LN, int NPASS, int NST, int NTW, bool DBG = false>
+template <int EPI, bool LN, int NPASS, int NST, int NTW, bool LAG, bool DBG = false>
 __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, int wave, int tile0) {
     const unsigned long long t_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
     const int lane = tid & 63;
@@ -231,6 +235,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     // iteration prepares a stage that does not exist (stale LDS, results unused): no special cases in the body.
     bf16x8 A0[3], A1[3];                         // split A fragment (hi, mid, lo): current / next, ping-pong
     bf16x8 b0h[NB0], b0m[NB0], b0l[NB0];         // B batch 0 of the current stage
+    bf16x8 b1h[NB1], b1m[NB1], b1l[NB1];         // B batch 1 (LAG waves keep it across the barrier)
     auto read_a = [&](unsigned slot, float (&x)[8], float (&gg)[8], float (&ee)[8]) {
         const char* st = smem + slot;
         // A fragment of 16x16x32: lane (i, kq) holds A[i][8 kq .. 8 kq + 7] = logical 16-B columns 2kq, 2kq+1
@@ -259,6 +264,11 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
 #pragma unroll
         for (int n = 0; n < NB0; ++n) { b0h[n] = bs[(n * 3 + 0) * 64]; b0m[n] = bs[(n * 3 + 1) * 64]; b0l[n] = bs[(n * 3 + 2) * 64]; }
     };
+    auto read_b1 = [&](unsigned slot) {
+        const bf16x8* bs = b_base(slot) + NB0 * 3 * 64;
+#pragma unroll
+        for (int n = 0; n < NB1; ++n) { b1h[n] = bs[(n * 3 + 0) * 64]; b1m[n] = bs[(n * 3 + 1) * 64]; b1l[n] = bs[(n * 3 + 2) * 64]; }
+    };
     {   // prologue: stage 0 landed for everyone
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -266,6 +276,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         float x[8], gg[8], ee[8];
         read_a(0, x, gg, ee);
         read_b0(0);
+        if (LAG) read_b1(0);
         norm_split(x, gg, ee, A0);
     }
     unsigned slot_c = 0;                         // ring slot (byte offset) of the current stage
@@ -281,42 +292,54 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         return v;
     };
+    // With X3_DEPHASE the two waves of a SIMD run the stage in different orders so that one is in its MFMA-only
+    // batch while the other interleaves MFMAs with the VALU-heavy split:
+    //   waves 0..3 (LAG = false):  batch 0 of stage t | barrier t | split(t+1) x batch 1 of stage t
+    //   waves 4..7 (LAG = true):   barrier t | batch 0 of stage t | split(t+1) x batch 1 of stage t | B reads of t+1
+    // (a LAG wave holds both B batches of a stage in registers across the barrier that frees the stage's slot).
     auto stage = [&](int t, f32x4 (&accp)[NTW], const bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
         unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         if (DBG) s0 = now();
         const unsigned slot_n = slot_after(slot_c);
-        bf16x8 b1h[NB1], b1m[NB1], b1l[NB1];
-        {
-            const bf16x8* bs = b_base(slot_c) + NB0 * 3 * 64;
-#pragma unroll
-            for (int n = 0; n < NB1; ++n) { b1h[n] = bs[(n * 3 + 0) * 64]; b1m[n] = bs[(n * 3 + 1) * 64]; b1l[n] = bs[(n * 3 + 2) * 64]; }
+        auto batch0 = [&]() {
+            MPL_X3(cur[2], b0h, NB0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot the last barrier freed under the matrix pipe's shadow: the batch-0 MFMAs have no
+            // VALU work to pair with, the DMA issue is scalar + 4..6 VMEM instructions
+            if ((LAG || t >= 1) && is_t < T && !(a.abl & 1)) issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+            MPL_X3(cur[0], b0l, NB0, 0)
+            MPL_X3(cur[1], b0m, NB0, 0)
+            MPL_X3(cur[1], b0h, NB0, 0)
+            MPL_X3(cur[0], b0m, NB0, 0)
+            MPL_X3(cur[0], b0h, NB0, 0)
+        };
+        auto sync = [&]() {
+            // own pieces of stage t+1 landed: with a full ring, NST-2 later stages (>= MIN_PIECES pieces each) may
+            // stay in flight; near the end (and for NST = 2) simply drain.  Every read of stage t has returned.
+            if (NST > 2 && t + NST - 1 < T) wait_vm((NST - 2) * MIN_PIECES);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (DBG) s2 = now();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (DBG) s3 = now();
+        };
+        if (!LAG) {
+            read_b1(slot_c);
+            batch0();
+            if (DBG) s1 = now();
+            sync();
+        } else {
+            sync();
+            batch0();
+            if (DBG) s1 = now();
         }
-        MPL_X3(cur[2], b0h, NB0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        // refill the slot the previous barrier freed (stage t-1+NST) under the matrix pipe's shadow: the batch-0
-        // MFMAs have no VALU work to pair with, the DMA issue is scalar + 4..6 VMEM instructions
-        if (t >= 1 && is_t < T && !(a.abl & 1)) issue_next();
-        __builtin_amdgcn_sched_barrier(0);
-        MPL_X3(cur[0], b0l, NB0, 0)
-        MPL_X3(cur[1], b0m, NB0, 0)
-        MPL_X3(cur[1], b0h, NB0, 0)
-        MPL_X3(cur[0], b0m, NB0, 0)
-        MPL_X3(cur[0], b0h, NB0, 0)
-        if (DBG) s1 = now();
-        // own pieces of stage t+1 landed: with a full ring, NST-2 later stages (>= MIN_PIECES pieces each) may stay
-        // in flight; near the end (and for NST = 2) simply drain.  Batch-1 reads have returned.
-        if (NST > 2 && t + NST - 1 < T) wait_vm((NST - 2) * MIN_PIECES);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (DBG) s2 = now();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (DBG) s3 = now();
         if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res)
             load_residual_w<NTW>(rv, a.R, a.ldr, M, N, row0, n0 + tile0 * 16, li);
         float x[8], gg[8], ee[8];
         read_a(slot_n, x, gg, ee);
-        if (!LN) read_b0(slot_n);
+        if (!LN && !LAG) read_b0(slot_n);
         // Hand-interleaved: the 6 * NB1 MFMAs of batch 1 alternate with the split of the next A fragment, one MFMA
         // (16 cycles of matrix pipe) per ~4 VALU ops; sched_barrier(0) pins the order hipcc would otherwise undo
         // (it groups all VALU first and lets the wave sit on the ds_read latency with the matrix pipe idle).
@@ -381,11 +404,14 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
         nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
         // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
-        if (LN) read_b0(slot_n);
+        if (LN || LAG) read_b0(slot_n);
+        if (LAG) read_b1(slot_n);
         slot_c = slot_n;
         if (DBG) {
             const unsigned long long s4 = now();
-            dbg[0] += s1 - s0; dbg[1] += s2 - s1; dbg[2] += s3 - s2; dbg[3] += s4 - s3; dbg[4] += 1;
+            if (!LAG) { dbg[0] += s1 - s0; dbg[1] += s2 - s1; dbg[2] += s3 - s2; dbg[3] += s4 - s3; }
+            else { dbg[0] += s1 - s3; dbg[1] += s2 - s0; dbg[2] += s3 - s2; dbg[3] += s4 - s1; }
+            dbg[4] += 1;
         }
     };
 #pragma unroll
@@ -474,8 +500,8 @@ __global__ __launch_bounds__(512, (NPASS == 1 && EPI != MPL_EPI_BIAS_RESIDUAL) ?
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave < 4) x3_body<EPI, LN, NPASS, NST, X3_T0, DBG>(a, smem, tid, wave, 0);
-    else x3_body<EPI, LN, NPASS, NST, NT - X3_T0, DBG>(a, smem, tid, wave, X3_T0);
+    if (wave < 4) x3_body<EPI, LN, NPASS, NST, X3_T0, false, DBG>(a, smem, tid, wave, 0);
+    else x3_body<EPI, LN, NPASS, NST, NT - X3_T0, X3_DEPHASE, DBG>(a, smem, tid, wave, X3_T0);
 }
 
 static int x3_abl() {
