@@ -339,7 +339,10 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             load_residual_w<NTW>(rv, a.R, a.ldr, M, N, row0, n0 + tile0 * 16, li);
         float x[8], gg[8], ee[8];
         read_a(slot_n, x, gg, ee);
-        if (!LN && !LAG) read_b0(slot_n);
+        // LayerNorm variants fetch their next B batch only after the split (measured: fetching it up front costs 5 % on the
+        // fused attention instance even where registers are plentiful -- the A fragment then queues behind 9 more reads)
+        constexpr bool B0_EARLY = !LAG && !LN;
+        if (B0_EARLY) read_b0(slot_n);
         // Hand-interleaved: the 6 * NB1 MFMAs of batch 1 alternate with the split of the next A fragment, one MFMA
         // (16 cycles of matrix pipe) per ~4 VALU ops; sched_barrier(0) pins the order hipcc would otherwise undo
         // (it groups all VALU first and lets the wave sit on the ds_read latency with the matrix pipe idle).
@@ -404,7 +407,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
         nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
         // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
-        if (LN || LAG) read_b0(slot_n);
+        if (!B0_EARLY) read_b0(slot_n);
         if (LAG) read_b1(slot_n);
         slot_c = slot_n;
         if (DBG) {
