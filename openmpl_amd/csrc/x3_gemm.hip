@@ -31,6 +31,8 @@
 // not depend on the batch size or launch geometry.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_common.hpp"
 
 namespace mpl {
@@ -176,17 +178,19 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     asm volatile("" : "+v"(voW));
     const float* gb_src = ((lane & 8) ? a.ln_b : a.ln_w) + 4 * (lane & 7);
     const bool gb_on = LN && wave == 7;
-    constexpr int MIN_PIECES = 4;                // every wave issues at least A + 3 W pieces per stage
+    // every wave issues at least this many pieces per stage (A + 3 W; the q|k|v instance stages A only with q)
+    constexpr int MIN_PIECES = NPASS == 1 ? 4 : 3;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // running state of the NEXT stage to issue (stages are issued strictly in order)
-    int is_t = 0, is_kt = 0, is_pass = 0;
+    // Running state of the NEXT stage to issue (stages are issued strictly in order).  NPASS = 3 interleaves the
+    // three column groups k-tile by k-tile: stage t = 3 kt + g carries W of group g (q, k, v) for k-tile kt, and the
+    // A tile + gamma/beta of k-tile kt ride along with g = 0 only.
+    int is_t = 0, is_kt = 0, is_g = 0;
     unsigned is_slot = 0;                        // byte offset of its ring slot
-    const char* is_w = a.W3 + (size_t)(colbase(0) / BN) * KT * X3_W;
+    const char* is_w[NPASS];
+#pragma unroll
+    for (int g = 0; g < NPASS; ++g) is_w[g] = a.W3 + (size_t)(colbase(g) / BN) * KT * X3_W;
     const float* is_a = a.A;
-    auto issue_next = [&]() {
-        const unsigned st = lds0 + is_slot;
-        const unsigned keep = dma_m0_save();
-        dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
+    auto issue_w = [&](const char* wsrc, unsigned st) {
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
@@ -194,24 +198,35 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
             "global_load_lds_dwordx4 %0, %1 offset:2048"
             :
-            : "v"(voW), "s"(is_w), "s"(st + (unsigned)(SUB_A + w_first * 1024))
+            : "v"(voW), "s"(wsrc), "s"(st + (unsigned)(SUB_A + w_first * 1024))
             : "memory");
-        if (w_four) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(is_w) : "memory");
-        if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
+        if (w_four) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(wsrc) : "memory");
+    };
+    auto issue_next = [&]() {
+        const unsigned st = lds0 + is_slot;
+        const unsigned keep = dma_m0_save();
+        if (NPASS == 1) {
+            dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
+            issue_w(is_w[0], st);
+            if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
+            is_w[0] += X3_W;
+            is_a += BK;
+            ++is_kt;
+        } else {
+            if (is_g == 0) {
+                dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
+                if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
+                is_a += BK;
+            }
+#pragma unroll
+            for (int g = 0; g < NPASS; ++g)
+                if (g == is_g) { issue_w(is_w[g], st); is_w[g] += X3_W; }
+            if (++is_g == NPASS) { is_g = 0; ++is_kt; }
+        }
         dma_m0_restore(keep);
         ++is_t;
         is_slot += X3_STAGE;
         if (is_slot == NST * X3_STAGE) is_slot = 0;
-        is_a += BK;
-        is_w += X3_W;
-        if (NPASS > 1 && ++is_kt == KT) {        // next pass: k restarts, W moves to the next of q | k | v
-            is_kt = 0;
-            ++is_pass;
-            is_a = a.A;
-            is_w = a.W3 + (size_t)(colbase(is_pass) / BN) * KT * X3_W;
-        } else if (NPASS == 1) {
-            ++is_kt;
-        }
     };
 #pragma unroll
     for (int t = 0; t < NST; ++t)
@@ -297,7 +312,10 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     //   waves 0..3 (LAG = false):  batch 0 of stage t | barrier t | split(t+1) x batch 1 of stage t
     //   waves 4..7 (LAG = true):   barrier t | batch 0 of stage t | split(t+1) x batch 1 of stage t | B reads of t+1
     // (a LAG wave holds both B batches of a stage in registers across the barrier that frees the stage's slot).
-    auto stage = [&](int t, f32x4 (&accp)[NTW], const bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
+    // SPLIT (std::true_type / false_type): whether this stage prepares a new A fragment for the next one (always for
+    // NPASS = 1; only the last of the three q|k|v stages of a k-tile for NPASS = 3, which share one fragment)
+    auto stage = [&](auto split_c, int t, f32x4 (&accp)[NTW], const bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
+        constexpr bool do_split = decltype(split_c)::value;
         unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         if (DBG) s0 = now();
         const unsigned slot_n = slot_after(slot_c);
@@ -366,46 +384,51 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         };
         auto lo_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w << 16); };
         auto hi_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w & 0xffff0000u); };
+        if constexpr (do_split) {
         __builtin_amdgcn_sched_barrier(0);
-        mfma_next();
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_next();
-        __builtin_amdgcn_sched_barrier(0);
+            mfma_next();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_next();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {            // hi part + first residual of pair j
-            float x0 = x[2 * j], x1 = x[2 * j + 1];
-            if (LN) {
-                x0 = (x0 - mu) * rs * gg[2 * j] + ee[2 * j];
-                x1 = (x1 - mu) * rs * gg[2 * j + 1] + ee[2 * j + 1];
+            for (int j = 0; j < 4; ++j) {            // hi part + first residual of pair j
+                float x0 = x[2 * j], x1 = x[2 * j + 1];
+                if (LN) {
+                    x0 = (x0 - mu) * rs * gg[2 * j] + ee[2 * j];
+                    x1 = (x1 - mu) * rs * gg[2 * j + 1] + ee[2 * j + 1];
+                }
+                wh[j] = pack(x0, x1);
+                r0[j] = x0 - lo_f(wh[j]);
+                r1[j] = x1 - hi_f(wh[j]);
+                mfma_next();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            wh[j] = pack(x0, x1);
-            r0[j] = x0 - lo_f(wh[j]);
-            r1[j] = x1 - hi_f(wh[j]);
-            mfma_next();
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {            // mid part + second residual
-            wm[j] = pack(r0[j], r1[j]);
-            r0[j] -= lo_f(wm[j]);
-            r1[j] -= hi_f(wm[j]);
-            mfma_next();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int j = 0; j < 4; ++j) {            // mid part + second residual
+                wm[j] = pack(r0[j], r1[j]);
+                r0[j] -= lo_f(wm[j]);
+                r1[j] -= hi_f(wm[j]);
+                mfma_next();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {         // lo part
-            wl[j] = pack(r0[j], r1[j]);
-            wl[j + 1] = pack(r0[j + 1], r1[j + 1]);
-            mfma_next();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int j = 0; j < 4; j += 2) {         // lo part
+                wl[j] = pack(r0[j], r1[j]);
+                wl[j + 1] = pack(r0[j + 1], r1[j + 1]);
+                mfma_next();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-        for (int k = 0; k < NM; ++k) mfma_next();   // whatever is left (mi is a compile-time value here)
-        __builtin_amdgcn_sched_barrier(0);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        nxt[0] = __builtin_bit_cast(bf16x8, (u32x4){wh[0], wh[1], wh[2], wh[3]});
-        nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
-        nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
+            for (int k = 0; k < NM; ++k) mfma_next();   // whatever is left (mi is a compile-time value here)
+            __builtin_amdgcn_sched_barrier(0);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            nxt[0] = __builtin_bit_cast(bf16x8, (u32x4){wh[0], wh[1], wh[2], wh[3]});
+            nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
+            nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
+        } else {
+#pragma unroll
+            for (int k = 0; k < NM; ++k) mfma_next();
+        }
         // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
         if (!B0_EARLY) read_b0(slot_n);
         if (LAG) read_b1(slot_n);
@@ -417,18 +440,30 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             dbg[4] += 1;
         }
     };
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int tb = pass * KT;
+    constexpr std::true_type SPLIT{};
+    constexpr std::false_type KEEP{};
+    if constexpr (NPASS == 1) {
         int kt = 0;
         for (; kt + 1 < KT; kt += 2) {
-            stage(tb + kt, acc[pass], A0, A1);
-            stage(tb + kt + 1, acc[pass], A1, A0);
+            stage(SPLIT, kt, acc[0], A0, A1);
+            stage(SPLIT, kt + 1, acc[0], A1, A0);
+        }
+        if (kt < KT) stage(SPLIT, kt, acc[0], A0, A1);
+    } else {
+        // k-tile by k-tile: q, k, v stages share the fragment of the k-tile; the v stage prepares the next one
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(KEEP, 3 * kt, acc[0], A0, A0);
+            stage(KEEP, 3 * kt + 1, acc[1], A0, A0);
+            stage(SPLIT, 3 * kt + 2, acc[2], A0, A1);
+            stage(KEEP, 3 * kt + 3, acc[0], A1, A1);
+            stage(KEEP, 3 * kt + 4, acc[1], A1, A1);
+            stage(SPLIT, 3 * kt + 5, acc[2], A1, A0);
         }
         if (kt < KT) {
-            stage(tb + kt, acc[pass], A0, A1);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) A0[i] = A1[i];
+            stage(KEEP, 3 * kt, acc[0], A0, A0);
+            stage(KEEP, 3 * kt + 1, acc[1], A0, A0);
+            stage(SPLIT, 3 * kt + 2, acc[2], A0, A1);
         }
     }
 #undef MPL_X3
