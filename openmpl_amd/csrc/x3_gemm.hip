@@ -568,10 +568,12 @@ static int launch_x3(const X3Args& a, hipStream_t s) {
 
 template <int EPI, bool LN>
 static int launch_x3_auto(const X3Args& a, hipStream_t s) {
-    // two workgroups per CU (2-stage rings) once there are more workgroups than CUs, else one with a deeper ring
+    // two workgroups per CU (2-stage rings) once there are more workgroups than CUs, else one with a deeper ring.  The
+    // residual instances hold their prefetched residual + LayerNorm hand-over in ~190 registers, so only one of them
+    // fits a CU whatever the ring: always the deeper one.
     static const int force = getenv("MPL_X3_NST") ? atoi(getenv("MPL_X3_NST")) : 0;   // bench-only
     const int wgs = a.grid_m * a.grid_n;
-    int nst = wgs > 256 ? 2 : 3;
+    int nst = (wgs > 256 && EPI != MPL_EPI_BIAS_RESIDUAL) ? 2 : 3;
     if (force) nst = force;
     static const bool dbg = getenv("MPL_X3_DBG") != nullptr;   // bench-only phase timing into stats_out
     if (dbg && EPI == MPL_EPI_BIAS_RESIDUAL && !LN && a.stats_out) {
