@@ -24,9 +24,15 @@
 // one k-tile of 32: A 64 x 128 B (16-B columns XOR-swizzled with key (row >> 1) & 5: conflict free for the
 // two-b128-per-lane A fragment) | W 27 KiB | gamma, beta 1 KiB = 36 KiB; ring of NST stages (2: two workgroups
 // per CU; 3: one; 4: the attention variant, whose epilogue needs 117 KiB).
-// NPASS = 3 (fused LN1 + qkv + attention): the workgroup runs the k loop three times -- q, k, v slices of its 136
-// channels, accumulators of finished passes parked in registers -- and then finishes Attention.forward :55-64
-// exactly like ln_gemm_ng_kernel<ATT>.
+// The k loop is software pipelined around a barrier in the MIDDLE of the iteration (see x3_body): MFMA batch 0 of
+// stage t | barrier | LayerNorm + split of the A fragment of stage t+1 interleaved with MFMA batch 1 of stage t.
+// NPASS = 3 (fused LN1 + qkv + attention): three accumulator sets for the q, k, v slices of the workgroup's 136
+// channels; the stages run k-tile by k-tile (q, k, v of k-tile 0, q, k, v of k-tile 1, ...) so that ONE A fragment
+// (LayerNorm + split) serves three stages, and the A tile is staged only with the q stage.  Afterwards the workgroup
+// finishes Attention.forward :55-64 exactly like ln_gemm_ng_kernel<ATT> (attention_on_tile).
+// Special values: an operand is reproduced exactly unless |x| > 3.389e38 (bf16(x) overflows) or its low parts fall
+// below the bf16 normal range (|x| < ~1e-33 loses trailing bits) -- outside anything a LayerNorm-ed activation or a
+// trained weight takes; inf / nan propagate as nan, as inf - inf does in the residual.
 // The k order of every output element is fixed (k-tiles ascending, six products in the order above), so results do
 // not depend on the batch size or launch geometry.
 #include <stdlib.h>
@@ -152,15 +158,6 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     const int T = NPASS * KT;                    // stages
     auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0; };
 
-    float mu = 0.f, rs = 1.f;
-    if (LN) {
-        int m = m0 + rg * 16 + li;
-        m = m < M ? m : M - 1;
-        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
-        ln_combine(a.stats + (size_t)m * ns * 2, ns, sl, K, a.eps, mu, rs);
-        asm volatile("" : "+v"(mu), "+v"(rs));   // consume the loads before the k loop (see ln_gemm.hip)
-    }
-
     // ---- DMA slots of this wave: A piece `wave` (8 rows); a run of ADJACENT W pieces (waves 0..2: four starting at
     // 4 w, waves 3..7: three starting at 3 w + 3) -- source and destination are both contiguous, so one M0 write
     // serves the run and the pieces differ only by the instruction's immediate offset; gamma/beta from wave 7.
@@ -232,6 +229,18 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     for (int t = 0; t < NST; ++t)
         if (t < T) issue_next();
 
+    // LayerNorm statistics of this lane's row: loaded AFTER the first stages are in flight, so that the two cold
+    // latencies (statistics from the previous kernel's epilogue, first k-tiles) overlap instead of adding up
+    float mu = 0.f, rs = 1.f;
+    if (LN) {
+        int m = m0 + rg * 16 + li;
+        m = m < M ? m : M - 1;
+        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
+        ln_combine(a.stats + (size_t)m * ns * 2, ns, sl, K, a.eps, mu, rs);
+        asm volatile("" : "+v"(mu), "+v"(rs));   // consume the loads before the k loop (see ln_gemm.hip)
+    }
+
+
     f32x4 acc[NPASS][NTW];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p)
@@ -239,7 +248,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float rv[NTW][4];
     const int row0 = m0 + rg * 16 + 4 * kq;
-    const int t_res = T - 2;
+    const int t_res = T >= 4 ? T - 4 : 0;        // residual prefetch: ~4 stages (~3 us) ahead of the epilogue
     const int key = (li >> 1) & 5;
     constexpr int NB0 = (NTW + 1) / 2, NB1 = NTW - NB0;   // column tiles of the two B batches (3+2 or 2+2)
 
