@@ -97,6 +97,10 @@ def load():
         path = lib_path()
         if not os.path.exists(path):
             _build.build()
+        # torch bundles its own HIP runtime (libamdhip64): it must be in the process BEFORE this library is mapped, so
+        # that both resolve to ONE runtime instance -- loaded the other way round, the kernels of this library are
+        # launched on a second runtime that has no initialised device ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
         lib = C.CDLL(path)
         for name in EXPORTS:
             if not hasattr(lib, name):

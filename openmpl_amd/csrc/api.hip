@@ -117,6 +117,10 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     return MPL_OK;
 }
 
+// hipGetLastError() is per-thread state shared with the caller: a benign failure inside the caller's own HIP use (e.g.
+// torch probing a host pointer) would otherwise be reported by the first launch check of this library.
+inline void clear_stale_hip_error() { (void)hipGetLastError(); }
+
 int check_cfg(const mpl_config* cfg) {
     if (!cfg) return MPL_E_INVALID;
     if (cfg->num_views < 1 || cfg->num_views > MPL_MAX_VIEWS || cfg->depth < 0 || cfg->depth > 60) return MPL_E_INVALID;
@@ -184,6 +188,7 @@ size_t mpl_forward_workspace_bytes(const mpl_config* cfg, int batch) {
 }
 
 int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, void* stream) {
+    clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !in || !xs) return MPL_E_INVALID;
@@ -192,6 +197,7 @@ int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs
 
 int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
                     const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, void* stream) {
+    clear_stale_hip_error();
     return block_stack_impl(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes,
                             (hipStream_t)stream);
 }
@@ -199,6 +205,7 @@ int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mp
 int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const float* W,
                   const float* bias, int N, int epilogue, const float* residual, float* y, float* stats,
                   void* stream) {
+    clear_stale_hip_error();
     if (!x || !W || !bias || !y) return MPL_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (ln_w) {
@@ -215,6 +222,7 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
 size_t mpl_split_bf16x3_bytes(int N, int K) { return K >= 64 ? x3_operand_bytes(N, K) : 0; }
 
 int mpl_split_bf16x3(const float* W, int N, int K, uint16_t* dst, void* stream) {
+    clear_stale_hip_error();
     if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
     return launch_split_bf16x3(W, N, K, dst, (hipStream_t)stream);
 }
@@ -222,6 +230,7 @@ int mpl_split_bf16x3(const float* W, int N, int K, uint16_t* dst, void* stream) 
 int mpl_ln_linear_x3(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const uint16_t* W3,
                      const float* bias, int N, int epilogue, const float* residual, float* y, float* stats,
                      void* stream) {
+    clear_stale_hip_error();
     if (!x || !W3 || !bias || !y || mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (ln_w) {
@@ -235,15 +244,18 @@ int mpl_ln_linear_x3(const float* x, int M, int K, const float* ln_w, const floa
 }
 
 int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+    clear_stale_hip_error();
     return launch_convert_bf16(src, dst, n, (hipStream_t)stream);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {
+    clear_stale_hip_error();
     if (!qkv || !out) return MPL_E_INVALID;
     return launch_token_attention(qkv, n_seq, n_tok, dim, heads, out, (hipStream_t)stream);
 }
 
 int mpl_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, void* stream) {
+    clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !out) return MPL_E_INVALID;
@@ -251,6 +263,7 @@ int mpl_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, i
 }
 
 int mpl_view_fuse(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* y, void* stream) {
+    clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !y) return MPL_E_INVALID;
@@ -258,6 +271,7 @@ int mpl_view_fuse(const mpl_config* cfg, const mpl_weights* w, const float* x, i
 }
 
 int mpl_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* xn, void* stream) {
+    clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !xn || batch <= 0) return MPL_E_INVALID;
@@ -266,6 +280,7 @@ int mpl_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, i
 
 int mpl_layernorm(const float* x, int M, int K, const float* gamma, const float* beta, float eps, float* y,
                   void* stream) {
+    clear_stale_hip_error();
     if (!x || !gamma || !beta || !y) return MPL_E_INVALID;
     return launch_layernorm_rows(x, M, K, K, gamma, beta, eps, y, K, (hipStream_t)stream);
 }
@@ -273,6 +288,7 @@ int mpl_layernorm(const float* x, int M, int K, const float* gamma, const float*
 int mpl_linear(const float* xa, int Ka, const float* xb, int Kb, int M, const float* W, const float* bias, int N,
                const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var, float bn_eps, int relu,
                float* y, void* stream) {
+    clear_stale_hip_error();
     return launch_linear_act(xa, Ka, Ka, xb, Kb, Kb, M, W, Ka + Kb, bias, N, bn_w, bn_b, bn_mean, bn_var, bn_eps, relu, y, N,
                              (hipStream_t)stream);
 }
@@ -280,6 +296,7 @@ int mpl_linear(const float* xa, int Ka, const float* xb, int Kb, int M, const fl
 int mpl_prepare_inputs(const float* joints_px, const float* conf, const double* cams_dev, int batch, int views, int joints,
                        float img_w, float img_h, int normalize_inputs, int normalize_cameras, float* const* poses,
                        float* const* rays, float* const* centers, void* stream) {
+    clear_stale_hip_error();
     return launch_prepare_inputs(joints_px, conf, cams_dev, batch, views, joints, img_w, img_h, normalize_inputs,
                                  normalize_cameras, poses, rays, centers, (hipStream_t)stream);
 }
@@ -288,11 +305,13 @@ int mpl_pose_metrics_size(int joints) { return 4 + 2 * (joints + 1) + 3 * joints
 
 int mpl_pose_metrics(const float* output, const float* target, const float* weight, int batch, int joints,
                      const float* scale3, const float* offset3, float* result, void* stream) {
+    clear_stale_hip_error();
     return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, result, (hipStream_t)stream);
 }
 
 int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* out, void* workspace,
                 size_t workspace_bytes, void* stream) {
+    clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !in || !out || in->batch <= 0) return MPL_E_INVALID;

@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 kernels (wave64, fp32 MFMA 16x16x4).
 #pragma once
+#include <stdio.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -50,6 +51,7 @@ struct ProfScope {
 
 inline int hip_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "mpl_hip: kernel launch failed: %s\n", hipGetErrorString(e));
     return e == hipSuccess ? MPL_OK : MPL_E_LAUNCH;
 }
 

@@ -256,11 +256,14 @@ class MultiView_MPL(nn.Module):
         return self
 
     def _x3_supported(self) -> bool:
-        """The split-operand GEMMs need the FPT width to be a multiple of 136 (544, 1088: every view-token model)."""
+        """The split-operand GEMMs need every FPT Linear shape to have a split layout (out features a multiple of 136,
+        in features of 32: widths 544 and 1088, i.e. every view-token model at DIM 32); mpl_split_bf16x3_bytes decides."""
         if self.no_transformer_fpt or len(self.blocks) == 0:
             return False
-        d = self.blocks[0].attn.qkv.weight.shape[1]
-        return d % 136 == 0 and d >= 64
+        lib = cabi.load()
+        b = self.blocks[0]
+        return all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0
+                   for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight))
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _apply(self, fn, *a, **k):
