@@ -53,6 +53,9 @@ constexpr int X3_T0 = 5;                    // column tiles of waves 0..3; waves
 // M = 4096, D = 544: 444-446 k poses/s with, 450-455 k without -- the phases do not overlap better, the lagging wave
 // just holds more registers across the barrier.  Kept for experiments, off in the product build.
 constexpr bool X3_DEPHASE = false;
+#ifndef X3_LEAD
+#define X3_LEAD 2
+#endif
 
 // 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32).  Written
 // stage by stage over the 8 elements so that the four packed chains interleave instead of stalling on each other.
@@ -394,10 +397,10 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         auto lo_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w << 16); };
         auto hi_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w & 0xffff0000u); };
         if constexpr (do_split) {
-        __builtin_amdgcn_sched_barrier(0);
-            mfma_next();
+            // X3_LEAD MFMAs ahead of the first VALU group cover the latency of the A fragment reads just issued
             __builtin_amdgcn_sched_barrier(0);
-            mfma_next();
+#pragma unroll
+            for (int k = 0; k < X3_LEAD; ++k) mfma_next();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {            // hi part + first residual of pair j
