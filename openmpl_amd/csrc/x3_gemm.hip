@@ -155,11 +155,12 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         }
     }
     const int M = a.M, N = a.N, K = a.K;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // NPASS = 2: the workgroup owns two ADJACENT 136-column groups (tn counts pairs); NPASS = 3: the q, k, v slices
+    const int m0 = tm * BM, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
     const int Dq = N / 3;                        // NPASS == 3: width of each of q, k, v
     const int KT = K / BK;
     const int T = NPASS * KT;                    // stages
-    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0; };
+    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
 
     // ---- DMA slots of this wave: A piece `wave` (8 rows); a run of ADJACENT W pieces (waves 0..2: four starting at
     // 4 w, waves 3..7: three starting at 3 w + 3) -- source and destination are both contiguous, so one M0 write
@@ -461,6 +462,19 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             stage(SPLIT, kt + 1, acc[0], A1, A0);
         }
         if (kt < KT) stage(SPLIT, kt, acc[0], A0, A1);
+    } else if constexpr (NPASS == 2) {
+        // two column groups per k-tile share one fragment; the second stage prepares the next one
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(KEEP, 2 * kt, acc[0], A0, A0);
+            stage(SPLIT, 2 * kt + 1, acc[1], A0, A1);
+            stage(KEEP, 2 * kt + 2, acc[0], A1, A1);
+            stage(SPLIT, 2 * kt + 3, acc[1], A1, A0);
+        }
+        if (kt < KT) {
+            stage(KEEP, 2 * kt, acc[0], A0, A0);
+            stage(SPLIT, 2 * kt + 1, acc[1], A0, A1);
+        }
     } else {
         // k-tile by k-tile: q, k, v stages share the fragment of the k-tile; the v stage prepares the next one
         int kt = 0;
@@ -481,7 +495,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
 #undef MPL_X3
 
     const unsigned long long t_epi = DBG ? now() : 0;
-    if (NPASS == 3) {
+    if constexpr (NPASS == 3) {
         // ---- fused attention epilogue.  T[64][412]: q | k | v (+bias) of this workgroup's 136 channels.
         float* Tt = reinterpret_cast<float*>(smem);
         float* SC = Tt + BM * ATT_TS;
@@ -504,6 +518,11 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     }
 
     float v[NTW][4];
+    if constexpr (NPASS == 2) {   // two plain (bias / GELU) tiles side by side; no residual, no statistics
+        tile_values_store<EPI, NTW>(acc[0], a.bias, rv, a.C, a.ldc, M, N, row0, n0, n0 + tile0 * 16, li, v);
+        tile_values_store<EPI, NTW>(acc[1], a.bias, rv, a.C, a.ldc, M, N, row0, n0 + BN, n0 + BN + tile0 * 16, li, v);
+        return;
+    }
     tile_values_store<EPI, NTW>(acc[0], a.bias, rv, a.C, a.ldc, M, N, row0, n0, n0 + tile0 * 16, li, v);
     const unsigned long long t_st = DBG ? now() : 0;
     if (EPI == MPL_EPI_BIAS_RESIDUAL && a.stats_out) {
@@ -563,7 +582,8 @@ template <int EPI, bool LN, int NPASS, int NST>
 static int launch_x3(const X3Args& a, hipStream_t s) {
     constexpr int LDS = NST * X3_STAGE;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
-    static_assert(NPASS == 1 || (BM * ATT_TS + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
+    static_assert(NPASS != 3 || (BM * ATT_TS + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
+    static_assert(NPASS != 2 || EPI != MPL_EPI_BIAS_RESIDUAL, "the paired instance has no residual epilogue");
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
@@ -598,6 +618,18 @@ static int launch_x3_auto(const X3Args& a, hipStream_t s) {
         hipLaunchKernelGGL((x3_gemm_kernel<MPL_EPI_BIAS_RESIDUAL, false, 1, 3, true>), dim3(a.grid_m * a.grid_n), dim3(512),
                            3 * X3_STAGE, s, b);
         return hip_check_launch();
+    }
+    // More 136-column tiles than CUs (LN2 + fc1 + GELU, the unfused qkv): give each workgroup two adjacent column
+    // groups instead -- one LayerNorm + split of the A fragment then serves two stages, at one workgroup per CU with a
+    // 4-stage ring.  Measured on MI355X: fc1 at M = 4096, D = 544 39.4 -> 37.4 us, FULL flag set (D = 1088) +2.4 %.
+    // Same k order per output element: bitwise identical results (tools/x3_pair_check.py).
+    static const bool nopair = getenv("MPL_X3_NOPAIR") != nullptr;   // bench-only A/B switch
+    if constexpr (EPI != MPL_EPI_BIAS_RESIDUAL) {
+        if (!nopair && !force && (a.grid_n & 1) == 0 && wgs > 256) {
+            X3Args b = a;
+            b.grid_n = a.grid_n / 2;
+            return launch_x3<EPI, LN, 2, 4>(b, s);
+        }
     }
     switch (nst) {
         case 2: return launch_x3<EPI, LN, 1, 2>(a, s);
