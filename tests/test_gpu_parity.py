@@ -405,3 +405,21 @@ def test_fp32_paths_agree_and_are_both_batch_invariant():
     assert mx < 5e-6 and nw < 5e-6, (mx, nw)
     with pytest.raises(ValueError):
         m.set_matmul_precision("tf32")
+
+
+def test_split_operand_bytes_match_the_definition():
+    """mpl_split_bf16x3 against oracle/split_oracle.py: every bf16 part, in MFMA fragment order, byte for byte."""
+    from oracle import split_oracle
+    lib = cabi.load()
+    g = torch.Generator().manual_seed(3)
+    for N, K in ((272, 64), (544, 544), (1632, 544)):
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        W[0, 0], W[1, 1], W[2, 2] = 0.0, 1.0 + 2 ** -23, -255.99998
+        Wd = W.to(DEV)
+        dst = torch.zeros(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=DEV)
+        cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), N, K, dst.data_ptr(), _stream()), "mpl_split_bf16x3")
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy().view(np.uint16)
+        want = split_oracle.split_operand(W.numpy()).reshape(-1)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "N=%d K=%d: %d of %d bf16 words differ" % (N, K, int((got != want).sum()), want.size)
