@@ -286,6 +286,35 @@ def main():
             sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
             r3 = mpl_oracle.forward(sd3, f3, [x[:64].cpu() for x in P3], [x[:64].cpu() for x in R3], [x[:64].cpu() for x in C3])
             mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
+            # PCIe-inclusive rate of the headline workload: the same forwards fed from pinned host
+            # tensors, H2D of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
+            host = [tuple([t.cpu().pin_memory() for t in lst] for lst in b) for b in batches[:2]]
+            def h2d_step(i):
+                Ph, Rh, Ch = host[i % 2]
+                up = lambda lst: [t.to(dev, non_blocking=True) for t in lst]
+                return model(up(Ph), rays=up(Rh), centers=up(Ch))
+            with torch.no_grad():
+                for i in range(3):
+                    h2d_step(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_o):
+                    h2d_step(i)
+                torch.cuda.synchronize()
+            extra["h2d_inclusive_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
+            # BASELINE.json configs[4]: large-view stress V=31, batch 256 (31-token FPT; separate attention kernel), and
+            # the 17V = 527-token joints x views grid (KPTOK, LDS-resident K/V of one head)
+            for tag, fl in (("v31_b256_chosen", {}), ("v31_b256_kptok", dict(FPT_blocks_view_keypoint_tokens=True))):
+                from openmpl_amd import detrng as _dr
+                from openmpl_amd.multiview_mpl import MultiView_MPL as _M
+                f5 = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=a.depth, num_views=31, **CHOSEN, **fl)
+                m5 = _M(**f5)
+                _dr.fill_module_(m5, seed=11)
+                m5 = m5.to(dev).eval()
+                b5 = [make_batch(256, 31, dev, seed=3000, step=s) for s in range(2)]
+                n5 = max(5, a.steps // 5)
+                extra[tag + "_poses_per_s"] = round(256 * n5 / timed_steps(m5, b5, n5, 2, None, None), 1)
+                del m5
             extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1),
                                       "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
                                       "bf16_mpjpe_vs_ref": float("%.3e" % mpl_oracle.mpjpe(o16, r3))}
