@@ -423,3 +423,24 @@ def test_split_operand_bytes_match_the_definition():
         want = split_oracle.split_operand(W.numpy()).reshape(-1)
         assert got.shape == want.shape
         assert np.array_equal(got, want), "N=%d K=%d: %d of %d bf16 words differ" % (N, K, int((got != want).sum()), want.size)
+
+
+def test_split_operands_follow_in_place_weight_updates():
+    """The split operands are derived data: an in-place update of a Linear weight (what load_state_dict and optimizers
+    do) must be picked up by the next forward -- the nn.Parameter stays the only source of truth."""
+    m, g = _model("chosen_v4_b8_l2")
+    P, R, Cn = golden_inputs(g, DEV)
+    with torch.no_grad():
+        base = m(P, rays=R, centers=Cn).clone()
+        m.blocks[1].mlp.fc2.weight.mul_(1.25)
+        m.blocks[0].attn.qkv.weight.add_(0.01)
+        upd = m(P, rays=R, centers=Cn)
+    assert not torch.allclose(base, upd)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cp, cr, cc = golden_inputs(g, "cpu")
+    _assert_close(upd, mpl_oracle.forward(sd, g["flags"], cp, cr, cc), "after in-place weight update")
+    # load_state_dict restores the original weights in place: results are bitwise those of the first call
+    m.load_state_dict(golden_state_dict("chosen_v4_b8_l2", g), strict=True)
+    with torch.no_grad():
+        again = m(P, rays=R, centers=Cn)
+    assert torch.equal(again, base)
