@@ -56,6 +56,10 @@ constexpr bool X3_DEPHASE = false;
 #ifndef X3_LEAD
 #define X3_LEAD 2
 #endif
+#ifndef X3_B1_EARLY
+#define X3_B1_EARLY 0   // 1: fetch the second B batch of stage t+1 at the end of stage t -- measured -10 % (the reads hit the WAR
+                        // hazard on registers the batch-1 MFMAs still read and cannot slip under the next batch-0 MFMAs)
+#endif
 
 // 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32).  Written
 // stage by stage over the 8 elements so that the four packed chains interleave instead of stalling on each other.
@@ -304,7 +308,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         float x[8], gg[8], ee[8];
         read_a(0, x, gg, ee);
         read_b0(0);
-        if (LAG) read_b1(0);
+        if (LAG || X3_B1_EARLY) read_b1(0);
         norm_split(x, gg, ee, A0);
     }
     unsigned slot_c = 0;                         // ring slot (byte offset) of the current stage
@@ -357,7 +361,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             if (DBG) s3 = now();
         };
         if (!LAG) {
-            read_b1(slot_c);
+            if (!X3_B1_EARLY) read_b1(slot_c);
             batch0();
             if (DBG) s1 = now();
             sync();
@@ -444,7 +448,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         }
         // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
         if (!B0_EARLY) read_b0(slot_n);
-        if (LAG) read_b1(slot_n);
+        if (LAG || X3_B1_EARLY) read_b1(slot_n);
         slot_c = slot_n;
         if (DBG) {
             const unsigned long long s4 = now();
