@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X multi-view pose-lifting forward pass.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (plain: for N > 1 it starts its own N child ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (also fine: RANK / WORLD_SIZE / LOCAL_RANK from the env)
 
 Metric (BASELINE.json): poses/s at V=4, J=17, batch 1024 (per GPU), fp32, the paper's CHOSEN flag set
-(configs/h36m: NETWORK.DIM 32, depth 12, heads 8).  A "step" = one forward of one batch of 1024 synthetic
-poses that are already resident in HBM when the timed region starts; with N ranks every rank lifts its own
-1024 poses (weak scaling) and the per-shard (B,17,3) outputs are exchanged with ONE RCCL all-gather per
-step, the MI355X equivalent of the reference's DataParallel gather (valid_mpl.py:178).
+(configs/h36m: NETWORK.DIM 32, depth 12, heads 8).  A "step" = one forward of one batch of 1024 synthetic poses
+that are already resident in HBM when the timed region starts; with N ranks every rank lifts its own 1024 poses
+(weak scaling, inputs pre-sharded: no rank touches another rank's frames) and the per-shard (B,17,3) outputs are
+exchanged with ONE RCCL all-gather per step -- the MI355X equivalent of the reference's DataParallel gather
+(valid_mpl.py:177-178) -- issued asynchronously so that it overlaps the next step's forward.
+
+When invoked plainly with --gpus N > 1 the parent process imports nothing that touches the GPU: it starts N fresh
+children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's line.
 
 Rank 0 prints ONE JSON line: value = whole-job poses/s, plus
-  roofline     -- dominant kernel (the GEMMs of the FPT blocks): algorithmic fp32 FLOPs per launch / mean launch
-                  duration measured live with HIP events on the launch stream (mpl_profile_start/stop) against the
-                  157.3 TFLOP/s fp32 matrix peak.  The default fp32 path computes those GEMMs on the bf16 matrix
-                  cores from exactly split operands (csrc/x3_gemm.hip: fp32 in, fp32 out, at least fp32-accurate
-                  products, fp32 accumulation), so `matrix_pipe` also prices the executed bf16 MFMA work against
-                  the 2.5 PFLOP/s bf16 peak; --precision fp32_mfma runs the native fp32 MFMA kernels instead.
-  cpu_baseline -- the oracle (a port of the reference's CPU PyTorch path) timed on this box's host cores.
+  roofline     -- dominant kernel (x3_gemm_kernel: the GEMMs of the FPT blocks): FLOPs per launch / mean launch duration
+                  measured live with HIP events on the launch stream (mpl_profile_start/stop).  The default fp32 path
+                  computes those GEMMs on the bf16 matrix cores from exactly split operands (fp32 in, fp32 out, fp32
+                  accumulation, products at least fp32-accurate: csrc/x3_gemm.hip), so the binding ceiling is the bf16
+                  matrix pipe: `frac` = executed bf16 MFMA FLOP/s / 2.5 PFLOP/s; `fp32_equivalent` keeps the
+                  algorithmic fp32 FLOP/s against the 157.3 TFLOP/s fp32 matrix peak.  `kernels` lists every kernel
+                  kind of the forward (SPT included) the same way.
+  cpu_baseline -- the oracle (a port of the reference's CPU PyTorch path) timed on this box's host cores, headline
+                  workload first, BASELINE.md section 4's other configurations under `others`.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,12 +60,54 @@ def parse():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--flagset", choices=("chosen", "full"), default="chosen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary FULL-flag-set measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs / engines)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the rank code path (process group + all-gather) even at one GPU")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_mfma"],
                     help="fp32: split-operand GEMMs on the bf16 matrix cores (default); fp32_mfma: native fp32 MFMA")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------ parent: start the ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """Start n fresh child processes of this script, one per GPU.  Nothing GPU-related has been imported here."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:                            # one rank died: the others would hang in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            q.terminate()
+        rc = 130
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ helpers
 def effective_cpus():
     """Host cores this process may actually use: min(affinity, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -75,15 +126,29 @@ def effective_cpus():
     return max(1, n)
 
 
-def build_model(flagset, views, depth, dev):
-    import torch
-    from openmpl_amd import detrng
-    from openmpl_amd.multiview_mpl import MultiView_MPL
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def model_flags(flagset, views, depth, **more):
     flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=depth, num_views=views)
     flags.update(CHOSEN if flagset == "chosen" else FULL)
+    flags.update(more)
+    return flags
+
+
+def build_model(flags, dev):
+    from openmpl_amd import detrng
+    from openmpl_amd.multiview_mpl import MultiView_MPL
     m = MultiView_MPL(**flags)
     detrng.fill_module_(m, seed=11)          # random-init weights of the named architecture (no checkpoints offline)
-    return m.to(dev).eval(), flags
+    return m.to(dev).eval()
 
 
 def make_batch(batch, views, dev, seed, step=0):
@@ -94,67 +159,111 @@ def make_batch(batch, views, dev, seed, step=0):
     return mk(p), mk(r), mk(c)
 
 
+def fpt_width(flags):
+    return 17 * 32 * (2 if flags.get("input_rays_as_token") else 1)
+
+
 def gemm_flops_per_forward(flags, batch):
-    """Algorithmic FLOPs of the ln_gemm launches of one forward: per FPT block 16*N*D^2 (= the four Linear
-    layers, 2*MAC) x (depth+1) applications (the 4*N^2*D attention term runs in another kernel)."""
-    D = 17 * 32 * (2 if flags.get("input_rays_as_token") else 1)
-    V = flags["num_views"]
+    """Algorithmic FLOPs of the FPT GEMM launches of one forward: per block 16*N*D^2 (= the four Linear layers,
+    2*MAC) x (depth+1) applications -- the 4*N^2*D attention term that the qkv instance also
+    executes in its epilogue is NOT counted."""
+    D = fpt_width(flags)
     apps = flags["depth"] + 1
-    return apps * 16.0 * V * D * D * batch, apps * 4
+    return apps * 16.0 * flags["num_views"] * D * D * batch, apps * 4
 
 
-def timed_steps(model, batches, steps, warmup, dist, gather_buf):
+def spt_flops_per_forward(flags, batch):
+    """SPT stage (one launch): per view 17 tokens x 32 channels, depth+1 block applications."""
+    N, D = 17, 32
+    per_view = (flags["depth"] + 1) * (16.0 * N * D * D + 4.0 * N * N * D)
+    return per_view * flags["num_views"] * batch
+
+
+def timed_steps(model, batches, steps, warmup, lifter=None, global_batch=None):
+    """EXACTLY `steps` forwards between two (barrier +) device synchronisations.  With a lifter every step also starts
+    its all-gather; the wait for step i's exchange is issued after step i+1's forward has been enqueued."""
     import torch
-    if dist is not None:
-        from openmpl_amd.dist import gather_outputs as _go
-        gather_outputs = lambda out, total: _go(out, total)
-    def step(i):
-        P, R, C = batches[i % len(batches)]
-        out = model(P, rays=R, centers=C)
-        if dist is not None:
-            out = gather_outputs(out, gather_buf)      # ONE RCCL all-gather of the (B/G,17,3) shards
-        return out
+    import torch.distributed as dist
+
+    def run(n):
+        pending = None
+        for i in range(n):
+            P, R, C = batches[i % len(batches)]
+            if lifter is None:
+                model(P, rays=R, centers=C)
+            else:
+                h = lifter.lift_shard(P, R, C, batch=global_batch)
+                if pending is not None:
+                    pending.wait()
+                pending = h
+        if pending is not None:
+            pending.wait()
+
     with torch.no_grad():
-        for i in range(warmup):
-            step(i)
-        if dist is not None:
+        run(warmup)
+        if lifter is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        if dist is not None:
+        run(steps)
+        if lifter is not None:
             dist.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
 
-def main():
-    a = parse()
+def time_cpu(flags, sd, P, R, C, budget_s, label):
+    """Oracle (port of the reference CPU path) on the host cores: forwards of the given batch for ~budget_s seconds."""
+    from oracle import mpl_oracle
+    nb = P[0].shape[0]
+    mpl_oracle.forward(sd, flags, P, R, C)         # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        mpl_oracle.forward(sd, flags, P, R, C)
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s or reps >= 2000:
+            break
+    dt = time.perf_counter() - t0
+    return dict(config=label, value=round(nb * reps / dt, 1), unit="poses/s",
+                sample="%d forwards of %d poses in %.1f s" % (reps, nb, dt))
+
+
+def latest_profile(name):
+    """profiles/rNN_<name> of the newest round that has one."""
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+    return c[-1] if c else None
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(a):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: --gpus %d but this node exposes %d GPU(s)" % (rank, a.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist_mod.init_process_group("nccl", device_id=dev)   # backend "nccl" IS RCCL on ROCm
-        dist = dist_mod
-
-    model, flags = build_model(a.flagset, a.views, a.depth, dev)
+    lifter = None
+    flags = model_flags(a.flagset, a.views, a.depth)
+    model = build_model(flags, dev)
     model.set_matmul_precision(a.precision)
+    if world > 1 or a.force_dist:
+        import torch.distributed as dist
+        from openmpl_amd.dist import ShardedLifter
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # backend "nccl" IS RCCL on ROCm
+        lifter = ShardedLifter(model)
     split = a.precision == "fp32" and model._x3_supported()
-    # a few distinct resident batches so that no step can reuse a cached result
+    # a few distinct resident batches (per rank: pre-sharded inputs) so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
-    gather_buf = world * a.batch if dist is not None else None   # global batch size of the gathered result
 
-    dt = timed_steps(model, batches, a.steps, a.warmup, dist, gather_buf)
+    dt = timed_steps(model, batches, a.steps, a.warmup, lifter, world * a.batch)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,178 +273,255 @@ def main():
 
     result = None
     if rank == 0:
-        from openmpl_amd import cabi
-        from oracle import mpl_oracle
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
-        P, R, C = batches[0]
-        n_prof = 5
-        with torch.no_grad():
-            cabi.profile_start()
-            for _ in range(n_prof):
-                model(P, rays=R, centers=C)
-            torch.cuda.synchronize()
-            prof = cabi.profile_stop()
-        gemm_ms, gemm_n = prof["gemm"]
-        fl, launches = gemm_flops_per_forward(flags, a.batch)
-        assert gemm_n == launches * n_prof, (gemm_n, launches)
-        avg_launch_ms = gemm_ms / gemm_n
-        achieved = (fl / launches) / (avg_launch_ms * 1e-3) / 1e12
-        kernel_ms = {k: round(t / n_prof, 4) for k, (t, n) in prof.items()}
-        total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
-        io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
-        weight_bytes = sum(p.numel() for p in model.parameters()) * 4
-        # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed
-        # rocprofv3 PMC passes of the same kernels (profiles/), and only for the profiled workload shape.
-        traffic, traffic_src = None, None
-        try:
-            if a.flagset == "chosen" and a.batch == 1024 and a.views == 4:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))
-                if tj.get("kernel") != ("x3_gemm_kernel" if split else "ln_gemm_ng_kernel"):
-                    raise KeyError("profile is for the other GEMM kernel")
-                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), tj["source"]
-        except Exception:
-            pass
-        # executed matrix-pipe work of the split path: 6 bf16 products per fp32 product on 144-column (9 x 16) tiles
-        pipe = None
-        if split:
-            ex = achieved * 6.0 * 144.0 / 136.0
-            pipe = dict(instruction="v_mfma_f32_16x16x32_bf16", executed=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
-                        note="6 bf16 partial products per fp32 product (3-way exact operand split), 9 MFMA column "
-                             "tiles per 136 output columns")
-        roof = dict(bound="mfma", kernel="x3_gemm_kernel" if split else "ln_gemm_ng_kernel",
-                    arithmetic=("fp32 operands split exactly into 3 bf16 terms, 6 significant partial products per "
-                                "product on the bf16 matrix cores, fp32 accumulation (error vs fp64 <= native fp32)")
-                    if split else "native fp32 MFMA (v_mfma_f32_16x16x4_f32)",
-                    achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, matrix_pipe=pipe,
-                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                    traffic_source=traffic_src,
-                    avg_launch_us=round(avg_launch_ms * 1e3, 2), launches_per_step=launches,
-                    flops_per_launch=fl / launches,
-                    whole_forward_tflops=round(value / world * total_flop / 1e12, 2),
-                    whole_forward_frac=round(value / world * total_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    hbm_frac=round(value / world * (io_bytes + weight_bytes / a.batch) / 1e9 / PEAK_HBM_GBS, 5),
-                    kernel_ms_per_step=kernel_ms)
-
-        # ---- parity of this very run against the oracle (bounded: 64 poses)
-        nb = min(64, a.batch)
-        cp = [x[:nb].cpu() for x in P]; cr = [x[:nb].cpu() for x in R]; cc = [x[:nb].cpu() for x in C]
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        with torch.no_grad():
-            got = model([x[:nb].contiguous() for x in P], rays=[x[:nb].contiguous() for x in R],
-                        centers=[x[:nb].contiguous() for x in C]).cpu()
-        ref = mpl_oracle.forward(sd, flags, cp, cr, cc)
-        mx, nw = mpl_oracle.rel_errors(got, ref)
-        parity = dict(max_scaled=float("%.3e" % mx), norm_wise=float("%.3e" % nw),
-                      mpjpe_vs_ref=float("%.3e" % mpl_oracle.mpjpe(got, ref)), poses=nb, tol=1e-4)
-
-        # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
-        cpu = None
-        if not a.no_cpu_baseline:
-            cores = effective_cpus()
-            torch.set_num_threads(cores)
-            cb = min(a.batch, 256)                     # bounded sample: batches of 256 poses of the same workload
-            cp = [x[:cb].cpu() for x in P]; cr = [x[:cb].cpu() for x in R]; cc = [x[:cb].cpu() for x in C]
-            mpl_oracle.forward(sd, flags, cp, cr, cc)      # warm-up
-            reps, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 12.0 and reps < 400:
-                mpl_oracle.forward(sd, flags, cp, cr, cc)
-                reps += 1
-            cdt = time.perf_counter() - t0
-            cpu = dict(value=round(cb * reps / cdt, 1), unit="poses/s", cores=cores, kind="port",
-                       sample="%d forwards of %d poses in %.1f s (V=%d, depth %d, fp32, torch threads=%d = cgroup CPU "
-                              "quota of the box), oracle/mpl_oracle.py" % (reps, cb, cdt, a.views, a.depth, cores))
-
-        extra = {}
-        if not a.no_extra and world == 1 and a.flagset == "chosen":
-            # the other fp32 engine on the same workload, and all of them against an fp64 evaluation of the reference
-            # semantics: the split-operand path must not be less accurate than fp32 arithmetic
-            other = "fp32_mfma" if a.precision == "fp32" else "fp32"
-            model.set_matmul_precision(other)
-            n_o = max(10, a.steps // 2)
-            v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3, None, None)
-            with torch.no_grad():
-                got_o = model([x[:nb].contiguous() for x in P], rays=[x[:nb].contiguous() for x in R],
-                              centers=[x[:nb].contiguous() for x in C]).cpu()
-            model.set_matmul_precision(a.precision)
-            ref64 = mpl_oracle.forward(sd, flags, [x[:nb].cpu() for x in P], [x[:nb].cpu() for x in R],
-                                       [x[:nb].cpu() for x in C], dtype=torch.float64)
-            e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
-            extra[other + "_poses_per_s"] = round(v_o, 1)
-            extra["max_scaled_err_vs_fp64"] = {"hip_" + a.precision: e(got), "hip_" + other: e(got_o),
-                                               "reference_fp32_cpu": e(ref)}
-            # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
-            m2, f2 = build_model("full", a.views, a.depth, dev)
-            dt2 = timed_steps(m2, batches, max(5, a.steps // 4), 3, None, None)
-            v2 = a.batch * max(5, a.steps // 4) / dt2
-            extra["full_flagset_poses_per_s"] = round(v2, 1)
-            extra["full_flagset_tflops"] = round(v2 * mpl_oracle.flop_count(f2) / 1e12, 2)
-            del m2
-            # BASELINE.json configs[2]: CMU Panoptic shape V=8, batch 1024, bf16 matrix cores (yaml depth 2), with the
-            # fp32 run of the same shape and the bf16 deviation from the fp32 reference semantics (reported, not gated)
-            m3, f3 = build_model("chosen", 8, 2, dev)
-            b3 = [make_batch(a.batch, 8, dev, seed=2000, step=s) for s in range(2)]
-            n3 = max(10, a.steps // 2)
-            v32 = a.batch * n3 / timed_steps(m3, b3, n3, 3, None, None)
-            m3.set_matmul_precision("bf16")
-            v16 = a.batch * n3 / timed_steps(m3, b3, n3, 3, None, None)
-            P3, R3, C3 = b3[0]
-            with torch.no_grad():
-                o16 = m3([x[:64].contiguous() for x in P3], rays=[x[:64].contiguous() for x in R3],
-                         centers=[x[:64].contiguous() for x in C3]).cpu()
-            sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
-            r3 = mpl_oracle.forward(sd3, f3, [x[:64].cpu() for x in P3], [x[:64].cpu() for x in R3], [x[:64].cpu() for x in C3])
-            mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
-            # PCIe-inclusive rate of the headline workload: the same forwards fed from pinned host
-            # tensors, H2D of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
-            host = [tuple([t.cpu().pin_memory() for t in lst] for lst in b) for b in batches[:2]]
-            def h2d_step(i):
-                Ph, Rh, Ch = host[i % 2]
-                up = lambda lst: [t.to(dev, non_blocking=True) for t in lst]
-                return model(up(Ph), rays=up(Rh), centers=up(Ch))
-            with torch.no_grad():
-                for i in range(3):
-                    h2d_step(i)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(n_o):
-                    h2d_step(i)
-                torch.cuda.synchronize()
-            extra["h2d_inclusive_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
-            # BASELINE.json configs[4]: large-view stress V=31, batch 256 (31-token FPT; separate attention kernel), and
-            # the 17V = 527-token joints x views grid (KPTOK, LDS-resident K/V of one head)
-            for tag, fl in (("v31_b256_chosen", {}), ("v31_b256_kptok", dict(FPT_blocks_view_keypoint_tokens=True))):
-                from openmpl_amd import detrng as _dr
-                from openmpl_amd.multiview_mpl import MultiView_MPL as _M
-                f5 = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=a.depth, num_views=31, **CHOSEN, **fl)
-                m5 = _M(**f5)
-                _dr.fill_module_(m5, seed=11)
-                m5 = m5.to(dev).eval()
-                b5 = [make_batch(256, 31, dev, seed=3000, step=s) for s in range(2)]
-                n5 = max(5, a.steps // 5)
-                extra[tag + "_poses_per_s"] = round(256 * n5 / timed_steps(m5, b5, n5, 2, None, None), 1)
-                del m5
-            extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1),
-                                      "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
-                                      "bf16_mpjpe_vs_ref": float("%.3e" % mpl_oracle.mpjpe(o16, r3))}
-            del m3
-
-        result = {
-            "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) fp32" % (a.views, a.batch),
-            "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Human3.6M config: V=%d J=17 batch=%d fp32, %s flag set, depth %d, DIM 32, heads 8"
-                                   % (a.views, a.batch, a.flagset.upper(), a.depth),
-                       "global_batch": world * a.batch, "parallelism": "dp%d (batch shards + 1 all_gather/step)" % world
-                       if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "extra": extra,
-        }
+        result = report(a, model, flags, batches, dev, world, value, ms_per_step, split, dist is not None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+
+
+def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used_dist):
+    import torch
+    from openmpl_amd import cabi
+    from oracle import mpl_oracle
+    # ---- per-kernel time, measured live with HIP events on the launch stream (NOT part of the timed region above)
+    P, R, C = batches[0]
+    n_prof = 5
+    with torch.no_grad():
+        cabi.profile_start()
+        for _ in range(n_prof):
+            model(P, rays=R, centers=C)
+        torch.cuda.synchronize()
+        prof = cabi.profile_stop()
+    gemm_ms, gemm_n = prof["gemm"]
+    fl, launches = gemm_flops_per_forward(flags, a.batch)
+    assert gemm_n == launches * n_prof, (gemm_n, launches)
+    avg_launch_ms = gemm_ms / gemm_n
+    alg = (fl / launches) / (avg_launch_ms * 1e-3) / 1e12          # fp32-algorithmic TFLOP/s of the mean launch
+    kernel_ms = {k: round(t / n_prof, 4) for k, (t, n) in prof.items()}
+    total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
+    io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
+    weight_bytes = sum(p.numel() for p in model.parameters()) * 4
+    gemm_kernel = "x3_gemm_kernel" if split else "ln_gemm_ng_kernel"
+    # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
+    # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
+    traffic, traffic_src = None, None
+    try:
+        tp = latest_profile("gemm_traffic.json")
+        if tp and a.flagset == "chosen" and a.batch == 1024 and a.views == 4 and a.depth == 12:
+            tj = json.load(open(tp))
+            if tj.get("kernel") == gemm_kernel:
+                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tp, ROOT) + ": " + tj["source"]
+    except Exception:
+        pass
+    D = fpt_width(flags)
+    # algorithmic bytes of the mean GEMM launch: A + W operand + C (+ residual) once each
+    M = a.batch * a.views
+    w_bytes = 6.35 if split else 4.0        # split operand: 3 bf16 parts in 144/136-padded fragment order
+    alg_bytes = ((M * D * 4 + 3 * D * D * w_bytes + M * D * 4)            # LN1 + qkv + attention: x in, att out
+                 + (M * D * 4 + D * D * w_bytes + 2 * M * D * 4)           # proj: att in, x in/out
+                 + (M * D * 4 + 2 * D * D * w_bytes + M * 2 * D * 4)       # fc1: x in, hid out
+                 + (M * 2 * D * 4 + 2 * D * D * w_bytes + 2 * M * D * 4)) / 4.0   # fc2: hid in, x in/out
+    if split:
+        # executed matrix-pipe work: 6 bf16 partial products per fp32 product on 144-column (9 x 16) tiles of 136
+        ex = alg * 6.0 * 144.0 / 136.0
+        roof = dict(bound="mfma", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x32_bf16",
+                    achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                    arithmetic="fp32 GEMM: operands split exactly into 3 bf16 terms, 6 significant partial products per "
+                               "fp32 product on the bf16 matrix cores (9 MFMA column tiles per 136 output columns), fp32 "
+                               "accumulation; `achieved` = algorithmic fp32 FLOPs x 6 x 144/136 = executed bf16 MFMA FLOP/s",
+                    fp32_equivalent=dict(achieved=round(alg, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                         frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                                         note="algorithmic fp32 FLOP/s against the fp32 matrix pipe this kernel does not use"))
+    else:
+        roof = dict(bound="mfma", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x4_f32", achieved=round(alg, 2),
+                    peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                    arithmetic="native fp32 MFMA")
+    spt_ms, spt_n = prof["spt"]
+    spt_fl = spt_flops_per_forward(flags, a.batch)
+    spt_t = spt_fl / (spt_ms / max(1, spt_n) * 1e-3) / 1e12
+    kernels = [dict(kernel=gemm_kernel, launches_per_step=launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
+                    flops_per_launch=fl / launches, algorithmic_bytes_per_launch=round(alg_bytes),
+                    share_of_kernel_time=round(gemm_ms / sum(t for t, _ in prof.values()), 3)),
+               dict(kernel="spt_kernel", launches_per_step=1, avg_launch_us=round(spt_ms / max(1, spt_n) * 1e3, 2),
+                    flops_per_launch=spt_fl, bound="mfma", instruction="v_mfma_f32_16x16x4_f32 + VALU attention",
+                    achieved=round(spt_t, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(spt_t / PEAK_FP32_MFMA_TFLOPS, 4),
+                    share_of_kernel_time=round(spt_ms / sum(t for t, _ in prof.values()), 3))]
+    roof.update(traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(avg_launch_ms * 1e3, 2),
+                launches_per_step=launches, flops_per_launch=fl / launches,
+                algorithmic_bytes_per_launch=round(alg_bytes), kernels=kernels,
+                whole_forward_tflops=round(value / world * total_flop / 1e12, 2),
+                whole_forward_frac_of_fp32_peak=round(value / world * total_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                hbm_frac=round(value / world * (io_bytes + weight_bytes / a.batch) / 1e9 / PEAK_HBM_GBS, 5),
+                kernel_ms_per_step=kernel_ms,
+                kernel_ms_note="per-launch HIP-event brackets of 5 extra forwards outside the timed region; every "
+                               "bracket adds ~1 us, so their sum slightly exceeds ms_per_step")
+
+    # ---- parity of this very run against the oracle (bounded: 64 poses)
+    nb = min(64, a.batch)
+    sub = lambda lst, n: [x[:n].contiguous() for x in lst]
+    cpu = lambda lst, n: [x[:n].cpu() for x in lst]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        got = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
+    ref = mpl_oracle.forward(sd, flags, cpu(P, nb), cpu(R, nb), cpu(C, nb))
+    mx, nw = mpl_oracle.rel_errors(got, ref)
+    parity = dict(max_scaled=float("%.3e" % mx), norm_wise=float("%.3e" % nw),
+                  mpjpe_vs_ref=float("%.3e" % mpl_oracle.mpjpe(got, ref)), poses=nb, tol=1e-4)
+
+    # ---- CPU baseline: the oracle on the host cores (rank 0, N = 1 only)
+    cpu_base = None
+    if not a.no_cpu_baseline and world == 1:
+        cores = effective_cpus()
+        torch.set_num_threads(cores)
+        label = "configs[1] V=%d B=%d depth %d %s fp32" % (a.views, a.batch, a.depth, a.flagset.upper())
+        head = time_cpu(flags, sd, cpu(P, a.batch), cpu(R, a.batch), cpu(C, a.batch), 10.0, label)
+        others = []
+        if not a.no_extra:
+            # configs[0] (V=2, B=1, depth 12: the CPU plumbing case), configs[1] with the other
+            # flag set, configs[2]'s shape (V=8, depth 2; the CPU runs it in fp32)
+            from openmpl_amd import detrng
+            def case(fl_, batch, budget, lab):
+                shapes = mpl_oracle.param_shapes(fl_)
+                sdc = {k: torch.from_numpy(v) for k, v in detrng.make_state_dict(shapes, seed=11).items()}
+                p, r, c = detrng.make_inputs(batch, fl_["num_views"], seed=1000)
+                t = lambda l: [torch.from_numpy(x) for x in l]
+                return time_cpu(fl_, sdc, t(p), t(r), t(c), budget, lab)
+            others.append(case(model_flags("chosen", 2, 12), 1, 3.0, "configs[0] V=2 B=1 depth 12 CHOSEN fp32 (latency case)"))
+            other_set = "full" if a.flagset == "chosen" else "chosen"
+            others.append(case(model_flags(other_set, a.views, a.depth), a.batch, 8.0,
+                               "configs[1] V=%d B=%d depth %d %s fp32" % (a.views, a.batch, a.depth, other_set.upper())))
+            others.append(case(model_flags("chosen", 8, 2), 1024, 6.0, "configs[2] shape V=8 B=1024 depth 2 CHOSEN (fp32 on the CPU)"))
+        cpu_base = dict(value=head["value"], unit="poses/s", cores=cores, cpu=cpu_model(), kind="port",
+                        sample=head["sample"] + " (%s; torch threads = %d = cgroup CPU quota of the box), "
+                                                "oracle/mpl_oracle.py" % (label, cores),
+                        others=others)
+
+    extra = {}
+    if not a.no_extra and world == 1 and a.flagset == "chosen":
+        extra = extras(a, model, flags, batches, dev, sd, got, ref, nb)
+
+    return {
+        "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) fp32" % (a.views, a.batch),
+        "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": world if used_dist else 0,
+        "config": {"workload": "Human3.6M config: V=%d J=17 batch=%d fp32, %s flag set, depth %d, DIM 32, heads 8"
+                               % (a.views, a.batch, a.flagset.upper(), a.depth),
+                   "global_batch": world * a.batch,
+                   "parallelism": ("dp%d: pre-sharded batch, 1 async RCCL all_gather of (B/G,17,3) per step" % world)
+                   if used_dist else "single GPU"},
+        "roofline": roof, "cpu_baseline": cpu_base, "parity": parity, "extra": extra,
+    }
+
+
+def extras(a, model, flags, batches, dev, sd, got, ref, nb):
+    """Secondary measurements (single GPU): the other fp32 engine, accuracy of all engines against fp64, the FULL flag
+    set, BASELINE.json configs[2] (V=8, bf16) and configs[4] (V=31), small-batch latency, the PCIe-inclusive rate."""
+    import torch
+    from openmpl_amd import detrng
+    from openmpl_amd.multiview_mpl import MultiView_MPL
+    from oracle import mpl_oracle
+    extra = {}
+    P, R, C = batches[0]
+    sub = lambda lst, n: [x[:n].contiguous() for x in lst]
+    cpu = lambda lst, n: [x[:n].cpu() for x in lst]
+    other = "fp32_mfma" if a.precision == "fp32" else "fp32"
+    model.set_matmul_precision(other)
+    n_o = max(10, a.steps // 2)
+    v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3)
+    with torch.no_grad():
+        got_o = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
+    model.set_matmul_precision(a.precision)
+    ref64 = mpl_oracle.forward(sd, flags, cpu(P, nb), cpu(R, nb), cpu(C, nb), dtype=torch.float64)
+    e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
+    extra[other + "_poses_per_s"] = round(v_o, 1)
+    extra["max_scaled_err_vs_fp64"] = {"hip_" + a.precision: e(got), "hip_" + other: e(got_o), "reference_fp32_cpu": e(ref)}
+    # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
+    f2 = model_flags("full", a.views, a.depth)
+    m2 = build_model(f2, dev)
+    n2 = max(5, a.steps // 4)
+    v2 = a.batch * n2 / timed_steps(m2, batches, n2, 3)
+    extra["full_flagset_poses_per_s"] = round(v2, 1)
+    extra["full_flagset_tflops"] = round(v2 * mpl_oracle.flop_count(f2) / 1e12, 2)
+    del m2
+    # BASELINE.json configs[2]: CMU Panoptic shape V=8, batch 1024, bf16 matrix cores (yaml depth 2), with the fp32 run
+    # of the same shape and the bf16 deviation from the fp32 reference semantics (reported, not gated)
+    f3 = model_flags("chosen", 8, 2)
+    m3 = build_model(f3, dev)
+    b3 = [make_batch(a.batch, 8, dev, seed=2000, step=s) for s in range(2)]
+    n3 = max(10, a.steps // 2)
+    v32 = a.batch * n3 / timed_steps(m3, b3, n3, 3)
+    m3.set_matmul_precision("bf16")
+    v16 = a.batch * n3 / timed_steps(m3, b3, n3, 3)
+    P3, R3, C3 = b3[0]
+    with torch.no_grad():
+        o16 = m3(sub(P3, 64), rays=sub(R3, 64), centers=sub(C3, 64)).cpu()
+    sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
+    r3 = mpl_oracle.forward(sd3, f3, cpu(P3, 64), cpu(R3, 64), cpu(C3, 64))
+    mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
+    extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1),
+                              "bf16_tflops": round(v16 * mpl_oracle.flop_count(f3) / 1e12, 1),
+                              "bf16_frac_of_bf16_peak": round(v16 * mpl_oracle.flop_count(f3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                              "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
+                              "bf16_mpjpe_vs_ref": float("%.3e" % mpl_oracle.mpjpe(o16, r3))}
+    del m3
+    # PCIe-inclusive rate of the headline workload (SURVEY.md 8d): the same forwards fed from pinned host tensors, H2D
+    # of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
+    host = [tuple([t.cpu().pin_memory() for t in lst] for lst in b) for b in batches[:2]]
+
+    def h2d_step(i):
+        Ph, Rh, Ch = host[i % 2]
+        up = lambda lst: [t.to(dev, non_blocking=True) for t in lst]
+        return model(up(Ph), rays=up(Rh), centers=up(Ch))
+    with torch.no_grad():
+        for i in range(3):
+            h2d_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_o):
+            h2d_step(i)
+        torch.cuda.synchronize()
+    extra["h2d_inclusive_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
+    # BASELINE.json configs[0] shape on the GPU: single-frame latency (V=2, B=1, depth 12), synchronised per call
+    f0 = model_flags("chosen", 2, a.depth)
+    m0 = build_model(f0, dev)
+    b0 = [make_batch(1, 2, dev, seed=4000, step=s) for s in range(2)]
+    with torch.no_grad():
+        for i in range(5):
+            m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(50):
+            m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+            torch.cuda.synchronize()
+        extra["v2_b1_latency_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    del m0
+    # BASELINE.json configs[4]: large-view stress V=31, batch 256 (31-token FPT), and the 17V = 527-token joints x views
+    # grid (KPTOK, LDS-resident K/V of one head)
+    for tag, fl in (("v31_b256_chosen", {}), ("v31_b256_kptok", dict(FPT_blocks_view_keypoint_tokens=True))):
+        f5 = model_flags("chosen", 31, a.depth, **fl)
+        m5 = build_model(f5, dev)
+        b5 = [make_batch(256, 31, dev, seed=3000, step=s) for s in range(2)]
+        n5 = max(5, a.steps // 5)
+        v5 = 256 * n5 / timed_steps(m5, b5, n5, 2)
+        extra[tag + "_poses_per_s"] = round(v5, 1)
+        extra[tag + "_tflops"] = round(v5 * mpl_oracle.flop_count(f5) / 1e12, 1)
+        del m5
+    return extra
+
+
+def main():
+    a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+    run_rank(a)
 
 
 if __name__ == "__main__":

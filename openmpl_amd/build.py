@@ -28,36 +28,81 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libmpl_hip.so)")
 
 
+STAMP_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """Content hash of everything the library is built from (mtimes do not survive the snapshot copy to a GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP_PATH).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile + link under an exclusive file lock, into private temporaries, and publish the library with one
+    atomic rename: N ranks starting together (torchrun / bench.py --gpus N) never see a half-written .so, and all but
+    the first find it up to date once they get the lock."""
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     cc = _hipcc()
+    srchash = source_hash()          # of the sources as they are NOW: an edit during the build leaves the stamp stale
     objs = []
     procs = []
+    tag = ".%d" % os.getpid()
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIB_DIR, src.replace(".hip", tag + ".o"))
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
+    failed = None
     for src, p in procs:
         out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if p.returncode != 0 and failed is None:
+            failed = "hipcc failed on %s:\n%s" % (src, out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError(failed)
+    tmp_so = LIB_PATH + tag
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp_so] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    for o in objs:
+        try:
+            os.remove(o)
+        except OSError:
+            pass
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    os.replace(tmp_so, LIB_PATH)
+    with open(STAMP_PATH + tag, "w") as f:
+        f.write(srchash + "\n")
+    os.replace(STAMP_PATH + tag, STAMP_PATH)
     return LIB_PATH
 
 

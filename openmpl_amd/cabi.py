@@ -95,8 +95,16 @@ def load():
         if _lib is not None:
             return _lib
         path = lib_path()
-        if not os.path.exists(path):
-            _build.build()
+        # stale or missing library: rebuild (under build.py's file lock, published atomically) when a compiler is
+        # there; a box without hipcc must have received a library that is at least as new as the sources
+        if _build.needs_build():
+            try:
+                _build.build()
+            except RuntimeError:
+                if not os.path.exists(path):
+                    raise
+                import warnings
+                warnings.warn("libmpl_hip.so is older than openmpl_amd/csrc and hipcc is not available to rebuild it")
         # torch bundles its own HIP runtime (libamdhip64): it must be in the process BEFORE this library is mapped, so
         # that both resolve to ONE runtime instance -- loaded the other way round, the kernels of this library are
         # launched on a second runtime that has no initialised device ("no ROCm-capable device is detected")

@@ -4,31 +4,39 @@
 
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 using namespace mpl;
 
-// ------------------------------------------------------------------ profiling aid (not thread safe)
+// ------------------------------------------------------------------ profiling aid
+// The only process-global mutable state of the library besides the set-once function-attribute flags: a list of event
+// pairs, guarded by a mutex (launches may come from one thread per GPU under DataParallel).  Off unless
+// mpl_profile_start() was called; the fast path is one relaxed atomic load.
 namespace {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kind;
 };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
 mpl::ProfScope::ProfScope(int kind, hipStream_t s) : slot(-1), stream(s) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     ProfRec r;
     r.kind = kind;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, s);
+    std::lock_guard<std::mutex> g(g_prof_mu);
     g_prof.push_back(r);
     slot = (int)g_prof.size() - 1;
 }
 mpl::ProfScope::~ProfScope() {
-    if (slot >= 0) hipEventRecord(g_prof[slot].e1, stream);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    if (slot < (int)g_prof.size()) hipEventRecord(g_prof[slot].e1, stream);
 }
 
 namespace {
@@ -59,6 +67,8 @@ StackWs carve_stack_ws(void* base, size_t M, size_t D) {
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
                      const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!x || n_seq <= 0 || n_tok <= 0 || D <= 0 || H <= 0 || n_apps < 0) return MPL_E_INVALID;
+    // row counts are 32-bit in the kernels (byte offsets are 64-bit): refuse what would overflow instead of wrapping
+    if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int M = n_seq * n_tok;
@@ -132,13 +142,15 @@ int check_cfg(const mpl_config* cfg) {
 extern "C" {
 
 int mpl_profile_start(void) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
     g_prof.clear();
-    g_prof_on = true;
+    g_prof_on.store(true);
     return MPL_OK;
 }
 
 int mpl_profile_stop(float* kind_ms, int* kind_launches, int n_kinds) {
-    g_prof_on = false;
+    g_prof_on.store(false);
+    std::lock_guard<std::mutex> g(g_prof_mu);
     if (!kind_ms || !kind_launches || n_kinds < MPL_K_COUNT) return MPL_E_INVALID;
     for (int k = 0; k < n_kinds; ++k) {
         kind_ms[k] = 0.f;
@@ -315,6 +327,7 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !in || !out || in->batch <= 0) return MPL_E_INVALID;
+    if ((long long)in->batch * cfg->num_views * cfg->num_joints > (1ll << 30)) return MPL_E_UNSUPPORTED;
     const size_t need = mpl_forward_workspace_bytes(cfg, in->batch);
     if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;

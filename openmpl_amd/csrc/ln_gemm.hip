@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
         }
     }
     const int m0 = tm * BM;
+    // row base of the tile in the wave-uniform 64-bit DMA base: the per-lane 32-bit offsets are tile relative, so
+    // operands beyond 4 GiB are addressed correctly
+    const float* At = A + (size_t)m0 * lda;
     const int n0 = ATT ? tn * BN : tn * (BN * NG);
     const int Dq = N / 3;                                    // ATT: width of each of q, k, v
     auto colbase = [&](int g) -> int { return ATT ? g * Dq + n0 : n0 + g * BN; };   // first column of group g
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
         const int r = (a * NW + wave) * 8 + (lane >> 3);
         int m = m0 + r;
         m = m < M ? m : M - 1;
-        voA[a] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+        voA[a] = (unsigned)(((size_t)(m - m0) * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
         asm volatile("" : "+v"(voA[a]));   // opaque: keep it in a register instead of re-deriving it every stage
     }
 #pragma unroll
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
                 const int k0 = (t * KS + ks) * BK;
 #pragma unroll
                 for (int a = 0; a < A_PER; ++a)
-                    if (a < A_PER - 1 || a_on) dma16_fast(voA[a], A + k0, st + (unsigned)((a * NW + wave) * 1024));
+                    if (a < A_PER - 1 || a_on) dma16_fast(voA[a], At + k0, st + (unsigned)((a * NW + wave) * 1024));
 #pragma unroll
                 for (int b = 0; b < W_FULL; ++b) dma16_fast(voW[b], W + k0, st + (unsigned)((8 + b * NW + wave) * 1024));
                 if (w_extra) dma16_fast(voW[W_FULL], W + k0, st + (unsigned)((8 + W_FULL * NW + wave) * 1024));
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
             const int r = p * 8 + (lane >> 3);
             int m = m0 + r;
             m = m < M ? m : M - 1;
-            lA[p] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+            lA[p] = (unsigned)(((size_t)(m - m0) * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
             asm volatile("" : "+v"(lA[p]));
         }
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256 * NG * KG + (LDW ? 64 : 0), 1) void ln_gemm_ng_
                     const unsigned st = lds0 + (unsigned)((t % NST) * STAGE + ks * SS::BYTES);
                     const int k0 = (t * KS + ks) * BK;
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) dma16_fast(lA[p], A + k0, st + (unsigned)(p * 1024));
+                    for (int p = 0; p < 8; ++p) dma16_fast(lA[p], At + k0, st + (unsigned)(p * 1024));
 #pragma unroll
                     for (int p = 0; p < NPW; ++p) dma16_fast(lW[p], W + k0, st + (unsigned)((8 + p) * 1024));
                     if (LN) dma16(gb_src + k0, st + (unsigned)SS::GB);
@@ -465,14 +468,14 @@ static int launch_ng(const float* A, int lda, const float* stats, const float* l
     static_assert((KG - 1) * NG * 4 * NT * 4 * 64 * 4 <= LDS, "k-group reduction does not fit in the ring");
     const int gm = (M + BM - 1) / BM, gn = (N + BN * NG - 1) / (BN * NG);
     static_assert(!ATT || (BM * (3 * BN + 4) + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW, PF>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return MPL_E_LAUNCH;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     ProfScope prof(MPL_K_GEMM, s);
     hipLaunchKernelGGL((ln_gemm_ng_kernel<EPI, LN, NG, KG, KS, NST, ABL, ATT, LDW, PF>), dim3(gm * gn),
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(576, 1) void ln_gemm_cs_kernel(const float* __restr
         }
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    const float* At = A + (size_t)m0 * lda;   // tile row base in the 64-bit DMA base (per-lane offsets tile relative)
     float mu = 0.f, rs = 1.f;
     if (LN && wave < 8) {
         int m = m0 + rg * 16 + li;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(576, 1) void ln_gemm_cs_kernel(const float* __restr
             const int r = p * 8 + (lane >> 3);
             int m = m0 + r;
             m = m < M ? m : M - 1;
-            lA[p] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+            lA[p] = (unsigned)(((size_t)(m - m0) * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
             asm volatile("" : "+v"(lA[p]));
         }
 #pragma unroll
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(576, 1) void ln_gemm_cs_kernel(const float* __restr
             const unsigned st = lds0 + (unsigned)((t % NST) * STAGE);
             const int k0 = t * BK;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) dma16_fast(lA[p], A + k0, st + (unsigned)(p * 1024));
+            for (int p = 0; p < 8; ++p) dma16_fast(lA[p], At + k0, st + (unsigned)(p * 1024));
 #pragma unroll
             for (int p = 0; p < 17; ++p) dma16_fast(lW[p], W + k0, st + (unsigned)((8 + p) * 1024));
             if (LN) dma16(gb_src + k0, st + (unsigned)SS::GB);
@@ -699,14 +703,14 @@ static int launch_cs(const float* A, int lda, const float* stats, const float* l
     constexpr int LDS = NST * SubStage<1>::BYTES + CS_XFER;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)ln_gemm_cs_kernel<EPI, LN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess)
             return MPL_E_LAUNCH;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     ProfScope prof(MPL_K_GEMM, s);
     hipLaunchKernelGGL((ln_gemm_cs_kernel<EPI, LN, NST>), dim3(gm * gn), dim3(576), LDS, s, A, lda, stats, ln_w, ln_b, W,
@@ -841,6 +845,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_bf16_kernel(const float* __res
         }
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    const float* At = A + (size_t)m0 * lda;   // tile row base in the 64-bit DMA base (per-lane offsets tile relative)
     float mu = 0.f, rs = 1.f;
     if (LN) {
         int m = m0 + wave * 16 + li;
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_bf16_kernel(const float* __res
         const int r = (a * 4 + wave) * 8 + (lane >> 3);
         int m = m0 + r;
         m = m < M ? m : M - 1;
-        voA[a] = (unsigned)(((size_t)m * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
+        voA[a] = (unsigned)(((size_t)(m - m0) * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
         asm volatile("" : "+v"(voA[a]));
     }
 #pragma unroll
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_bf16_kernel(const float* __res
         const unsigned st = lds0 + (unsigned)((t % BF_NST) * BF_STAGE);
         const int k0 = t * BK;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) dma16_fast(voA[a], A + k0, st + (unsigned)((a * 4 + wave) * 1024));
+        for (int a = 0; a < 2; ++a) dma16_fast(voA[a], At + k0, st + (unsigned)((a * 4 + wave) * 1024));
 #pragma unroll
         for (int b = 0; b < 2; ++b) dma16_fast(voW[b], W16f + k0 / 2, st + (unsigned)(SUB_A + (b * 4 + wave) * 1024));
         if (w_extra) dma16_fast(voW[2], W16f + k0 / 2, st + (unsigned)(SUB_A + 8 * 1024));

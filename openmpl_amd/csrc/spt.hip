@@ -501,14 +501,14 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     }
     p.n_apps = n;
     // >64 KiB of dynamic LDS needs an explicit opt-in, once per device
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)spt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPT_LDS_BYTES) !=
             hipSuccess)
             return MPL_E_LAUNCH;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const int grid = cfg->num_views * ((in->batch + SEQ - 1) / SEQ);
     ProfScope prof(MPL_K_SPT, s);

@@ -244,14 +244,14 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
             if (spw > 8) spw = 8;
             const size_t lds = spw * seq_bytes;
             if (lds > 64 * 1024) {
-                static bool attr_set[64] = {};
+                static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
                 int dev = 0;
                 if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-                if (!attr_set[dev]) {
+                if (!attr_set[dev].load(std::memory_order_acquire)) {
                     if (hipFuncSetAttribute((const void*)token_attention_lds_kernel,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                         return MPL_E_LAUNCH;
-                    attr_set[dev] = true;
+                    attr_set[dev].store(true, std::memory_order_release);
                 }
             }
             hipLaunchKernelGGL(token_attention_lds_kernel, dim3((n_seq + spw - 1) / spw), dim3(256), lds, s, qkv, out,

@@ -174,7 +174,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
         const int r = wave * 8 + (lane >> 3);
         int m = m0 + r;
         m = m < M ? m : M - 1;
-        voA = (unsigned)(((size_t)m * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 5))) * sizeof(float));
+        voA = (unsigned)(((size_t)(m - m0) * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 5))) * sizeof(float));
         asm volatile("" : "+v"(voA));
     }
     const bool w_four = wave < 3;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
     const char* is_w[NPASS];
 #pragma unroll
     for (int g = 0; g < NPASS; ++g) is_w[g] = a.W3 + (size_t)(colbase(g) / BN) * KT * X3_W;
-    const float* is_a = a.A;
+    const float* is_a = a.A + (size_t)m0 * a.lda;   // tile row base in the 64-bit DMA base: per-lane offsets are tile relative
     auto issue_w = [&](const char* wsrc, unsigned st) {
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
@@ -588,14 +588,14 @@ static int launch_x3(const X3Args& a, hipStream_t s) {
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static_assert(NPASS != 3 || (BM * ATT_TS + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
     static_assert(NPASS != 2 || EPI != MPL_EPI_BIAS_RESIDUAL, "the paired instance has no residual epilogue");
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)x3_gemm_kernel<EPI, LN, NPASS, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess)
             return MPL_E_LAUNCH;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     ProfScope prof(MPL_K_GEMM, s);
     hipLaunchKernelGGL((x3_gemm_kernel<EPI, LN, NPASS, NST>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);

@@ -60,21 +60,84 @@ def gather_outputs(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
     return torch.cat(parts, 0)
 
 
+class GatherHandle:
+    """Result of an asynchronous output exchange: ``wait()`` returns the full (batch, J, 3) tensor.
+
+    With the RCCL backend the all-gather runs on the process group's own stream (it waits for the forward that produced
+    ``local`` through an event, the compute stream is NOT blocked), so the forward of the next batch overlaps it;
+    ``wait()`` makes the current stream wait for the collective -- call it when the gathered poses are needed."""
+
+    def __init__(self, work, buf, batch, world, keep):
+        self._work, self._buf, self._batch, self._world, self._keep = work, buf, batch, world, keep
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        buf, batch, world = self._buf, self._batch, self._world
+        if world == 1 or batch % world == 0:
+            return buf
+        mx = -(-batch // world)
+        parts = []
+        for r in range(world):
+            a, b = shard_range(batch, world, r)
+            parts.append(buf[r * mx: r * mx + (b - a)])
+        return torch.cat(parts, 0)
+
+
+def gather_outputs_async(local: torch.Tensor, batch: int, group=None) -> GatherHandle:
+    """Start the ONE all-gather of a batch (see gather_outputs) without blocking the stream that produced ``local``."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_range(batch, world, rank)
+    if local.shape[0] != hi - lo:
+        raise RuntimeError("rank %d holds %d poses, its shard of %d is %d" % (rank, local.shape[0], batch, hi - lo))
+    if world == 1:
+        return GatherHandle(None, local, batch, 1, None)
+    mx = -(-batch // world)
+    src = local.contiguous()
+    if batch % world:
+        src = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        src[: hi - lo] = local
+    buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(buf, src, group=group, async_op=True)
+    return GatherHandle(work, buf, batch, world, src)
+
+
 class ShardedLifter:
-    """``lifter(poses, rays=..., centers=...)`` with FULL-batch inputs on every rank: each rank lifts its
-    contiguous shard with its own resident model replica and all ranks return the full (B,J,3) result."""
+    """Batch-sharded lifting with one resident model replica per rank.
+
+    ``lifter(poses, rays=..., centers=...)`` takes FULL-batch inputs on every rank (each rank slices its contiguous
+    shard) and returns the full (B,J,3) result on every rank -- the call shape of the reference's DataParallel wrapper
+    (valid_mpl.py:177-178).  ``lifter.lift_shard(poses, ..., batch=B)`` takes inputs that are ALREADY sharded (rank r
+    holds poses shard_range(B, world, r) -- what a per-rank data loader produces: no rank ever touches another rank's
+    frames) and returns a GatherHandle, so the exchange of batch i overlaps the forward of batch i+1."""
 
     def __init__(self, model: Callable, group=None):
         self.model = model
         self.group = group
 
+    def lift_shard(self, poses, rays=None, centers=None, batch: Optional[int] = None) -> GatherHandle:
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        nloc = poses[0].shape[0]
+        if batch is None:
+            batch = nloc * world                       # equal shards
+        lo, hi = shard_range(batch, world, rank)
+        if nloc != hi - lo:
+            raise RuntimeError("rank %d was handed %d poses, its shard of %d is %d" % (rank, nloc, batch, hi - lo))
+        if nloc:
+            out = self.model(poses, rays=rays, centers=centers)
+            if isinstance(out, tuple):                  # head_kadkhod returns (x3, [x1, x2]): exchange the final estimate
+                out = out[0]
+        else:
+            out = poses[0].new_zeros((0, poses[0].shape[1], 3))
+        return gather_outputs_async(out, batch, self.group)
+
     def __call__(self, poses, rays=None, centers=None):
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         B = poses[0].shape[0]
-        p, r, c, (lo, hi) = shard_inputs(poses, rays, centers, world, rank)
-        if hi > lo:
-            out = self.model(p, rays=r, centers=c)
-        else:
-            out = poses[0].new_zeros((0, poses[0].shape[1], 3))
-        return gather_outputs(out, B, self.group)
+        p, r, c, _ = shard_inputs(poses, rays, centers, world, rank)
+        return self.lift_shard(p, r, c, batch=B).wait()

@@ -106,6 +106,7 @@ class MultiView_MPL(nn.Module):
         self.num_heads = num_heads
         self.drop_rate = float(drop_rate)
         self.attn_drop_rate = float(attn_drop_rate)
+        self.drop_path_rate = float(drop_path_rate)
         norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)                      # :139
         embed_dim = embed_dim_ratio * num_joints                                        # :140
         if input_rays_as_token:
@@ -219,6 +220,7 @@ class MultiView_MPL(nn.Module):
 
         self._unsupported = self._find_unsupported()
         self._hip_cache = {}
+        self._dp_replica = False
         self.matmul_precision = "fp32"
 
     # ------------------------------------------------------------------ support matrix
@@ -271,8 +273,13 @@ class MultiView_MPL(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _replicate_for_data_parallel(self):
+        """DataParallel replicas (valid_mpl.py:177-178) get fresh broadcast copies of every parameter on every forward,
+        so derived operand copies could never be reused: replicas run the engines that read the nn.Parameter storage in
+        place (native fp32 MFMA) instead of re-splitting ~180 MB of weights per forward.  The persistent one-process-
+        per-GPU path (openmpl_amd/dist.py) keeps the split-operand engine."""
         r = super()._replicate_for_data_parallel()
-        r._hip_cache = {}           # replicas get fresh broadcast copies of the parameters every forward
+        r._hip_cache = {}
+        r._dp_replica = True
         return r
 
     # ------------------------------------------------------------------ C-ABI argument marshalling
@@ -333,8 +340,8 @@ class MultiView_MPL(nn.Module):
         cache stays valid under in-place updates; it is rebuilt whenever any storage address changes."""
         plist = self._param_list()
         key = tuple(map(torch.Tensor.data_ptr, plist))
-        bf16 = self.matmul_precision == "bf16"
-        x3 = self.matmul_precision == "fp32" and self._x3_supported()
+        bf16 = self.matmul_precision == "bf16" and not self._dp_replica
+        x3 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
         if bf16 or x3:    # derived copies go stale on in-place updates too
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b)[2:12:2])
         ent = self._hip_cache.get(device.index)
@@ -407,6 +414,11 @@ class MultiView_MPL(nn.Module):
             w.head_ln_w, w.head_ln_b = _ptr(self.head[0].weight), _ptr(self.head[0].bias)
             w.head_w, w.head_b = _ptr(self.head[1].weight), _ptr(self.head[1].bias)
         ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks, w16_keep), cfg=self._config(), fpt_blocks=fpt)
+        # the struct blob and the derived copies were enqueued on the stream current NOW: a later forward on another
+        # stream must not read them before that work has finished
+        ent["ready"] = torch.cuda.Event()
+        ent["ready"].record(torch.cuda.current_stream(device))
+        ent["ready_stream"] = torch.cuda.current_stream(device).cuda_stream
         self._hip_cache[device.index] = ent
         return ent
 
@@ -449,9 +461,11 @@ class MultiView_MPL(nn.Module):
     def forward(self, poses: Sequence[torch.Tensor], rays=None, centers=None):
         if self._unsupported:
             raise NotImplementedError("MultiView_MPL (HIP): unsupported configuration: " + self._unsupported)
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("MultiView_MPL (HIP) implements the inference forward only; call .eval() / "
-                               "torch.no_grad() (training loop is out of scope, SURVEY.md section 2 row 3)")
+        if self.training:
+            # train-mode semantics (Dropout, DropPath, BatchNorm batch statistics in the deep / kadkhod heads) are not
+            # implemented, with or without autograd: only the eval forward of validate() exists here
+            raise RuntimeError("MultiView_MPL (HIP) implements the inference forward only (eval-mode semantics): call "
+                               ".eval() first (training loop is out of scope, SURVEY.md section 2 row 3)")
         lib = cabi.load()
         dev, B, poses, rays, centers = self._check_inputs(poses, rays, centers)
         with torch.cuda.device(dev):
@@ -464,6 +478,8 @@ class MultiView_MPL(nn.Module):
                 inp.rays[v] = _ptr(rays[v])
                 inp.centers[v] = _ptr(centers[v])
             stream = torch.cuda.current_stream(dev).cuda_stream
+            if stream != ent["ready_stream"]:
+                torch.cuda.current_stream(dev).wait_event(ent["ready"])
             if self.linear_weighted_mean or self.deep_head or self.head_kadkhod:
                 return self._forward_staged(lib, ent, inp, B, dev, stream)
             ws_bytes = lib.mpl_forward_workspace_bytes(C.byref(cfg), B)

@@ -88,3 +88,65 @@ def build_reference(flags: dict):
     m = mod.MultiView_MPL(**flags)
     m.eval()
     return m
+
+
+CONFIG_FILE = os.path.join(REFERENCE_ROOT, "MPL", "lib", "core", "config.py")
+CONFIG_DIR = os.path.join(REFERENCE_ROOT, "MPL", "configs")
+
+
+def _install_easydict_stub():
+    """``easydict`` is absent from the image; core/config.py only needs attribute access on nested dicts."""
+    if "easydict" in sys.modules and not getattr(sys.modules["easydict"], "_openmpl_stub", False):
+        return
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        @classmethod
+        def _wrap(cls, v):
+            if isinstance(v, dict) and not isinstance(v, cls):
+                return cls(v)
+            if isinstance(v, (list, tuple)):
+                return type(v)(cls._wrap(x) for x in v)
+            return v
+
+        def __setitem__(self, k, v):
+            super().__setitem__(k, self._wrap(v))
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    m = types.ModuleType("easydict")
+    m._openmpl_stub = True
+    m.EasyDict = EasyDict
+    sys.modules["easydict"] = m
+
+
+def load_reference_config(yaml_path: str):
+    """A FRESH copy of the reference's ``core/config.py`` defaults updated from one of its shipped YAMLs
+    (``update_config``, config.py:359-373) -- what ``valid_mpl.py:162`` hands to ``get_multiview_mpl_net``."""
+    if not os.path.isfile(CONFIG_FILE):
+        raise FileNotFoundError(CONFIG_FILE)
+    _install_easydict_stub()
+    spec = importlib.util.spec_from_file_location("_openmpl_reference_config_%d" % len(_CACHE), CONFIG_FILE)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _CACHE["cfg%d" % len(_CACHE)] = mod
+    mod.update_config(yaml_path)
+    return mod.config
+
+
+def shipped_yamls():
+    out = []
+    for root, _, files in os.walk(CONFIG_DIR):
+        out += [os.path.join(root, f) for f in sorted(files) if f.endswith(".yaml")]
+    return sorted(out)

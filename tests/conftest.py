@@ -13,14 +13,19 @@ def pytest_configure(config):
 
 
 def has_gpu():
+    """Counting devices does not initialise the GPU in this process (is_available() would): test_dist_gpu.py starts
+    its child ranks from a process that has not touched the device."""
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 
 
 def pytest_collection_modifyitems(config, items):
+    # the multi-process GPU tests run first: they spawn fresh child ranks and must do so before any other test has
+    # initialised the GPU in this (the parent) process
+    items.sort(key=lambda it: 0 if "test_dist_gpu" in it.nodeid else 1)
     if has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

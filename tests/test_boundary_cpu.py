@@ -95,6 +95,8 @@ def test_no_cpu_fallback_and_loud_errors():
     m.train()
     with pytest.raises(RuntimeError, match="inference forward only"):
         m(x)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="inference forward only"):
+        m(x)          # train mode is refused with autograd off too: Dropout / DropPath / BatchNorm batch statistics
     k = MultiView_MPL(num_views=2, depth=1, FPT_blocks_view_keypoint_tokens=True, input_rays_as_token=True).eval()
     with pytest.raises(NotImplementedError):
         k(x)
@@ -140,3 +142,29 @@ def test_detrng_is_stable():
     # pinned values: any change to the generator invalidates every golden fixture
     v = detrng.uniform01(0, "x", 3)
     assert [round(float(t), 12) for t in v] == [round(float(t), 12) for t in detrng.uniform01(0, "x", 5)[:3]]
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present")
+def test_shipped_yaml_configs_build_the_reference_module_layout():
+    """valid_mpl.py:162 path: every YAML under MPL/configs, loaded through the reference's own core/config.py
+    (update_config, config.py:359-373; easydict stand-in), must construct a module with the reference's parameter
+    names, order and shapes, the same num_views, and load the reference's state_dict strictly."""
+    yamls = ref_import.shipped_yamls()
+    assert len(yamls) == 4
+    ref_mod = ref_import.load_reference_module()
+    seen = set()
+    for y in yamls:
+        cfg = ref_import.load_reference_config(y)
+        assert cfg.MODEL == "multiview_mpl"
+        ref = ref_mod.get_multiview_mpl_net(cfg, is_train=False)
+        ours = get_multiview_mpl_net(cfg, is_train=False)
+        rs, os_ = ref.state_dict(), ours.state_dict()
+        assert list(rs.keys()) == list(os_.keys()), y
+        assert [tuple(v.shape) for v in rs.values()] == [tuple(v.shape) for v in os_.values()], y
+        assert ours.features.num_views == ref.features.num_views
+        assert ours.features.depth == cfg.NETWORK.TRANSFORMER_DEPTH
+        ours.load_state_dict(rs, strict=True)
+        assert ours.features._unsupported is None, (y, ours.features._unsupported)
+        seen.add((ours.features.num_views, ours.features.depth, ours.features.input_rays_as_token))
+    # h36m.yaml: CHOSEN depth 12, 2 views; hm_0_...: FULL depth 12, 4 views; cmu.yaml: CHOSEN depth 2; cmu_0_...: FULL depth 2
+    assert seen == {(2, 12, False), (4, 12, True), (2, 2, False), (2, 2, True)}, seen

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from openmpl_amd import detrng
-from openmpl_amd.dist import ShardedLifter, gather_outputs, shard_range
+from openmpl_amd.dist import ShardedLifter, gather_outputs, shard_inputs, shard_range
 from oracle import mpl_oracle
 
 
@@ -49,7 +49,19 @@ def _worker(rank, world, port, batch, q):
     p, r, c = detrng.make_inputs(batch, 2, seed=9)
     P, R, C = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
     model = lambda poses, rays=None, centers=None: mpl_oracle.forward(sd, FLAGS, poses, rays, centers)
-    out = ShardedLifter(model)(P, rays=R, centers=C)
+    lifter = ShardedLifter(model)
+    out = lifter(P, rays=R, centers=C)
+    # pre-sharded inputs (what a per-rank loader hands over), two exchanges in flight before the first wait
+    ps, rs, cs, _ = shard_inputs(P, R, C, world, rank)
+    h1 = lifter.lift_shard(ps, rs, cs, batch=batch)
+    h2 = lifter.lift_shard([x * 0.5 for x in ps], rs, cs, batch=batch)
+    o1, o2 = h1.wait(), h2.wait()
+    assert torch.equal(o1, out) and o2.shape == out.shape and not torch.equal(o2, out)
+    try:
+        lifter.lift_shard([x[:-1] for x in ps], rs, cs, batch=batch)
+        raise AssertionError("a wrong shard size must raise")
+    except RuntimeError:
+        pass
     lo, hi = shard_range(batch, world, rank)
     # explicit gather of a rank-tagged tensor checks ordering independently of the model
     tag = torch.full((hi - lo, 17, 3), float(rank)) + torch.arange(lo, hi).reshape(-1, 1, 1)

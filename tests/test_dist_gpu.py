@@ -1,0 +1,78 @@
+"""GPU test of the multi-GPU path (BASELINE.json configs[3]): the HIP model through
+openmpl_amd.dist.ShardedLifter over RCCL, in fresh child processes (one per GPU), against the single-process result.
+
+Batch-split invariance of the kernels is bitwise (tests/test_gpu_parity.py), so the sharded result must equal the
+single-GPU result BITWISE, whatever the world size.  World size 1 always runs; world size 2 when the box has two GPUs.
+The children are started by this process, which itself never initialises the GPU (tests/conftest.py orders this module
+first and only counts devices)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(backend, world, out, batch):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, backend, out, str(batch)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, "rank failed:\n" + log[-4000:]
+    return dict(np.load(out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [64, 37])
+def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch):
+    single = _run("single", 1, str(tmp_path / "single.npz"), batch)
+    worlds = [1] + ([2] if torch.cuda.device_count() >= 2 else [])
+    for world in worlds:
+        got = _run("nccl", world, str(tmp_path / ("w%d.npz" % world)), batch)
+        for i in range(2):
+            assert got["full%d" % i].shape == (batch, 17, 3)
+            assert np.array_equal(got["full%d" % i], single["full%d" % i]), "world %d full-batch call differs" % world
+            assert np.array_equal(got["shard%d" % i], single["full%d" % i]), "world %d pre-sharded call differs" % world
+    assert not np.array_equal(single["full0"], single["full1"])
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` invoked plainly (no torchrun) starts N fresh child ranks itself; with one GPU on the
+    box N = 1 still goes through the same rank code path (process group of size 1 when --force-dist is given)."""
+    n = min(2, torch.cuda.device_count())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                        "--no-extra", "--no-cpu-baseline", "--force-dist"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-4000:]
+    import json
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == n and j["rccl_ranks"] == n and j["value"] > 0
+    assert j["parity"]["max_scaled"] < 1e-4
