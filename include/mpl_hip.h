@@ -7,8 +7,11 @@
  * header is the boundary a binding for that contract calls: plain pointers and sizes,
  * no torch types.  All `const float*` below are DEVICE pointers to fp32 data in the
  * reference's own parameter layouts (nn.Linear weight = [out][in] row-major, i.e. the
- * tensors of the reference state_dict are consumed as they are -- nothing is re-packed,
- * so an optimizer updating parameters in place never invalidates anything).
+ * tensors of the reference state_dict are consumed as they are).  The one exception is
+ * optional DERIVED data: the bf16 / split-operand copies of the FPT Linear weights that
+ * mpl_convert_bf16 / mpl_split_bf16x3 build from those tensors; whoever hands them over
+ * must rebuild them when the source parameters change (the Python binding keys them on
+ * the parameters' storage addresses and versions).
  * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); every call only
  * enqueues work on it and never synchronises.  Every function returns 0 on success or a
  * negative MPL_E_* code (mpl_hip_error_string() explains it); nothing falls back to a CPU
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 3
+#define MPL_HIP_ABI_VERSION 4
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -78,11 +81,12 @@ typedef struct mpl_block_weights {
      * GEMMs run on the bf16 matrix cores (bf16 operands, fp32 accumulate; LayerNorm, softmax, GELU, residual and
      * stored activations stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
     const uint16_t *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;
-    /* Optional split operands (mpl_split_bf16x3) of the four Linear weights.  When all four are non-NULL (and the
-     * *_w16 are NULL) the block's GEMMs run as fp32 arithmetic on the bf16 matrix cores: every fp32 operand is the
-     * exact sum of three bf16 numbers and each product is accumulated in fp32 from its six significant partial
-     * products -- at least as accurate as an fp32 multiply (csrc/x3_gemm.hip), 2.7x less matrix-pipe time than the
-     * native fp32 MFMA.  Shapes must satisfy mpl_split_bf16x3_bytes() != 0, else leave them NULL. */
+    /* Optional split operands (mpl_split_bf16x3) of the four Linear layers: qkv built with norm1 folded, fc1 with norm2
+     * folded, proj / fc2 plain.  When all four are non-NULL (and the *_w16 are NULL) in every block of a stack whose
+     * shape the engine supports (D a multiple of 544, n_tok <= 32), the stack runs as fp32 arithmetic on the bf16 matrix
+     * cores: every fp32 operand is the exact sum of three bf16 numbers, each product is accumulated in fp32 from its six
+     * significant partial products -- at least as accurate as an fp32 multiply (csrc/x3_gemm.hip) at 2.7x less matrix-
+     * pipe time than the native fp32 MFMA.  Shapes must satisfy mpl_split_bf16x3_bytes() != 0, else leave them NULL. */
     const uint16_t *qkv_w3, *proj_w3, *fc1_w3, *fc2_w3;
 } mpl_block_weights;
 
@@ -162,15 +166,26 @@ int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the optional *_w16 operands of mpl_block_weights. */
 int mpl_convert_bf16(const float *src, uint16_t *dst, size_t n, void *stream);
 
-/* Split operand of an nn.Linear weight W[N][K] for the fp32-on-bf16-matrix-core GEMMs: three bf16 parts
- * (hi + mid + lo == w exactly) in MFMA fragment order.  mpl_split_bf16x3_bytes() is the size of `dst` in bytes, or 0
- * when the shape is not supported (N must be a multiple of 136, K of 32, K >= 64). */
+/* Split operand of an nn.Linear layer (W[N][K], bias[N]) for the fp32-on-bf16-matrix-core GEMMs: three bf16 parts per
+ * weight (hi + mid + lo == w exactly) in MFMA fragment order, followed by two fp32 vectors of N entries.  With
+ * ln_w / ln_b != NULL the LayerNorm in front of the layer is folded in:  LN(x).W^T + b = rstd (x.(gamma o W)^T - mean s) + c,
+ * the operand holds gamma o W, s_n = sum_k gamma_k W_nk and c_n = b_n + sum_k beta_k W_nk (else c = bias, s = 0).
+ * mpl_split_bf16x3_bytes() is the size of `dst` in bytes, or 0 when the shape is not supported (N must be a multiple
+ * of 136, K of 544). */
 size_t mpl_split_bf16x3_bytes(int N, int K);
-int mpl_split_bf16x3(const float *W, int N, int K, uint16_t *dst, void *stream);
-/* mpl_ln_linear with the split operand W3 in place of W (same epilogues; `stats` as there).  fp32 in, fp32 out. */
-int mpl_ln_linear_x3(const float *x, int M, int K, const float *ln_w, const float *ln_b, float eps, const uint16_t *W3,
-                     const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
+int mpl_split_bf16x3(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
                      void *stream);
+/* mpl_ln_linear on the split operand W3 (built WITH ln_w / ln_b when has_ln): fp32 in, fp32 out, same epilogues.
+ * `stats` as in mpl_ln_linear (needed when has_ln); `workspace` holds the split copy of x
+ * (mpl_ln_linear_x3_workspace_bytes). */
+size_t mpl_ln_linear_x3_workspace_bytes(int M, int K);
+int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W3, int N, int epilogue,
+                     const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Diagnostics (tools/x3_phase.py): when non-NULL, every split-operand GEMM launch writes five shader-clock stamps per
+ * wave (entry, k-loop start, k-loop end, stores issued, stores drained) at device_buffer[(block * 8 + wave) * 8 ..];
+ * the buffer must hold 64 bytes per wave of the largest launch.  NULL (the default) switches it off. */
+int mpl_x3_debug_buffer(void *device_buffer);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

@@ -64,6 +64,80 @@ StackWs carve_stack_ws(void* base, size_t M, size_t D) {
     return w;
 }
 
+// split-operand path (x3_gemm.hip): the activations between the GEMMs of a block live as split A3 operands
+struct X3Ws {
+    unsigned short *x3, *att3, *hid3;
+    float* stats;
+    unsigned* counters;          // one arrival counter per row tile (x3_stack_kernel)
+    size_t bytes;
+};
+
+X3Ws carve_x3_ws(void* base, size_t M, size_t D, int rpt) {
+    X3Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.x3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt)));
+    w.att3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt)));
+    w.hid3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)(2 * D), rpt)));
+    w.stats = reinterpret_cast<float*>(take(M * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
+    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt) * sizeof(unsigned)));
+    w.bytes = off;
+    return w;
+}
+
+bool stack_uses_x3(const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps, int n_tok, int D, int H) {
+    if (!x3_attention_fusable(n_tok, D, H) || !x3_shape_ok(D, 2 * D)) return false;
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        if (b.qkv_w16 || !(b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3)) return false;
+    }
+    return n_apps > 0;
+}
+
+// Block stack on split operands: per application LN1+qkv+attention | proj+residual | LN2+fc1+GELU | fc2+residual, the
+// activations handed from epilogue to k loop as A3 (x3 -> att3 -> x3 -> hid3 -> x3), x itself stays fp32 in place.
+int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
+                   int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int M = n_seq * n_tok, rpt = x3_rows_per_tile(n_tok);
+    const X3Ws w = carve_x3_ws(ws, (size_t)M, (size_t)D, rpt);
+    if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
+    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
+    int rc;
+    if ((rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
+    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, s))) return rc;
+    // bench-only A/B switch: MPL_X3_LAUNCHES=1 runs one launch per GEMM (the same phases, kernel boundaries in between)
+    static const bool per_gemm = getenv("MPL_X3_LAUNCHES") != nullptr;
+    if (!per_gemm) {
+        const unsigned short* ops[MPL_MAX_APPS * 4];
+        if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
+        for (int a = 0; a < n_apps; ++a) {
+            const mpl_block_weights& b = blocks[schedule[a]];
+            ops[4 * a + 0] = b.qkv_w3; ops[4 * a + 1] = b.proj_w3; ops[4 * a + 2] = b.fc1_w3; ops[4 * a + 3] = b.fc2_w3;
+        }
+        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, s);
+    }
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
+        if ((rc = launch_x3_qkv_attention(w.x3, b.qkv_w3, w.stats, eps, M, D, n_tok, H, w.att3, s))) return rc;
+        if ((rc = launch_x3_gemm(w.att3, b.proj_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, D, rpt,
+                                 MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+        // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
+        if ((rc = launch_x3_gemm(w.x3, b.fc1_w3, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid3, nullptr, M, 2 * D, D, rpt,
+                                 MPL_EPI_BIAS_GELU, s)))
+            return rc;
+        if ((rc = launch_x3_gemm(w.hid3, b.fc2_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, 2 * D, rpt,
+                                 MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+    }
+    return MPL_OK;
+}
+
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
                      const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!x || n_seq <= 0 || n_tok <= 0 || D <= 0 || H <= 0 || n_apps < 0) return MPL_E_INVALID;
@@ -71,6 +145,8 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
+    if (stack_uses_x3(blocks, schedule, n_apps, n_tok, D, H))
+        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, s);
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
@@ -85,42 +161,32 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     const bool fusable = qkv_attention_fusable(n_tok, D, H);
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        // bf16 matrix-core path for this block when the binding supplied bf16 weight copies; fp32-on-bf16-cores
-        // (split operands) when it supplied those
+            // bf16 matrix-core path for this block when the binding supplied bf16 weight copies (split operands take the
+        // block_stack_x3 route above)
         const bool bf = b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16;
-        const bool x3 = !bf && b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3;
-        if (x3 && (x3_operand_bytes(3 * D, D) == 0 || x3_operand_bytes(D, 2 * D) == 0 || D < 64)) return MPL_E_INVALID;
+        if (!bf && (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3)) return MPL_E_UNSUPPORTED;   // split operands this stack cannot use
         const bool fused_att = fusable && !bf;
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         if (fused_att) {
-            rc = x3 ? launch_x3_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w3, b.qkv_b, n_tok, H, w.att, s)
-                    : launch_ln_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, n_tok, H, w.att, s);
+            rc = launch_ln_qkv_attention(x, M, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, n_tok, H, w.att, s);
             if (rc) return rc;
         } else {
-            rc = x3 ? launch_x3_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w3, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                     3 * D, D, MPL_EPI_BIAS, nullptr, s)
-                    : launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                     3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr);
+            rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
+                                3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr);
             if (rc) return rc;
             if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
         }
-        rc = x3 ? launch_x3_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w3, b.proj_b, x, D, x, D, M, D, D,
-                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)
-                : launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
-                                 MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr);
+        rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
+                            MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr);
         if (rc) return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
         if (!st_out && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
-        rc = x3 ? launch_x3_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w3, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
-                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s)
-                : launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
-                                 2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr);
+        rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
+                            2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr);
         if (rc) return rc;
-        rc = x3 ? launch_x3_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w3, b.fc2_b, x, D, x, D, M, D, 2 * D,
-                                 MPL_EPI_BIAS_RESIDUAL, st_out, s)
-                : launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
-                                 2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr);
+        rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
+                            2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr);
         if (rc) return rc;
         have_stats = st_out != nullptr;
     }
@@ -130,6 +196,17 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
 // hipGetLastError() is per-thread state shared with the caller: a benign failure inside the caller's own HIP use (e.g.
 // torch probing a host pointer) would otherwise be reported by the first launch check of this library.
 inline void clear_stale_hip_error() { (void)hipGetLastError(); }
+
+// either engine may run the stack (the binding decides by the operands it supplies): size for the larger layout
+size_t stack_ws_bytes(size_t M, size_t D, int n_tok) {
+    size_t b = carve_stack_ws(nullptr, M, D).bytes;
+    const int rpt = x3_rows_per_tile(n_tok);
+    if (rpt > 0 && n_tok <= 32 && x3_shape_ok((int)D, (int)(2 * D))) {
+        const size_t b3 = carve_x3_ws(nullptr, M, D, rpt).bytes;
+        b = b3 > b ? b3 : b;
+    }
+    return b;
+}
 
 int check_cfg(const mpl_config* cfg) {
     if (!cfg) return MPL_E_INVALID;
@@ -187,7 +264,7 @@ int mpl_fpt_width(const mpl_config* cfg) {
 }
 
 size_t mpl_block_stack_workspace_bytes(int n_seq, int n_tok, int dim) {
-    return carve_stack_ws(nullptr, (size_t)n_seq * n_tok, (size_t)dim).bytes;
+    return stack_ws_bytes((size_t)n_seq * n_tok, (size_t)dim, n_tok);
 }
 
 size_t mpl_forward_workspace_bytes(const mpl_config* cfg, int batch) {
@@ -196,7 +273,7 @@ size_t mpl_forward_workspace_bytes(const mpl_config* cfg, int batch) {
     // joints x views token grid (:496-497): the same xs memory seen as (B, V*J, d)
     const bool kp = (cfg->flags & MPL_F_KPTOK) != 0;
     const size_t Ms = kp ? M * cfg->num_joints : M, Ds = kp ? (size_t)cfg->dim : D;
-    return align_up(M * D * sizeof(float), 256) + carve_stack_ws(nullptr, Ms, Ds).bytes;
+    return align_up(M * D * sizeof(float), 256) + stack_ws_bytes(Ms, Ds, kp ? cfg->num_views * cfg->num_joints : cfg->num_views);
 }
 
 int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, void* stream) {
@@ -231,28 +308,37 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
                           (timing && !ln_w) ? stats : nullptr, s);
 }
 
-size_t mpl_split_bf16x3_bytes(int N, int K) { return K >= 64 ? x3_operand_bytes(N, K) : 0; }
+size_t mpl_split_bf16x3_bytes(int N, int K) { return x3_operand_bytes(N, K); }
 
-int mpl_split_bf16x3(const float* W, int N, int K, uint16_t* dst, void* stream) {
-    clear_stale_hip_error();
-    if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
-    return launch_split_bf16x3(W, N, K, dst, (hipStream_t)stream);
-}
-
-int mpl_ln_linear_x3(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const uint16_t* W3,
-                     const float* bias, int N, int epilogue, const float* residual, float* y, float* stats,
+int mpl_split_bf16x3(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst,
                      void* stream) {
     clear_stale_hip_error();
-    if (!x || !W3 || !bias || !y || mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
+    if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
+    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
+}
+
+int mpl_x3_debug_buffer(void* device_buffer) {
+    x3_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
+    return MPL_OK;
+}
+
+size_t mpl_ln_linear_x3_workspace_bytes(int M, int K) { return x3_act_bytes(M, K, 64); }
+
+int mpl_ln_linear_x3(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
+                     const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    clear_stale_hip_error();
+    if (!x || !W3 || !y || mpl_split_bf16x3_bytes(N, K) == 0 || M <= 0) return MPL_E_INVALID;
+    const size_t need = x3_act_bytes(M, K, 64);
+    if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (ln_w) {
+    int rc;
+    if (has_ln) {
         if (!stats) return MPL_E_INVALID;
-        int rc = launch_row_stats(x, M, K, K, stats, s);
-        if (rc) return rc;
+        if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
     }
-    static const bool dbg = getenv("MPL_X3_DBG") != nullptr;   // bench-only: phase timings land in `stats`
-    return launch_x3_gemm(x, K, stats, ln_w, ln_b, eps, W3, bias, residual, N, y, N, M, N, K, epilogue,
-                          (dbg && !ln_w && epilogue == MPL_EPI_BIAS_RESIDUAL) ? stats : nullptr, s);
+    unsigned short* a3 = reinterpret_cast<unsigned short*>(workspace);
+    if ((rc = launch_split_rows(x, M, K, K, 64, a3, s))) return rc;
+    return launch_x3_gemm(a3, W3, has_ln != 0, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
 }
 
 int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {

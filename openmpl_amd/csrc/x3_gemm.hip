@@ -1,40 +1,46 @@
-// fp32 GEMM on the bf16 matrix cores by exact operand splitting ("fp32x3"):  C = epi( LN(A) . W^T + bias ).
+// fp32 GEMM on the bf16 matrix cores by exact operand splitting ("fp32x3"), engine v2:
+//     C = epi( LN(A) . W^T + bias )      with BOTH operands pre-split and in MFMA fragment order.
 //
-// Same reference ops and tile geometry as ln_gemm.hip (Block.norm1 + Attention.qkv :55, Attention.proj :65,
-// Block.norm2 + Mlp.fc1 + GELU :32-33, Mlp.fc2 :35 of MPL/lib/models/multiview_mpl.py), different arithmetic:
-// on gfx950 the bf16 matrix pipe is 16x faster than the fp32 one (2.5 PFLOP/s vs 157 TFLOP/s dense), so each
-// fp32 operand is written as the exact sum of three bf16 numbers
+// Reference ops (MPL/lib/models/multiview_mpl.py): Block.norm1 + Attention.qkv :55 + Attention.forward :55-64,
+// Attention.proj :65 + residual :90, Block.norm2 + Mlp.fc1 + GELU :32-33, Mlp.fc2 :35 + residual :91.
+//
+// Arithmetic (unchanged from v1).  On gfx950 the bf16 matrix pipe is 16x faster than the fp32 one, so each fp32
+// operand is the exact sum of three bf16 numbers
 //     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)     (3 x 8 = 24 mantissa bits)
-// and a product a.b is accumulated (fp32 accumulators, v_mfma_f32_16x16x32_bf16) from the six partial products
-// whose weight is >= 2^-16:  lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi.  The three dropped ones (mid.lo,
-// lo.mid, lo.lo) are <= 2^-24 relative -- below the rounding of an fp32 multiply; measured against an fp64
-// product the 6-term sum is 70x MORE accurate than an fp32 GEMM (7e-9 vs 5e-7 max-scaled at K = 544), so the
-// result is limited by the fp32 accumulation exactly like the native fp32 MFMA path.  6 bf16 MFMAs of 16x16x32
-// replace 8 fp32 MFMAs of 16x16x4 at 1/16 of the cycles each: 2.7x less matrix-pipe time per k-tile.
+// and a product is accumulated in fp32 (v_mfma_f32_16x16x32_bf16) from the six partial products of weight >= 2^-16,
+// in the fixed order  lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi  (A part . W part).  The dropped three are
+// <= 2^-24 relative -- below the rounding of an fp32 multiply.
 //
-// Operands: A stays fp32 in memory and LDS (LayerNorm is applied in fp32, then the fragment is split in registers:
-// ~6 VALU ops per element with v_cvt_pk_bf16_f32); W is split ONCE by the binding (launch_split_bf16x3) into
-// fragment order  W3[N/136 groups][K/32 k-tiles][9 column tiles][3 parts][64 lanes][8 bf16]  so that a k-tile of a
-// 136-column group is 27 contiguous 1-KiB DMA pieces and a B fragment is one conflict-free ds_read_b128 at
-// lane * 16.
+// What is new.  v1 kept A in fp32 and every wave normalised (LayerNorm) and split its A fragment inside the k loop:
+// ~50 VALU instructions per 54 MFMAs, gamma/beta traffic, and the same rows split again by every column-group
+// workgroup.  v2 removes all vector work from the k loop:
+//   * activations travel between the GEMMs of a block ALREADY SPLIT, in fragment order ("A3"): the epilogue that
+//     produces a row block writes its hi/mid/lo parts once (the MFMA is issued with swapped operands, so a lane owns 4
+//     consecutive columns of ONE row and two adjacent column tiles are exactly one consumer fragment: one 16-byte
+//     store per part, no cross-lane traffic);
+//   * LayerNorm is folded into the GEMM that follows it:
+//         LN(x) . W^T + b  =  rstd * ( x . (gamma o W)^T  -  mean * s )  +  c,
+//         s_n = sum_k gamma_k W_nk,   c_n = sum_k beta_k W_nk + b_n,
+//     gamma is multiplied into W when the binding splits the weights, mean / rstd come from the per-slice statistics
+//     the residual epilogues emit (as in v1) and are applied to the accumulator tile.  |mean| / sigma of a residual
+//     stream is O(0.1), so the cancellation in (acc - mean * s) costs nothing (measured: 5.0e-7 folded vs 5.5e-7
+//     unfolded against fp64 at the deepest LayerNorm of the bench model); it would cost a factor sqrt(1 + (mean /
+//     sigma)^2) for a badly centred stream.
+// The k loop is then: LDS-DMA of both operands (no VGPRs), ds_read_b128 fragments prefetched one stage ahead, MFMA.
 //
-// Workgroup = 64 rows x 136 columns, 8 waves: wave w owns row group w & 3 (16 rows) and column tiles 0..4
-// (w < 4) or 5..8 (w >= 4) -- waves w and w + 4 share a SIMD, which therefore sees 9 tiles = 54 MFMAs per k-tile
-// whatever the wave.  All 8 waves issue the LDS-DMA (4-6 pieces each per stage, counted vmcnt waits).  Stage =
-// one k-tile of 32: A 64 x 128 B (16-B columns XOR-swizzled with key (row >> 1) & 5: conflict free for the
-// two-b128-per-lane A fragment) | W 27 KiB | gamma, beta 1 KiB = 36 KiB; ring of NST stages (2: two workgroups
-// per CU; 3: one; 4: the attention variant, whose epilogue needs 117 KiB).
-// The k loop is software pipelined around a barrier in the MIDDLE of the iteration (see x3_body): MFMA batch 0 of
-// stage t | barrier | LayerNorm + split of the A fragment of stage t+1 interleaved with MFMA batch 1 of stage t.
-// NPASS = 3 (fused LN1 + qkv + attention): three accumulator sets for the q, k, v slices of the workgroup's 136
-// channels; the stages run k-tile by k-tile (q, k, v of k-tile 0, q, k, v of k-tile 1, ...) so that ONE A fragment
-// (LayerNorm + split) serves three stages, and the A tile is staged only with the q stage.  Afterwards the workgroup
-// finishes Attention.forward :55-64 exactly like ln_gemm_ng_kernel<ATT> (attention_on_tile).
-// Special values: an operand is reproduced exactly unless |x| > 3.389e38 (bf16(x) overflows) or its low parts fall
-// below the bf16 normal range (|x| < ~1e-33 loses trailing bits) -- outside anything a LayerNorm-ed activation or a
-// trained weight takes; inf / nan propagate as nan, as inf - inf does in the residual.
-// The k order of every output element is fixed (k-tiles ascending, six products in the order above), so results do
-// not depend on the batch size or launch geometry.
+// Layouts (K = 136 G columns, G a multiple of 4: 544, 1088, 2176; KT = K / 32 k-tiles):
+//   k-tile t < 4G ("full"):  group g = t / 4, quarter p = t % 4; lane (i, kq) element j  <->  column
+//                            136 g + 32 p + 16 (j / 4) + 4 kq + (j % 4)
+//   k-tile t = 4G + u ("tail", the 8 last columns of groups 4u .. 4u+3):  lane (i, kq) element j  <->  column
+//                            136 (4u + kq) + 128 + j
+//   A3[row tile][4 row groups][KT][3 parts][64 lanes][8 bf16]   lane = 16 kq + i, i = row in the 16-row group
+//       row tile T holds rows T*rpt .. T*rpt + rpt-1 (rpt <= 64 rows per tile; rows >= rpt of a tile are padding)
+//   W3[N/136][KT][9 slots][3 parts][64 lanes][8 bf16]           lane = 16 kq + i, i = column in the 16-column tile;
+//       slot s holds column tile {0,1,2,3,8,4,5,6,7}[s]: waves 0..3 own slots 0..4 (two tile pairs + the half tile),
+//       waves 4..7 slots 5..8 (two pairs); followed by the fold vectors c[N], s[N] (fp32)
+// Workgroup = one row tile x 136 columns (x NPASS column groups), 8 waves: wave w owns row group w & 3 and slots
+// 0..4 (w < 4) or 5..8: every SIMD sees 9 tiles = 54 MFMAs per k-tile.  Stage = A3 12 KiB + W3 27 KiB, ring of 4.
+// The k order of every output element is fixed, so results do not depend on batch size or launch geometry.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -44,25 +50,38 @@
 namespace mpl {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int X3_W = 27 * 1024;             // W bytes per k-tile of a 136-column group
-constexpr int X3_GB = SUB_A + X3_W;         // gamma/beta piece
-constexpr int X3_STAGE = X3_GB + 1024;      // 36864
-constexpr int X3_T0 = 5;                    // column tiles of waves 0..3; waves 4..7 take the other NT - 5
-// Run the second wave of every SIMD half a stage out of phase (see `stage` in x3_body).  Measured on MI355X at
-// M = 4096, D = 544: 444-446 k poses/s with, 450-455 k without -- the phases do not overlap better, the lagging wave
-// just holds more registers across the barrier.  Kept for experiments, off in the product build.
-constexpr bool X3_DEPHASE = false;
-#ifndef X3_LEAD
-#define X3_LEAD 2
-#endif
-#ifndef X3_B1_EARLY
-#define X3_B1_EARLY 0   // 1: fetch the second B batch of stage t+1 at the end of stage t -- measured -10 % (the reads hit the WAR
-                        // hazard on registers the batch-1 MFMAs still read and cannot slip under the next batch-0 MFMAs)
-#endif
+constexpr int X3_RG = 3 * 1024;              // A3 bytes per (row group, k-tile)
+constexpr int X3_A = 4 * X3_RG;              // A3 bytes per stage (64 rows)
+constexpr int X3_W = 27 * 1024;              // W3 bytes per k-tile of a 136-column group
+constexpr int X3_STAGE = X3_A + X3_W;        // 39936
+constexpr int X3_NST = 4;                    // ring depth (159744 B of LDS, one workgroup per CU)
+constexpr int X3_T0 = 5;                     // slots of waves 0..3; waves 4..7 take the other 4
 
-// 8 fp32 -> hi / mid / lo bf16x8 (round to nearest even at every step; the residuals are exact in fp32).  Written
-// stage by stage over the 8 elements so that the four packed chains interleave instead of stalling on each other.
+__host__ __device__ constexpr int x3_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
+
+// column of element j of lane quarter kq in k-tile t (G = K / 136)
+__host__ __device__ inline int x3_col(int t, int kq, int j, int G) {
+    if (t < 4 * G) return 136 * (t >> 2) + 32 * (t & 3) + 16 * (j >> 2) + 4 * kq + (j & 3);
+    return 136 * (4 * (t - 4 * G) + kq) + 128 + j;
+}
+
+bool x3_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 * BN) == 0; }
+
+size_t x3_operand_bytes(int N, int K) {
+    if (!x3_shape_ok(N, K)) return 0;
+    return (size_t)(N / BN) * (K / BK) * X3_W + (size_t)2 * N * sizeof(float);
+}
+
+size_t x3_act_bytes(int M, int K, int rpt) {
+    if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
+    const size_t tiles = ((size_t)M + rpt - 1) / rpt;
+    return tiles * 4 * (K / BK) * X3_RG;
+}
+
+// 8 fp32 -> hi / mid / lo packed bf16 (RNE at every step; the residuals are exact in fp32)
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
     float r[8], r2[8];
 #pragma unroll
@@ -77,74 +96,716 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& 
     for (int i = 0; i < 8; ++i) lo[i] = (__bf16)r2[i];
 }
 
-size_t x3_operand_bytes(int N, int K) {
-    if (N <= 0 || K <= 0 || N % BN || K % BK) return 0;
-    return (size_t)(N / BN) * (K / BK) * X3_W;
-}
-
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ W, int N, int K,
-                                                            bf16x8* __restrict__ dst, size_t total) {
-    const int KT = K / BK;
+// ---------------------------------------------------------------------------------------------- weight operand
+__global__ __launch_bounds__(256) void split_w3_kernel(const float* __restrict__ W, const float* __restrict__ gamma, int N,
+                                                        int K, bf16x8* __restrict__ dst, size_t total) {
+    const int KT = K / BK, G = K / BN;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int lane = (int)(idx & 63);
-        const int tile = (int)((idx >> 6) % NT);
+        const int slot = (int)((idx >> 6) % NT);
         const int kt = (int)((idx / (64 * NT)) % KT);
         const int g = (int)(idx / ((size_t)64 * NT * KT));
         const int li = lane & 15, kq = lane >> 4;
-        const int c = tile * 16 + li;
+        const int c = x3_slot_tile(slot) * 16 + li;
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = 0.f;
-        if (c < BN) {
-            const float* src = W + (size_t)(g * BN + c) * K + kt * BK + 8 * kq;
-            const float4 p = ld4(src), q = ld4(src + 4);
-            x[0] = p.x; x[1] = p.y; x[2] = p.z; x[3] = p.w; x[4] = q.x; x[5] = q.y; x[6] = q.z; x[7] = q.w;
+        for (int j = 0; j < 8; ++j) {
+            x[j] = 0.f;
+            if (c < BN) {
+                const int k = x3_col(kt, kq, j, G);
+                const float w = W[(size_t)(g * BN + c) * K + k];
+                x[j] = gamma ? w * gamma[k] : w;           // LayerNorm gain folded into the weight (one fp32 rounding)
+            }
         }
         bf16x8 hi, mid, lo;
         split3(x, hi, mid, lo);
-        bf16x8* o = dst + ((size_t)(g * KT + kt) * 27 + tile * 3) * 64 + lane;
+        bf16x8* o = dst + ((size_t)(g * KT + kt) * 27 + slot * 3) * 64 + lane;
         o[0] = hi;
         o[64] = mid;
         o[128] = lo;
     }
 }
 
-int launch_split_bf16x3(const float* W, int N, int K, unsigned short* dst, hipStream_t s) {
-    if (!W || !dst || x3_operand_bytes(N, K) == 0) return MPL_E_INVALID;
+// fold vectors: c_n = bias_n + sum_k beta_k W_nk,  s_n = sum_k fl32(gamma_k W_nk)  (fp64 sums, one wave per n)
+__global__ __launch_bounds__(256) void fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ bias,
+                                                            int N, int K, float* __restrict__ cvec, float* __restrict__ svec) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double s = 0.0, c = 0.0;
+    if (gamma) {
+        for (int k = lane; k < K; k += 64) {
+            const float w = W[(size_t)n * K + k];
+            s += (double)(w * gamma[k]);
+            c += (double)w * (double)beta[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            c += __shfl_xor(c, o, 64);
+        }
+    }
+    if (lane == 0) {
+        cvec[n] = (float)(c + (double)bias[n]);
+        svec[n] = (float)s;
+    }
+}
+
+int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
+                        unsigned short* dst, hipStream_t s) {
+    if (!W || !dst || !bias || !x3_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr))) return MPL_E_INVALID;
     const size_t total = (size_t)(N / BN) * (K / BK) * NT * 64;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid), dim3(256), 0, s, W, N, K, reinterpret_cast<bf16x8*>(dst), total);
+    hipLaunchKernelGGL(split_w3_kernel, dim3(grid), dim3(256), 0, s, W, ln_w, N, K, reinterpret_cast<bf16x8*>(dst), total);
+    float* vec = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * (K / BK) * X3_W);
+    hipLaunchKernelGGL(fold_vectors_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, vec, vec + N);
     return hip_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------- activation operand
+// fp32 rows -> A3 (used for the rows that enter a block stack from outside: the SPT output, the unit-test entry)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int M, int K, int ldx, int rpt,
+                                                          bf16x8* __restrict__ dst, size_t total) {
+    const int KT = K / BK, G = K / BN;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        const int kt = (int)((idx >> 6) % KT);
+        const size_t rgi = idx / ((size_t)64 * KT);          // tile * 4 + row group
+        const int li = lane & 15, kq = lane >> 4;
+        const int rl = (int)(rgi & 3) * 16 + li;
+        const size_t row = (rgi >> 2) * rpt + rl;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = 0.f;
+        if (rl < rpt && row < (size_t)M) {
+            const float* src = X + row * ldx;
+            const int c0 = x3_col(kt, kq, 0, G), c4 = x3_col(kt, kq, 4, G);
+            const float4 p = ld4(src + c0), q = ld4(src + c4);
+            x[0] = p.x; x[1] = p.y; x[2] = p.z; x[3] = p.w; x[4] = q.x; x[5] = q.y; x[6] = q.z; x[7] = q.w;
+        }
+        bf16x8 hi, mid, lo;
+        split3(x, hi, mid, lo);
+        bf16x8* o = dst + (rgi * KT + kt) * 3 * 64 + lane;
+        o[0] = hi;
+        o[64] = mid;
+        o[128] = lo;
+    }
+}
+
+int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, hipStream_t s) {
+    if (!X || !dst || x3_act_bytes(M, K, rpt) == 0 || (ldx & 3)) return MPL_E_INVALID;
+    const size_t tiles = ((size_t)M + rpt - 1) / rpt;
+    const size_t total = tiles * 4 * (K / BK) * 64;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<bf16x8*>(dst), total);
+    return hip_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM
 struct X3Args {
-    const float* A;
-    int lda;
-    const float* stats;
-    const float* ln_w;
-    const float* ln_b;
-    const char* W3;
-    const float* bias;
-    const float* R;
+    const char* A3;          // split activations, K columns
+    const char* W3;          // split weights (gamma folded for LNF)
+    const float* cvec;       // bias (or folded c) per output column
+    const float* svec;       // LNF: s per output column
+    const float* stats;      // LNF: per-row slice partials of the K-wide input rows
+    const float* R;          // residual (fp32), EPI_BIAS_RESIDUAL
     int ldr;
-    float* C;
+    float* C;                // fp32 output (optional)
     int ldc;
-    int M, N, K;
+    char* C3;                // A3 output (optional): the next GEMM's operand
+    float* stats_out;        // residual epilogue: slice partials of the rows produced
+    int M, N, K, rpt;
     int grid_m, grid_n;
     float eps;
-    float* stats_out;
     int att_ntok, att_hd;
-    float* att_out;
-    int abl;                                     // bench-only ablation mask (MPL_X3_ABL): 1 no ring refill
+    unsigned long long* dbg;   // bench-only (mpl_x3_debug_buffer): per-wave s_memtime stamps, else NULL
 };
 
-// Everything a compute wave does, for its NTW column tiles starting at tile `tile0`.
-template <int EPI, bool LN, int NPASS, int NST, int NTW, bool LAG, bool DBG = false>
-__device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, int wave, int tile0) {
-    const unsigned long long t_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
+static std::atomic<unsigned long long*> g_x3_dbg{nullptr};
+void x3_set_debug_buffer(unsigned long long* p) { g_x3_dbg.store(p); }
+
+enum { X3_EPI_BIAS = 0, X3_EPI_GELU = 1, X3_EPI_RES = 2, X3_EPI_ATT = 3 };
+
+constexpr int X3_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the attention epilogue
+
+// ---- stores / loads of data that crosses workgroups INSIDE a launch (chain mode, see x3_stack_kernel): write-through
+// (sc0 sc1) stores and L1-bypassing (sc1) loads on both sides -- a valid hand-off for ANY placement of the workgroups
+// (MI355X_MICROARCH.md, "Valid forms").  Kernel boundaries make plain accesses sufficient in the one-GEMM launches.
+template <bool WT>
+__device__ __forceinline__ void st16(void* p, const bf16x8& v) {
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    else *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <bool WT>
+__device__ __forceinline__ void st8(void* p, const bf16x8& v) {      // the 4 low bf16 of a fragment
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    const u32x2 h = {w[0], w[1]};
+    if (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(h) : "memory");
+    else *reinterpret_cast<u32x2*>(p) = h;
+}
+template <bool WT>
+__device__ __forceinline__ void st_f2(float* p, float x, float y) {
+    const u32x2 h = {__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)};
+    if (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(h) : "memory");
+    else *reinterpret_cast<u32x2*>(p) = h;
+}
+
+// Attention.forward :55-64 on the q | k | v tile T[64][X3_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
+// channels: S whole sequences of nt tokens (rows S*nt.. are padding); output written as A3 of width Dq for proj.
+template <bool WT>
+__device__ __forceinline__ void x3_attention(float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
+                                             int g_out, int Dq) {
+    const int hd4 = hd >> 2;
+    const int HP = BN / hd, nn = nt * nt;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int t = tid; t < S * HP * nn; t += 512) {
+        const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
+        const float* q = T + (sq * nt + i) * X3_ATT_TS + hh * hd;
+        const float* k = T + (sq * nt + j) * X3_ATT_TS + BN + hh * hd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int e = 0; e < hd4; ++e) {
+            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+            s0 = fmaf(a.x, b.x, s0);
+            s1 = fmaf(a.y, b.y, s1);
+            s2 = fmaf(a.z, b.z, s2);
+            s3 = fmaf(a.w, b.w, s3);
+        }
+        SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
+    }
+    __syncthreads();
+    for (int t = tid; t < S * HP * nt; t += 512) {
+        float* pr = SC + t * nt;
+        float mx = pr[0];
+        for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
+        float l = 0.f;
+        for (int j = 0; j < nt; ++j) {
+            const float e = __expf(pr[j] - mx);
+            pr[j] = e;
+            l += e;
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < nt; ++j) pr[j] *= inv;
+    }
+    __syncthreads();
+    // P.V and the A3 fragments of the output rows: task = (row, quarter p, lane quarter kq) -> 8 values = the two
+    // 4-column chunks 32p + 4kq and 32p + 16 + 4kq; tail tasks (row, kq < 2) -> 4 values at 128 + 4kq
+    const int KTo = Dq / BK, Go = Dq / BN;
+    auto pv4 = [&](int row, int c) -> float4 {
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+        if (row < S * nt) {
+            const int sq = row / nt, i = row - sq * nt;
+            const int hh = c / hd;
+            const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
+            const float* v = T + (sq * nt) * X3_ATT_TS + 2 * BN + c;
+            for (int j = 0; j < nt; ++j) {
+                const float4 vv = ld4(v + j * X3_ATT_TS);
+                const float pj = pr[j];
+                o.x = fmaf(pj, vv.x, o.x);
+                o.y = fmaf(pj, vv.y, o.y);
+                o.z = fmaf(pj, vv.z, o.z);
+                o.w = fmaf(pj, vv.w, o.w);
+            }
+        }
+        return o;
+    };
+    for (int t = tid; t < BM * 16; t += 512) {
+        const int li = t & 15, kq = (t >> 4) & 3, rg = (t >> 6) & 3, p = t >> 8;
+        const int row = rg * 16 + li;
+        const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8 hi, mid, lo;
+        split3(x, hi, mid, lo);
+        char* o = C3 + (((size_t)tile_m * 4 + rg) * KTo + (4 * g_out + p)) * X3_RG + (kq * 16 + li) * 16;
+        st16<WT>(o, hi);
+        st16<WT>(o + 1024, mid);
+        st16<WT>(o + 2048, lo);
+    }
+    for (int t = tid; t < BM * 2; t += 512) {
+        const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
+        const int row = rg * 16 + li;
+        const float4 a = pv4(row, 128 + 4 * kq);
+        const float x[8] = {a.x, a.y, a.z, a.w, 0.f, 0.f, 0.f, 0.f};
+        bf16x8 hi, mid, lo;
+        split3(x, hi, mid, lo);
+        char* o = C3 + (((size_t)tile_m * 4 + rg) * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8;
+        st8<WT>(o, hi);
+        st8<WT>(o + 1024, mid);
+        st8<WT>(o + 2048, lo);
+    }
+}
+
+// One GEMM of one workgroup tile (tm, tn): everything a wave does for its NTW slots starting at slot `slot0`.
+// CHAIN = false: the GEMM is a launch of its own.  CHAIN = true: it is one phase of x3_stack_kernel -- the workgroups
+// (tm, 0 .. G-1) of a row tile advance together through the GEMMs of the whole block stack; `chain` counts their
+// arrivals, the A operand of this phase may be read once it reaches `chain_need`, and this workgroup arrives when its
+// outputs are written.  The W operand does not depend on the other workgroups: its first stages are requested BEFORE
+// the wait.
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
+__device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
+                                         unsigned* chain, unsigned chain_need) {
+    constexpr int NST = X3_NST;
+    constexpr bool HAS_A = NTW == X3_T0;         // waves 0..3 (slots 0..4) bring the A pieces
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
+    const int M = a.M, N = a.N, K = a.K;
+    // NPASS = 2: two ADJACENT 136-column groups (tn counts pairs); NPASS = 3: the q, k, v slices of one group
+    const int m0 = tm * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
+    const int Dq = N / 3;
+    const int KT = K / BK;
+    const int T = NPASS * KT;
+    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
+    const unsigned long long t_entry = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+
+    // ---- DMA slots of this wave.  A3: waves 0..3 bring the 3 KiB of row group `wave`; W3: waves 4..7 pieces 4(w-4)..+3,
+    // waves 0..2 pieces 16+3w..+2, wave 3 pieces 25, 26.  Source and destination of a run are contiguous: one M0 write.
+    const int w_first = wave >= 4 ? 4 * (wave - 4) : 16 + 3 * wave;
+    const int w_cnt = wave >= 4 ? 4 : (wave == 3 ? 2 : 3);
+    unsigned voA = (unsigned)(lane * 16), voW = (unsigned)(lane * 16 + w_first * 1024);
+    asm volatile("" : "+v"(voA), "+v"(voW));
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // running state of the next W / A stage to request (stage u carries W of pass u % NPASS, and A when that pass is 0)
+    int iw_t = 0, iw_g = 0, ia_t = 0;
+    unsigned iw_slot = 0, ia_slot = 0;
+    const char* is_w[NPASS];
+#pragma unroll
+    for (int g = 0; g < NPASS; ++g) is_w[g] = a.W3 + (size_t)(colbase(g) / BN) * KT * X3_W;
+    const char* is_a = a.A3 + ((size_t)tm * 4 + (wave & 3)) * KT * X3_RG;
+    auto issue_w = [&]() {
+        const unsigned st = lds0 + iw_slot;
+        const unsigned keep = dma_m0_save();
+#pragma unroll
+        for (int g = 0; g < NPASS; ++g)
+            if (g == iw_g) {
+                asm volatile(
+                    "s_mov_b32 m0, %2\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %0, %1\n\t"
+                    "global_load_lds_dwordx4 %0, %1 offset:1024"
+                    :
+                    : "v"(voW), "s"(is_w[g]), "s"(st + (unsigned)(X3_A + w_first * 1024))
+                    : "memory");
+                if (w_cnt > 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(is_w[g]) : "memory");
+                if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(is_w[g]) : "memory");
+                is_w[g] += X3_W;
+            }
+        if (++iw_g == NPASS) iw_g = 0;
+        dma_m0_restore(keep);
+        ++iw_t;
+        iw_slot += X3_STAGE;
+        if (iw_slot == NST * X3_STAGE) iw_slot = 0;
+    };
+    // A of stage ia_t (a no-op for the stages of passes 1, 2); in chain mode the operand was written by other
+    // workgroups of this launch: L1-bypassing loads
+    auto issue_a = [&]() {
+        if ((ia_t % NPASS) == 0) {
+            if (HAS_A) {
+                const unsigned keep = dma_m0_save();
+                if (CHAIN)
+                    asm volatile(
+                        "s_mov_b32 m0, %2\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %0, %1 sc1\n\t"
+                        "global_load_lds_dwordx4 %0, %1 offset:1024 sc1\n\t"
+                        "global_load_lds_dwordx4 %0, %1 offset:2048 sc1"
+                        :
+                        : "v"(voA), "s"(is_a), "s"(lds0 + ia_slot + (unsigned)(wave * X3_RG))
+                        : "memory");
+                else
+                    asm volatile(
+                        "s_mov_b32 m0, %2\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %0, %1\n\t"
+                        "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                        "global_load_lds_dwordx4 %0, %1 offset:2048"
+                        :
+                        : "v"(voA), "s"(is_a), "s"(lds0 + ia_slot + (unsigned)(wave * X3_RG))
+                        : "memory");
+                dma_m0_restore(keep);
+            }
+            is_a += X3_RG;
+        }
+        ++ia_t;
+        ia_slot += X3_STAGE;
+        if (ia_slot == NST * X3_STAGE) ia_slot = 0;
+    };
+    // ---- prologue: the first NST stages.  W first (chain mode: before the wait for the other workgroups), then A.
+    // In-order queue of this wave after the prologue:  W(0) .. W(NST-1)  A(0) [A(k) of the later pass-0 stages].
+#pragma unroll
+    for (int t = 0; t < NST; ++t)
+        if (t < T) issue_w();
+    if (CHAIN) {
+        if (tid == 0) {
+            // one lane polls (relaxed, L2-bypassing); bounded so that a lost partner cannot hang the GPU: after ~2 s the
+            // workgroup goes on with whatever is there and the result fails the parity tests instead
+            for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+                if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NST; ++t)
+        if (t < T) issue_a();
+
+    const int row_l = rg * 16 + li;
+    const bool row_ok = row_l < a.rpt && m0 + row_l < M;
+    const int row = row_ok ? m0 + row_l : (M - 1);
+    const int ns = K / BN;                       // LNF: slices of the K-wide row (4 or 8)
+    float4 st_raw[4];
+    float4 rv[NTW];
+    // epilogue operands that do not depend on the accumulators (LayerNorm partials of this lane's row, residual):
+    // requested a few stages before the end of the k loop, consumed after it
+    auto epilogue_operands = [&]() {
+        if (LNF) {
+            const float* sp = a.stats + (size_t)row * ns * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (2 * i < ns) {
+                    if (CHAIN) {   // written by the other workgroups of the team in this launch: L1-bypassing loads
+                        st_raw[i].x = __hip_atomic_load(sp + 4 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st_raw[i].y = __hip_atomic_load(sp + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st_raw[i].z = __hip_atomic_load(sp + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st_raw[i].w = __hip_atomic_load(sp + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        st_raw[i] = ld4(sp + 4 * i);
+                    }
+                } else {
+                    st_raw[i] = float4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (EPI == X3_EPI_RES) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                int c = 16 * x3_slot_tile(slot0 + n) + 4 * kq;
+                c = c + 3 < BN ? c : 0;
+                rv[n] = ld4(a.R + (size_t)row * a.ldr + n0 + c);    // private to this workgroup (it wrote them itself)
+            }
+        }
+    };
+    const int t_ops = T >= 8 ? T - 5 : 0;
+
+    f32x4 acc[NPASS][NTW];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment registers, ping-pong: the reads of stage t+1 are issued among the MFMAs of stage t
+    bf16x8 A0[3], A1[3];
+    bf16x8 B0[NTW][3], B1[NTW][3];
+    auto read_a = [&](unsigned slot, bf16x8 (&f)[3]) {
+        const bf16x8* as = reinterpret_cast<const bf16x8*>(smem + slot + rg * X3_RG) + lane;
+        f[0] = as[0];
+        f[1] = as[64];
+        f[2] = as[128];
+    };
+    auto read_b = [&](unsigned slot, bf16x8 (&f)[NTW][3]) {
+        const bf16x8* bs = reinterpret_cast<const bf16x8*>(smem + slot + X3_A) + slot0 * 3 * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            f[n][0] = bs[(n * 3 + 0) * 64];
+            f[n][1] = bs[(n * 3 + 1) * 64];
+            f[n][2] = bs[(n * 3 + 2) * 64];
+        }
+    };
+    auto slot_after = [](unsigned sl) -> unsigned { return sl + X3_STAGE == NST * X3_STAGE ? 0u : sl + X3_STAGE; };
+    // Six products, fixed order (A part . W part): lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, each over the wave's
+    // NTW tiles (an accumulator is touched every NTW MFMAs).  The W fragment is the FIRST MFMA operand: lane (i, kq) then
+    // holds C[row i][4 consecutive columns 16 tile + 4 kq ..] (transposed tile).
+    // The fragment reads of stage t+1 are spread between the product rows of stage t (3 ds_read_b128 per row): issued
+    // as one burst right after the barrier, the 18 reads of a wave overflow the 15-deep LDS queue and the wave sits in
+    // the burst -- with its SIMD partner, which is in the same phase -- while the matrix pipe idles.
+    auto mfma_row = [&](f32x4 (&accp)[NTW], const bf16x8& af, const bf16x8 (&bf)[NTW][3], int bp) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n][bp], af, accp[n], 0, 0, 0);
+    };
+    {   // stage 0 landed for everyone: the wave's queue is W(0..3) A(0) A(later): everything up to A(0) must be in
+        constexpr int A_LATER = NPASS == 1 ? 3 : (NPASS == 2 ? 1 : 1);   // pass-0 stages among stages 1..3
+        if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * A_LATER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12) : "memory");            // W(1..3), four pieces each
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_a(0, A0);
+        read_b(0, B0);
+    }
+    const unsigned long long t_loop = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_vm = 0, t_bar = 0;      // bench-only: cycles at the counted DMA wait / at lgkmcnt + barrier
+    unsigned slot_c = 0;
+    // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage
+    // t with the fragment reads of stage t+1 in between
+    auto stage = [&](int t, f32x4 (&accp)[NTW], const bf16x8 (&a_cur)[3], bf16x8 (&a_nxt)[3], const bf16x8 (&b_cur)[NTW][3],
+                     bf16x8 (&b_nxt)[NTW][3], bool next_has_a) {
+        const unsigned slot_n = slot_after(slot_c);
+        const bool more = t + 1 < T;
+        unsigned long long w0 = 0, w1 = 0;
+        if (a.dbg) w0 = __builtin_amdgcn_s_memtime();
+        if (more) {
+            // own pieces of stage t+1 landed (stages t+2, t+3 may stay in flight); every fragment read of stage t has
+            // returned: the barrier must not be passed before, the slot of stage t is refilled right after it.
+            // The wait is an immediate, counted with the SMALLEST number of pieces any wave of the role has per stage
+            // (conservative: a wave with more pieces then also waits for part of stage t+2, requested two stage times
+            // ago).  After the W-first prologue the queue of an A-carrying wave ends with A(0) A(later): stage 1 of a
+            // one-pass GEMM is complete once at most A(2), A(3) are outstanding.
+            constexpr int MINP = NPASS == 1 ? (HAS_A ? 5 : 4) : (HAS_A ? 2 : 4);
+            static_assert(NST == 4, "the counted waits assume three stages in flight");
+            if (NPASS == 1 && HAS_A && t == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // A(2) A(3)
+            else if (NPASS == 1 && HAS_A && t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A(3) W(4) A(4)
+            else if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
+            else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
+        }
+        const bf16x8* bs = reinterpret_cast<const bf16x8*>(smem + slot_n + X3_A) + slot0 * 3 * 64 + lane;
+        auto rd_b = [&](int n) {
+            if (more && n < NTW) {
+                b_nxt[n][0] = bs[(n * 3 + 0) * 64];
+                b_nxt[n][1] = bs[(n * 3 + 1) * 64];
+                b_nxt[n][2] = bs[(n * 3 + 2) * 64];
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[2], b_cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && iw_t < T) {                      // stage t+NST into the slot of stage t
+            issue_w();
+            issue_a();
+        }
+        if (t == t_ops) epilogue_operands();
+        if (more && next_has_a) read_a(slot_n, a_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[0], b_cur, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(0);
+        if (!next_has_a) rd_b(4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[1], b_cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[1], b_cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[0], b_cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(3);
+        if (next_has_a) rd_b(4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[0], b_cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_c = slot_n;
+    };
+    if constexpr (NPASS == 1) {
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(kt, acc[0], A0, A1, B0, B1, true);
+            stage(kt + 1, acc[0], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) stage(kt, acc[0], A0, A1, B0, B1, true);
+    } else if constexpr (NPASS == 2) {
+        // two column groups share the A fragment of the k-tile; the second stage prefetches the next k-tile's.  The A
+        // ping-pong alternates per k-tile; two stages per k-tile keep the B parity the same in every k-tile.
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) {
+            stage(2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+        }
+    } else {
+        // k-tile by k-tile: q, k, v stages share the A fragment; three stages per k-tile flip the B parity every k-tile
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            stage(3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) {
+            stage(3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ epilogue
+    const unsigned long long t_epi = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    float mu = 0.f, rs = 1.f;
+    if (LNF) {
+        float st[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            st[4 * i] = st_raw[i].x; st[4 * i + 1] = st_raw[i].y; st[4 * i + 2] = st_raw[i].z; st[4 * i + 3] = st_raw[i].w;
+        }
+        // Chan's combination of the per-slice {mean, M2} partials (gemm_common.hpp ln_combine, from registers)
+        float msum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) msum += (i < ns) ? st[2 * i] : 0.f;
+        const float mean = msum / (float)ns;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = st[2 * i] - mean;
+            m2 += (i < ns) ? st[2 * i + 1] + (float)BN * d * d : 0.f;
+        }
+        mu = mean;
+        rs = 1.0f / sqrtf(m2 / (float)K + a.eps);
+    }
+    // acc[p][n][r] = C[row_l][colbase(p) + 16 tile(n) + 4 kq + r]
+    auto tile_of = [&](int n) -> int { return x3_slot_tile(slot0 + n); };
+    auto value4 = [&](int p, int n, float (&v)[4]) {
+        const int cl = 16 * tile_of(n) + 4 * kq;
+        const bool ok = cl + 3 < BN;
+        const int cg = colbase(p) + (ok ? cl : 0);
+        const float4 cv = ld4(a.cvec + cg);
+        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (LNF) {
+            const float4 sv = ld4(a.svec + cg);
+            s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = acc[p][n][r];
+            if (LNF) t = rs * (t - mu * s4[r]);
+            t += c4[r];
+            if (EPI == X3_EPI_GELU) t = gelu_erf(t);
+            v[r] = ok ? t : 0.f;
+        }
+    };
+    unsigned long long t_st = 0;
+
+    if constexpr (EPI == X3_EPI_ATT) {
+        float* Tt = reinterpret_cast<float*>(smem);
+        float* SC = Tt + BM * X3_ATT_TS;
+        __syncthreads();                        // every wave is done reading the last stage
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int cl = 16 * tile_of(n) + 4 * kq;
+                if (cl + 3 < BN) {
+                    float v[4];
+                    value4(p, n, v);
+                    st4(Tt + row_l * X3_ATT_TS + p * BN + cl, float4{v[0], v[1], v[2], v[3]});
+                }
+            }
+        __syncthreads();
+        x3_attention<CHAIN>(Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+    } else {
+        const int KTo = N / BK, Go = N / BN;
+        float vals[NTW][4];
+#pragma unroll
+        for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
+            const int g_out = colbase(p) / BN;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                value4(p, n, vals[n]);
+                const int cl = 16 * tile_of(n) + 4 * kq;
+                const bool ok = cl + 3 < BN;
+                if (EPI == X3_EPI_RES) {
+                    vals[n][0] += rv[n].x; vals[n][1] += rv[n].y; vals[n][2] += rv[n].z; vals[n][3] += rv[n].w;
+                    if (!ok) vals[n][0] = vals[n][1] = vals[n][2] = vals[n][3] = 0.f;
+                }
+                if (a.C && ok && row_ok)
+                    st4(a.C + (size_t)row * a.ldc + colbase(p) + cl, float4{vals[n][0], vals[n][1], vals[n][2], vals[n][3]});
+            }
+            if (a.C3) {
+                // two adjacent column tiles = one fragment of the consumer: slots (0,1) (2,3) of each half
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float x[8] = {vals[2 * q][0], vals[2 * q][1], vals[2 * q][2], vals[2 * q][3],
+                                        vals[2 * q + 1][0], vals[2 * q + 1][1], vals[2 * q + 1][2], vals[2 * q + 1][3]};
+                    bf16x8 hi, mid, lo;
+                    split3(x, hi, mid, lo);
+                    const int pq = (slot0 ? 2 : 0) + q;
+                    char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * g_out + pq)) * X3_RG + lane * 16;
+                    st16<CHAIN>(o, hi);
+                    st16<CHAIN>(o + 1024, mid);
+                    st16<CHAIN>(o + 2048, lo);
+                }
+                if (NTW == X3_T0 && kq < 2) {     // the half tile: 4 values per lane into the shared tail k-tile
+                    const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
+                    bf16x8 hi, mid, lo;
+                    split3(x, hi, mid, lo);
+                    char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8;
+                    st8<CHAIN>(o, hi);
+                    st8<CHAIN>(o + 1024, mid);
+                    st8<CHAIN>(o + 2048, lo);
+                }
+            }
+        }
+        if (a.dbg) t_st = __builtin_amdgcn_s_memtime();
+        if constexpr (EPI == X3_EPI_RES) {
+            if (a.stats_out) {
+                // LayerNorm partials {mean, M2} of the 136-column slice of each row: a row's values sit in the 4 kq lanes
+                // of BOTH waves of a SIMD pair (w, w+4): two exchanges through LDS (sum, then centred squares), each
+                // combined in the fixed order (half 0) + (half 1)
+                float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][64 rows]
+                const int half = slot0 ? 1 : 0;
+                float sum = 0.f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) sum += (vals[n][0] + vals[n][1]) + (vals[n][2] + vals[n][3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                __syncthreads();                    // every wave is done with the ring
+                if (kq == 0) xch[half * 64 + row_l] = sum;
+                __syncthreads();
+                const float mean = (xch[row_l] + xch[64 + row_l]) * (1.0f / (float)BN);
+                float q = 0.f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    const bool ok = 16 * tile_of(n) + 4 * kq + 3 < BN;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = vals[n][r] - mean;
+                        q = ok ? fmaf(d, d, q) : q;
+                    }
+                }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (kq == 0) xch[128 + half * 64 + row_l] = q;
+                __syncthreads();
+                if (half == 0 && kq == 0 && row_ok)
+                    st_f2<CHAIN>(a.stats_out + ((size_t)row * Go + n0 / BN) * 2, mean, xch[128 + row_l] + xch[192 + row_l]);
+            }
+        }
+    }
+    if (CHAIN) {
+        // arrive: every store of this workgroup has been acknowledged (write-through), nobody touches the ring any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.dbg) {   // bench-only: entry, loop start, loop end, stores issued, stores drained (shader clock), wait sums
+        if (!t_st) t_st = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
+            o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar;
+        }
+    }
+}
+
+template <int EPI, bool LNF, int NPASS>
+__global__ __launch_bounds__(512, 2) void x3_gemm_kernel(const X3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tm, tn;
     {
         const int b = blockIdx.x;
@@ -158,523 +819,219 @@ __device__ __forceinline__ void x3_body(const X3Args& a, char* smem, int tid, in
             tn = b / a.grid_m;
         }
     }
-    const int M = a.M, N = a.N, K = a.K;
-    // NPASS = 2: the workgroup owns two ADJACENT 136-column groups (tn counts pairs); NPASS = 3: the q, k, v slices
-    const int m0 = tm * BM, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
-    const int Dq = N / 3;                        // NPASS == 3: width of each of q, k, v
-    const int KT = K / BK;
-    const int T = NPASS * KT;                    // stages
-    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
-
-    // ---- DMA slots of this wave: A piece `wave` (8 rows); a run of ADJACENT W pieces (waves 0..2: four starting at
-    // 4 w, waves 3..7: three starting at 3 w + 3) -- source and destination are both contiguous, so one M0 write
-    // serves the run and the pieces differ only by the instruction's immediate offset; gamma/beta from wave 7.
-    unsigned voA;
-    {
-        const int r = wave * 8 + (lane >> 3);
-        int m = m0 + r;
-        m = m < M ? m : M - 1;
-        voA = (unsigned)(((size_t)(m - m0) * a.lda + 4 * ((lane & 7) ^ ((r >> 1) & 5))) * sizeof(float));
-        asm volatile("" : "+v"(voA));
-    }
-    const bool w_four = wave < 3;
-    const int w_first = w_four ? 4 * wave : 3 * wave + 3;
-    unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
-    asm volatile("" : "+v"(voW));
-    const float* gb_src = ((lane & 8) ? a.ln_b : a.ln_w) + 4 * (lane & 7);
-    const bool gb_on = LN && wave == 7;
-    // every wave issues at least this many pieces per stage (A + 3 W; the q|k|v instance stages A only with q)
-    constexpr int MIN_PIECES = NPASS == 1 ? 4 : 3;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // Running state of the NEXT stage to issue (stages are issued strictly in order).  NPASS = 3 interleaves the
-    // three column groups k-tile by k-tile: stage t = 3 kt + g carries W of group g (q, k, v) for k-tile kt, and the
-    // A tile + gamma/beta of k-tile kt ride along with g = 0 only.
-    int is_t = 0, is_kt = 0, is_g = 0;
-    unsigned is_slot = 0;                        // byte offset of its ring slot
-    const char* is_w[NPASS];
-#pragma unroll
-    for (int g = 0; g < NPASS; ++g) is_w[g] = a.W3 + (size_t)(colbase(g) / BN) * KT * X3_W;
-    const float* is_a = a.A + (size_t)m0 * a.lda;   // tile row base in the 64-bit DMA base: per-lane offsets are tile relative
-    auto issue_w = [&](const char* wsrc, unsigned st) {
-        asm volatile(
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %0, %1\n\t"
-            "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-            "global_load_lds_dwordx4 %0, %1 offset:2048"
-            :
-            : "v"(voW), "s"(wsrc), "s"(st + (unsigned)(SUB_A + w_first * 1024))
-            : "memory");
-        if (w_four) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(wsrc) : "memory");
-    };
-    auto issue_next = [&]() {
-        const unsigned st = lds0 + is_slot;
-        const unsigned keep = dma_m0_save();
-        if (NPASS == 1) {
-            dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
-            issue_w(is_w[0], st);
-            if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
-            is_w[0] += X3_W;
-            is_a += BK;
-            ++is_kt;
-        } else {
-            if (is_g == 0) {
-                dma16_fast(voA, is_a, st + (unsigned)(wave * 1024));
-                if (gb_on) dma16(gb_src + is_kt * BK, st + (unsigned)X3_GB);
-                is_a += BK;
-            }
-#pragma unroll
-            for (int g = 0; g < NPASS; ++g)
-                if (g == is_g) { issue_w(is_w[g], st); is_w[g] += X3_W; }
-            if (++is_g == NPASS) { is_g = 0; ++is_kt; }
-        }
-        dma_m0_restore(keep);
-        ++is_t;
-        is_slot += X3_STAGE;
-        if (is_slot == NST * X3_STAGE) is_slot = 0;
-    };
-#pragma unroll
-    for (int t = 0; t < NST; ++t)
-        if (t < T) issue_next();
-
-    // LayerNorm statistics of this lane's row: loaded AFTER the first stages are in flight, so that the two cold
-    // latencies (statistics from the previous kernel's epilogue, first k-tiles) overlap instead of adding up
-    float mu = 0.f, rs = 1.f;
-    if (LN) {
-        int m = m0 + rg * 16 + li;
-        m = m < M ? m : M - 1;
-        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
-        ln_combine(a.stats + (size_t)m * ns * 2, ns, sl, K, a.eps, mu, rs);
-        asm volatile("" : "+v"(mu), "+v"(rs));   // consume the loads before the k loop (see ln_gemm.hip)
-    }
-
-
-    f32x4 acc[NPASS][NTW];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float rv[NTW][4];
-    const int row0 = m0 + rg * 16 + 4 * kq;
-    const int t_res = T >= 4 ? T - 4 : 0;        // residual prefetch: ~4 stages (~3 us) ahead of the epilogue
-    const int key = (li >> 1) & 5;
-    constexpr int NB0 = (NTW + 1) / 2, NB1 = NTW - NB0;   // column tiles of the two B batches (3+2 or 2+2)
-
-    // Software pipeline.  The barrier sits in the MIDDLE of an iteration: by then a wave has read everything of
-    // stage t into registers, so the barrier both frees slot t % NST for the DMA of stage t + NST and publishes
-    // stage t + 1, whose A fragment (LayerNorm + 3-way split: ~50 VALU ops) is prepared while the matrix pipe works
-    // on the second B batch of stage t (sched_group_barrier: one MFMA, then four VALU ops, repeated).  The last
-    // iteration prepares a stage that does not exist (stale LDS, results unused): no special cases in the body.
-    bf16x8 A0[3], A1[3];                         // split A fragment (hi, mid, lo): current / next, ping-pong
-    bf16x8 b0h[NB0], b0m[NB0], b0l[NB0];         // B batch 0 of the current stage
-    bf16x8 b1h[NB1], b1m[NB1], b1l[NB1];         // B batch 1 (LAG waves keep it across the barrier)
-    auto read_a = [&](unsigned slot, float (&x)[8], float (&gg)[8], float (&ee)[8]) {
-        const char* st = smem + slot;
-        // A fragment of 16x16x32: lane (i, kq) holds A[i][8 kq .. 8 kq + 7] = logical 16-B columns 2kq, 2kq+1
-        const float* as = reinterpret_cast<const float*>(st) + (rg * 16 + li) * BK;
-        const float4 a0 = ld4(as + (((2 * kq) ^ key) << 2)), a1 = ld4(as + (((2 * kq + 1) ^ key) << 2));
-        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
-        if (LN) {
-            const float* gb = reinterpret_cast<const float*>(st + X3_GB);
-            const float4 g0 = ld4(gb + 8 * kq), g1 = ld4(gb + 8 * kq + 4), e0 = ld4(gb + 32 + 8 * kq), e1 = ld4(gb + 36 + 8 * kq);
-            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-            ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
-        }
-    };
-    auto norm_split = [&](float (&x)[8], const float (&gg)[8], const float (&ee)[8], bf16x8 (&o)[3]) {
-        if (LN) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = (x[i] - mu) * rs * gg[i] + ee[i];
-        }
-        split3(x, o[0], o[1], o[2]);
-    };
-    auto b_base = [&](unsigned slot) -> const bf16x8* {
-        return reinterpret_cast<const bf16x8*>(smem + slot + SUB_A) + tile0 * 3 * 64 + lane;
-    };
-    auto read_b0 = [&](unsigned slot) {
-        const bf16x8* bs = b_base(slot);
-#pragma unroll
-        for (int n = 0; n < NB0; ++n) { b0h[n] = bs[(n * 3 + 0) * 64]; b0m[n] = bs[(n * 3 + 1) * 64]; b0l[n] = bs[(n * 3 + 2) * 64]; }
-    };
-    auto read_b1 = [&](unsigned slot) {
-        const bf16x8* bs = b_base(slot) + NB0 * 3 * 64;
-#pragma unroll
-        for (int n = 0; n < NB1; ++n) { b1h[n] = bs[(n * 3 + 0) * 64]; b1m[n] = bs[(n * 3 + 1) * 64]; b1l[n] = bs[(n * 3 + 2) * 64]; }
-    };
-    {   // prologue: stage 0 landed for everyone
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        float x[8], gg[8], ee[8];
-        read_a(0, x, gg, ee);
-        read_b0(0);
-        if (LAG || X3_B1_EARLY) read_b1(0);
-        norm_split(x, gg, ee, A0);
-    }
-    unsigned slot_c = 0;                         // ring slot (byte offset) of the current stage
-    auto slot_after = [](unsigned sl) -> unsigned { return sl + X3_STAGE == NST * X3_STAGE ? 0u : sl + X3_STAGE; };
-#define MPL_X3(AP, BP, NN, OFF)                   \
-    _Pragma("unroll") for (int n = 0; n < NN; ++n) \
-        accp[OFF + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AP, BP[n], accp[OFF + n], 0, 0, 0);
-    // one stage: MFMAs of stage t from `cur`, split fragment of stage t + 1 into `nxt`
-    unsigned long long dbg[5] = {0, 0, 0, 0, 0};
-    const unsigned long long t_loop = DBG ? __builtin_amdgcn_s_memtime() : 0;
-    auto now = [] {
-        const unsigned long long v = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        return v;
-    };
-    // With X3_DEPHASE the two waves of a SIMD run the stage in different orders so that one is in its MFMA-only
-    // batch while the other interleaves MFMAs with the VALU-heavy split:
-    //   waves 0..3 (LAG = false):  batch 0 of stage t | barrier t | split(t+1) x batch 1 of stage t
-    //   waves 4..7 (LAG = true):   barrier t | batch 0 of stage t | split(t+1) x batch 1 of stage t | B reads of t+1
-    // (a LAG wave holds both B batches of a stage in registers across the barrier that frees the stage's slot).
-    // SPLIT (std::true_type / false_type): whether this stage prepares a new A fragment for the next one (always for
-    // NPASS = 1; only the last of the three q|k|v stages of a k-tile for NPASS = 3, which share one fragment)
-    auto stage = [&](auto split_c, int t, f32x4 (&accp)[NTW], const bf16x8 (&cur)[3], bf16x8 (&nxt)[3]) {
-        constexpr bool do_split = decltype(split_c)::value;
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        if (DBG) s0 = now();
-        const unsigned slot_n = slot_after(slot_c);
-        auto batch0 = [&]() {
-            MPL_X3(cur[2], b0h, NB0, 0)
-            __builtin_amdgcn_sched_barrier(0);
-            // refill the slot the last barrier freed under the matrix pipe's shadow: the batch-0 MFMAs have no
-            // VALU work to pair with, the DMA issue is scalar + 4..6 VMEM instructions
-            if ((LAG || t >= 1) && is_t < T && !(a.abl & 1)) issue_next();
-            __builtin_amdgcn_sched_barrier(0);
-            MPL_X3(cur[0], b0l, NB0, 0)
-            MPL_X3(cur[1], b0m, NB0, 0)
-            MPL_X3(cur[1], b0h, NB0, 0)
-            MPL_X3(cur[0], b0m, NB0, 0)
-            MPL_X3(cur[0], b0h, NB0, 0)
-        };
-        auto sync = [&]() {
-            // own pieces of stage t+1 landed: with a full ring, NST-2 later stages (>= MIN_PIECES pieces each) may
-            // stay in flight; near the end (and for NST = 2) simply drain.  Every read of stage t has returned.
-            if (NST > 2 && t + NST - 1 < T) wait_vm((NST - 2) * MIN_PIECES);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (DBG) s2 = now();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (DBG) s3 = now();
-        };
-        if (!LAG) {
-            if (!X3_B1_EARLY) read_b1(slot_c);
-            batch0();
-            if (DBG) s1 = now();
-            sync();
-        } else {
-            sync();
-            batch0();
-            if (DBG) s1 = now();
-        }
-        if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res)
-            load_residual_w<NTW>(rv, a.R, a.ldr, M, N, row0, n0 + tile0 * 16, li);
-        float x[8], gg[8], ee[8];
-        read_a(slot_n, x, gg, ee);
-        // LayerNorm variants fetch their next B batch only after the split (measured: fetching it up front costs 5 % on the
-        // fused attention instance even where registers are plentiful -- the A fragment then queues behind 9 more reads)
-        constexpr bool B0_EARLY = !LAG && !LN;
-        if (B0_EARLY) read_b0(slot_n);
-        // Hand-interleaved: the 6 * NB1 MFMAs of batch 1 alternate with the split of the next A fragment, one MFMA
-        // (16 cycles of matrix pipe) per ~4 VALU ops; sched_barrier(0) pins the order hipcc would otherwise undo
-        // (it groups all VALU first and lets the wave sit on the ds_read latency with the matrix pipe idle).
-        unsigned wh[4], wm[4], wl[4];            // packed bf16 pairs of the next fragment
-        float r0[4], r1[4];
-        constexpr int NM = 6 * NB1;              // MFMAs to place
-        int mi = 0;
-        auto mfma_next = [&]() {                 // the mi-th MFMA of batch 1 in the canonical product order
-            if (mi < NM) {
-                const int prod = mi / NB1, n = mi % NB1;
-                const bf16x8& ap = cur[prod == 0 ? 2 : (prod == 2 || prod == 3) ? 1 : 0];
-                const bf16x8& bp = (prod == 0 || prod == 3 || prod == 5) ? b1h[n] : (prod == 1) ? b1l[n] : b1m[n];
-                accp[NB0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap, bp, accp[NB0 + n], 0, 0, 0);
-                ++mi;
-            }
-        };
-        auto pack = [](float lo_, float hi_) -> unsigned {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            const bf16x2 v = {(__bf16)lo_, (__bf16)hi_};
-            return __builtin_bit_cast(unsigned, v);
-        };
-        auto lo_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w << 16); };
-        auto hi_f = [](unsigned w) -> float { return __builtin_bit_cast(float, w & 0xffff0000u); };
-        if constexpr (do_split) {
-            // X3_LEAD MFMAs ahead of the first VALU group cover the latency of the A fragment reads just issued
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < X3_LEAD; ++k) mfma_next();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {            // hi part + first residual of pair j
-                float x0 = x[2 * j], x1 = x[2 * j + 1];
-                if (LN) {
-                    x0 = (x0 - mu) * rs * gg[2 * j] + ee[2 * j];
-                    x1 = (x1 - mu) * rs * gg[2 * j + 1] + ee[2 * j + 1];
-                }
-                wh[j] = pack(x0, x1);
-                r0[j] = x0 - lo_f(wh[j]);
-                r1[j] = x1 - hi_f(wh[j]);
-                mfma_next();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {            // mid part + second residual
-                wm[j] = pack(r0[j], r1[j]);
-                r0[j] -= lo_f(wm[j]);
-                r1[j] -= hi_f(wm[j]);
-                mfma_next();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {         // lo part
-                wl[j] = pack(r0[j], r1[j]);
-                wl[j + 1] = pack(r0[j + 1], r1[j + 1]);
-                mfma_next();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int k = 0; k < NM; ++k) mfma_next();   // whatever is left (mi is a compile-time value here)
-            __builtin_amdgcn_sched_barrier(0);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            nxt[0] = __builtin_bit_cast(bf16x8, (u32x4){wh[0], wh[1], wh[2], wh[3]});
-            nxt[1] = __builtin_bit_cast(bf16x8, (u32x4){wm[0], wm[1], wm[2], wm[3]});
-            nxt[2] = __builtin_bit_cast(bf16x8, (u32x4){wl[0], wl[1], wl[2], wl[3]});
-        } else {
-#pragma unroll
-            for (int k = 0; k < NM; ++k) mfma_next();
-        }
-        // LayerNorm variants keep gamma/beta live above: their next B batch is fetched only now (128-register budget)
-        if (!B0_EARLY) read_b0(slot_n);
-        if (LAG || X3_B1_EARLY) read_b1(slot_n);
-        slot_c = slot_n;
-        if (DBG) {
-            const unsigned long long s4 = now();
-            if (!LAG) { dbg[0] += s1 - s0; dbg[1] += s2 - s1; dbg[2] += s3 - s2; dbg[3] += s4 - s3; }
-            else { dbg[0] += s1 - s3; dbg[1] += s2 - s0; dbg[2] += s3 - s2; dbg[3] += s4 - s1; }
-            dbg[4] += 1;
-        }
-    };
-    constexpr std::true_type SPLIT{};
-    constexpr std::false_type KEEP{};
-    if constexpr (NPASS == 1) {
-        int kt = 0;
-        for (; kt + 1 < KT; kt += 2) {
-            stage(SPLIT, kt, acc[0], A0, A1);
-            stage(SPLIT, kt + 1, acc[0], A1, A0);
-        }
-        if (kt < KT) stage(SPLIT, kt, acc[0], A0, A1);
-    } else if constexpr (NPASS == 2) {
-        // two column groups per k-tile share one fragment; the second stage prepares the next one
-        int kt = 0;
-        for (; kt + 1 < KT; kt += 2) {
-            stage(KEEP, 2 * kt, acc[0], A0, A0);
-            stage(SPLIT, 2 * kt + 1, acc[1], A0, A1);
-            stage(KEEP, 2 * kt + 2, acc[0], A1, A1);
-            stage(SPLIT, 2 * kt + 3, acc[1], A1, A0);
-        }
-        if (kt < KT) {
-            stage(KEEP, 2 * kt, acc[0], A0, A0);
-            stage(SPLIT, 2 * kt + 1, acc[1], A0, A1);
-        }
-    } else {
-        // k-tile by k-tile: q, k, v stages share the fragment of the k-tile; the v stage prepares the next one
-        int kt = 0;
-        for (; kt + 1 < KT; kt += 2) {
-            stage(KEEP, 3 * kt, acc[0], A0, A0);
-            stage(KEEP, 3 * kt + 1, acc[1], A0, A0);
-            stage(SPLIT, 3 * kt + 2, acc[2], A0, A1);
-            stage(KEEP, 3 * kt + 3, acc[0], A1, A1);
-            stage(KEEP, 3 * kt + 4, acc[1], A1, A1);
-            stage(SPLIT, 3 * kt + 5, acc[2], A1, A0);
-        }
-        if (kt < KT) {
-            stage(KEEP, 3 * kt, acc[0], A0, A0);
-            stage(KEEP, 3 * kt + 1, acc[1], A0, A0);
-            stage(SPLIT, 3 * kt + 2, acc[2], A0, A1);
-        }
-    }
-#undef MPL_X3
-
-    const unsigned long long t_epi = DBG ? now() : 0;
-    if constexpr (NPASS == 3) {
-        // ---- fused attention epilogue.  T[64][412]: q | k | v (+bias) of this workgroup's 136 channels.
-        float* Tt = reinterpret_cast<float*>(smem);
-        float* SC = Tt + BM * ATT_TS;
-        __syncthreads();                        // every wave is done reading the last stage
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int cb = colbase(p);
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const int c = (tile0 + n) * 16 + li;
-                if (c < BN) {
-                    const float bv = a.bias[cb + c];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Tt[(rg * 16 + 4 * kq + r) * ATT_TS + p * BN + c] = acc[p][n][r] + bv;
-                }
-            }
-        }
-        attention_on_tile(Tt, SC, tid, 512, a.att_ntok, a.att_hd, a.att_out, m0, n0, M, Dq);
-        return;
-    }
-
-    float v[NTW][4];
-    if constexpr (NPASS == 2) {   // two plain (bias / GELU) tiles side by side; no residual, no statistics
-        tile_values_store<EPI, NTW>(acc[0], a.bias, rv, a.C, a.ldc, M, N, row0, n0, n0 + tile0 * 16, li, v);
-        tile_values_store<EPI, NTW>(acc[1], a.bias, rv, a.C, a.ldc, M, N, row0, n0 + BN, n0 + BN + tile0 * 16, li, v);
-        return;
-    }
-    tile_values_store<EPI, NTW>(acc[0], a.bias, rv, a.C, a.ldc, M, N, row0, n0, n0 + tile0 * 16, li, v);
-    const unsigned long long t_st = DBG ? now() : 0;
-    if (EPI == MPL_EPI_BIAS_RESIDUAL && a.stats_out) {
-        // LayerNorm partials of the 136-column slice: the second half hands its final values to the first through
-        // the stage slot nobody reads any more (stage T-2: every wave passed barrier T-1), and the first half
-        // reduces all 9 tiles in the order of the fp32 kernels' epilogue
-        constexpr int NT1 = NT - X3_T0;
-        float4* xfer = reinterpret_cast<float4*>(smem + ((T - 2) % NST) * X3_STAGE);
-        if (tile0) {
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) xfer[(rg * NT1 + n) * 64 + lane] = float4{v[n][0], v[n][1], v[n][2], v[n][3]};
-        }
-        __syncthreads();
-        if (!tile0) {
-            float vv[NT][4];
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[n][r] = v[n][r];
-#pragma unroll
-            for (int n = 0; n < NT1; ++n) {
-                const float4 q = xfer[(rg * NT1 + n) * 64 + lane];
-                vv[X3_T0 + n][0] = q.x; vv[X3_T0 + n][1] = q.y; vv[X3_T0 + n][2] = q.z; vv[X3_T0 + n][3] = q.w;
-            }
-            slice_stats_store(vv, a.stats_out, N / BN, M, row0, n0, li);
-        }
-    }
-    if (DBG) {   // bench-only: per-wave phase cycles into the (otherwise unused) att_out pointer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = now();
-        if (lane == 0) {
-            float* o = a.att_out + (size_t)(blockIdx.x * 8 + wave) * 16;
-            for (int i = 0; i < 5; ++i) o[i] = (float)dbg[i];
-            o[5] = (float)(t_loop - t_entry);
-            o[6] = (float)(t_epi - t_loop);
-            o[7] = (float)(t_st - t_epi);
-            o[8] = (float)(t_end - t_st);
-        }
-    }
+    if (wave < 4) x3_phase<EPI, LNF, NPASS, X3_T0, false>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else x3_phase<EPI, LNF, NPASS, NT - X3_T0, false>(a, smem, tid, wave, X3_T0, tm, tn, nullptr, 0u);
 }
 
-template <int EPI, bool LN, int NPASS, int NST, bool DBG = false>
-__global__ __launch_bounds__(512, (NPASS == 1 && EPI != MPL_EPI_BIAS_RESIDUAL) ? 4 : 2) void x3_gemm_kernel(const X3Args a) {
+// ---------------------------------------------------------------------------------------------- whole block stack
+// ONE launch for all Block applications of a stack.  The GEMM chain of a block only couples the workgroups of one ROW
+// TILE: proj of row tile tm needs the attention output of the G = D/136 workgroups (tm, 0..G-1) and nothing else, and so
+// on down the stack.  So G workgroups form a team that walks one row tile through every GEMM of every block
+// application, synchronising only among themselves (a monotonic arrival counter per row tile); teams never wait for
+// each other and drift apart, which spreads the operand-fetch and store bursts that a grid of lock-stepped one-GEMM
+// launches concentrates at its start and end -- and the weight stages of the next GEMM are requested before the wait.
+// All teams are resident at once (one workgroup per CU, grid <= CU count): nobody waits for a workgroup that has not
+// started.  With more row tiles than teams a team takes several tiles one after the other.
+struct X3StackArgs {
+    char *x3, *att3, *hid3;
+    float *x, *stats;
+    unsigned* counters;          // one per row tile, zeroed before the launch
+    int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps;
+    float eps;
+    unsigned long long* dbg;
+    const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
+};
+
+__global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave < 4) x3_body<EPI, LN, NPASS, NST, X3_T0, false, DBG>(a, smem, tid, wave, 0);
-    else x3_body<EPI, LN, NPASS, NST, NT - X3_T0, X3_DEPHASE, DBG>(a, smem, tid, wave, X3_T0);
+    const int G = s.G, D = s.D;
+    int team, tn;
+    {
+        const int b = blockIdx.x;
+        if ((s.n_teams & 7) == 0) {   // blocks b, b+8, .. share an XCD: keep a team inside one (speed only, never needed)
+            team = (b & 7) + 8 * ((b >> 3) / G);
+            tn = (b >> 3) % G;
+        } else {
+            team = b / G;
+            tn = b % G;
+        }
+    }
+    auto vecs = [&](const char* w3, int N, int K) -> const float* {
+        return reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
+    };
+    // One loop over the 4 * n_apps GEMM phases of a row tile.  Every phase starts from OPAQUE copies of the thread id and
+    // the tile index: nothing derived from them is loop invariant, so the compiler does not keep the address arithmetic
+    // of all eight phase bodies alive across the loop (which spilled ~200 VGPRs).
+    for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
+        unsigned need = 0;           // arrivals that complete the phase whose output the next phase reads
+        for (int ph = 0; ph < 4 * s.n_apps; ++ph, need += G) {
+            int tidp = tid, tile = tile0, tnp = tn;
+            asm volatile("" : "+v"(tidp));
+            asm volatile("" : "+s"(tile), "+s"(tnp));
+            const int wv = __builtin_amdgcn_readfirstlane(tidp >> 6);
+            unsigned* ctr = s.counters + tile;
+            const char* const* w = s.w[ph >> 2];
+            switch (ph & 3) {
+                case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
+                    const float* v = vecs(w[0], 3 * D, D);
+                    const X3Args a{s.x3, w[0], v, v + 3 * D, s.stats, nullptr, 0, nullptr, 0, s.att3, nullptr, s.M, 3 * D, D, s.rpt,
+                                   s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg};
+                    if (wv < 4) x3_phase<X3_EPI_ATT, true, 3, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    break;
+                }
+                case 1: {
+                    const float* v = vecs(w[1], D, D);
+                    const X3Args a{s.att3, w[1], v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, D, s.rpt,
+                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
+                    if (wv < 4) x3_phase<X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    break;
+                }
+                case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
+                    const float* v = vecs(w[2], 2 * D, D);
+                    const X3Args a{s.x3, w[2], v, v + 2 * D, s.stats, nullptr, 0, nullptr, 0, s.hid3, nullptr, s.M, 2 * D, D, s.rpt,
+                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
+                    if (wv < 4) x3_phase<X3_EPI_GELU, true, 2, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    break;
+                }
+                default: {
+                    const float* v = vecs(w[3], D, 2 * D);
+                    const X3Args a{s.hid3, w[3], v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, 2 * D, s.rpt,
+                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
+                    if (wv < 4) x3_phase<X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    break;
+                }
+            }
+        }
+    }
 }
 
-static int x3_abl() {
-    static const int v = getenv("MPL_X3_ABL") ? atoi(getenv("MPL_X3_ABL")) : 0;
-    return v;
-}
-
-template <int EPI, bool LN, int NPASS, int NST>
+template <int EPI, bool LNF, int NPASS>
 static int launch_x3(const X3Args& a, hipStream_t s) {
-    constexpr int LDS = NST * X3_STAGE;
+    constexpr int LDS = X3_NST * X3_STAGE;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
-    static_assert(NPASS != 3 || (BM * ATT_TS + ATT_SCORE_FLOATS) * 4 <= LDS, "attention epilogue does not fit in the ring");
-    static_assert(NPASS != 2 || EPI != MPL_EPI_BIAS_RESIDUAL, "the paired instance has no residual epilogue");
     static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)x3_gemm_kernel<EPI, LN, NPASS, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)x3_gemm_kernel<EPI, LNF, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess)
             return MPL_E_LAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((x3_gemm_kernel<EPI, LN, NPASS, NST>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((x3_gemm_kernel<EPI, LNF, NPASS>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);
     return hip_check_launch();
 }
 
-template <int EPI, bool LN>
-static int launch_x3_auto(const X3Args& a, hipStream_t s) {
-    // two workgroups per CU (2-stage rings) once there are more workgroups than CUs, else one with a deeper ring.  The
-    // residual instances hold their prefetched residual + LayerNorm hand-over in ~190 registers, so only one of them
-    // fits a CU whatever the ring: always the deeper one.
-    static const int force = getenv("MPL_X3_NST") ? atoi(getenv("MPL_X3_NST")) : 0;   // bench-only
-    const int wgs = a.grid_m * a.grid_n;
-    int nst = (wgs > 256 && EPI != MPL_EPI_BIAS_RESIDUAL) ? 2 : 3;
-    if (force) nst = force;
-    static const bool dbg = getenv("MPL_X3_DBG") != nullptr;   // bench-only phase timing into stats_out
-    if (dbg && EPI == MPL_EPI_BIAS_RESIDUAL && !LN && a.stats_out) {
-        X3Args b = a;
-        b.att_out = a.stats_out;      // timing dump
-        b.stats_out = nullptr;
-        ProfScope prof(MPL_K_GEMM, s);
-        hipFuncSetAttribute((const void*)x3_gemm_kernel<MPL_EPI_BIAS_RESIDUAL, false, 1, 3, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X3_STAGE);
-        hipLaunchKernelGGL((x3_gemm_kernel<MPL_EPI_BIAS_RESIDUAL, false, 1, 3, true>), dim3(a.grid_m * a.grid_n), dim3(512),
-                           3 * X3_STAGE, s, b);
-        return hip_check_launch();
-    }
-    // More 136-column tiles than CUs (LN2 + fc1 + GELU, the unfused qkv): give each workgroup two adjacent column
-    // groups instead -- one LayerNorm + split of the A fragment then serves two stages, at one workgroup per CU with a
-    // 4-stage ring.  Measured on MI355X: fc1 at M = 4096, D = 544 39.4 -> 37.4 us, FULL flag set (D = 1088) +2.4 %.
-    // Same k order per output element: bitwise identical results (tools/x3_pair_check.py).
-    static const bool nopair = getenv("MPL_X3_NOPAIR") != nullptr;   // bench-only A/B switch
-    if constexpr (EPI != MPL_EPI_BIAS_RESIDUAL) {
-        if (!nopair && !force && (a.grid_n & 1) == 0 && wgs > 256) {
-            X3Args b = a;
-            b.grid_n = a.grid_n / 2;
-            return launch_x3<EPI, LN, 2, 4>(b, s);
-        }
-    }
-    switch (nst) {
-        case 2: return launch_x3<EPI, LN, 1, 2>(a, s);
-        case 4: return launch_x3<EPI, LN, 1, 4>(a, s);
-        default: return launch_x3<EPI, LN, 1, 3>(a, s);
-    }
-}
-
-int launch_x3_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
-                   const unsigned short* W3, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
-                   int K, int epi, float* stats_out, hipStream_t s) {
-    if (M <= 0 || !A || !W3 || !bias || !C || (lda & 3) || x3_operand_bytes(N, K) == 0 || K < 2 * BK) return MPL_E_INVALID;
-    const bool ln = ln_w != nullptr;
-    if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
+// C (fp32, optional) and / or C3 (A3 of width N, optional) = epi( LN?(A) . W^T + bias ) from split operands.
+// ln: the weight operand was built with LayerNorm folded (launch_split_bf16x3 with ln_w) and `stats` holds the slice
+// partials of the K-wide rows behind A3.  rpt = rows per row tile of A3 (and of C3).
+int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
+                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi,
+                   hipStream_t s) {
+    if (M <= 0 || !A3 || !W3 || (!C && !C3) || !x3_shape_ok(N, K) || rpt <= 0 || rpt > BM) return MPL_E_INVALID;
+    if (ln && !stats) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
     if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
-    X3Args a{A, lda, stats, ln_w, ln_b, reinterpret_cast<const char*>(W3), bias, R, ldr, C, ldc, M, N, K,
-             (M + BM - 1) / BM, N / BN, eps, stats_out, 0, 0, nullptr, x3_abl()};
-#define MPL_X3_CASE(E) \
-    case E:            \
-        return ln ? launch_x3_auto<E, true>(a, s) : launch_x3_auto<E, false>(a, s);
+    if (C3 && N % (4 * BN)) return MPL_E_INVALID;           // an A3 output must itself be a valid operand width
+    const char* w3 = reinterpret_cast<const char*>(W3);
+    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
+    X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, R, ldr, C, ldc, reinterpret_cast<char*>(C3), stats_out,
+             M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load()};
+    const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0 && a.grid_m * a.grid_n > 256;
+    if (pair) a.grid_n /= 2;
     switch (epi) {
-        MPL_X3_CASE(MPL_EPI_BIAS)
-        MPL_X3_CASE(MPL_EPI_BIAS_GELU)
-        MPL_X3_CASE(MPL_EPI_BIAS_RESIDUAL)
+        case MPL_EPI_BIAS:
+            if (pair) return ln ? launch_x3<X3_EPI_BIAS, true, 2>(a, s) : launch_x3<X3_EPI_BIAS, false, 2>(a, s);
+            return ln ? launch_x3<X3_EPI_BIAS, true, 1>(a, s) : launch_x3<X3_EPI_BIAS, false, 1>(a, s);
+        case MPL_EPI_BIAS_GELU:
+            if (pair) return ln ? launch_x3<X3_EPI_GELU, true, 2>(a, s) : launch_x3<X3_EPI_GELU, false, 2>(a, s);
+            return ln ? launch_x3<X3_EPI_GELU, true, 1>(a, s) : launch_x3<X3_EPI_GELU, false, 1>(a, s);
+        case MPL_EPI_BIAS_RESIDUAL:
+            return ln ? launch_x3<X3_EPI_RES, true, 1>(a, s) : launch_x3<X3_EPI_RES, false, 1>(a, s);
         default:
             return MPL_E_INVALID;
     }
-#undef MPL_X3_CASE
 }
 
-// LN1 + qkv projection + softmax attention in one launch (see launch_ln_qkv_attention): att[M, D] from x[M, D]
-int launch_x3_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
-                            float eps, const unsigned short* W3, const float* bias, int n_tok, int heads, float* att,
-                            hipStream_t s) {
-    if (!qkv_attention_fusable(n_tok, D, heads) || !stats || !ln_w || !ln_b || !W3 || !bias || !att || M <= 0 ||
-        x3_operand_bytes(3 * D, D) == 0)
+// The whole block stack in one launch (see x3_stack_kernel).  `ops` = n_apps x {qkv, proj, fc1, fc2} split operands.
+int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
+                    unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
+                    hipStream_t s) {
+    if (!x || !ops || !x3 || !att3 || !hid3 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
+        !x3_attention_fusable(n_tok, D, heads) || !x3_shape_ok(D, 2 * D) || M % n_tok)
         return MPL_E_INVALID;
-    X3Args a{x, D, stats, ln_w, ln_b, reinterpret_cast<const char*>(W3), bias, nullptr, 0, nullptr, 0, M, 3 * D, D,
-             (M + BM - 1) / BM, D / BN, eps, nullptr, n_tok, D / heads, att, x3_abl()};
-    return launch_x3<MPL_EPI_BIAS, true, 3, 4>(a, s);
+    constexpr int LDS = X3_NST * X3_STAGE;
+    static std::atomic<bool> attr_set[64];
+    static std::atomic<int> resident[64];   // workgroups of this kernel the device holds at once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)x3_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MPL_E_LAUNCH;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)x3_stack_kernel, 512, LDS) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            return MPL_E_LAUNCH;
+        resident[dev].store(cus);            // the 156 KiB ring admits one workgroup per CU whatever the API answers
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    X3StackArgs a;
+    a.x3 = reinterpret_cast<char*>(x3);
+    a.att3 = reinterpret_cast<char*>(att3);
+    a.hid3 = reinterpret_cast<char*>(hid3);
+    a.x = x;
+    a.stats = stats;
+    a.counters = counters;
+    a.M = M; a.D = D; a.n_tok = n_tok; a.heads = heads;
+    a.rpt = x3_rows_per_tile(n_tok);
+    a.n_tiles = (M + a.rpt - 1) / a.rpt;
+    a.G = D / BN;
+    const int cap = resident[dev].load() / a.G;
+    if (cap < 1) return MPL_E_UNSUPPORTED;
+    a.n_teams = a.n_tiles < cap ? a.n_tiles : cap;
+    if (a.n_teams >= 8) a.n_teams &= ~7;    // whole XCD octets: a team then sits inside one XCD
+    a.n_apps = n_apps;
+    a.eps = eps;
+    a.dbg = g_x3_dbg.load();
+    for (int i = 0; i < n_apps; ++i)
+        for (int j = 0; j < 4; ++j) {
+            if (!ops[4 * i + j]) return MPL_E_INVALID;
+            a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
+        }
+    if (hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL(x3_stack_kernel, dim3(a.n_teams * a.G), dim3(512), LDS, s, a);
+    return hip_check_launch();
+}
+
+// rows per tile for the fused attention: whole sequences of n_tok tokens in at most 64 rows
+int x3_rows_per_tile(int n_tok) { return (n_tok >= 1 && n_tok <= BM) ? (BM / n_tok) * n_tok : 0; }
+
+bool x3_attention_fusable(int n_tok, int dim, int heads) {
+    if (n_tok < 1 || n_tok > 32 || heads <= 0 || dim % heads || !x3_shape_ok(3 * dim, dim)) return false;
+    const int hd = dim / heads;
+    if (BN % hd || (hd & 3)) return false;
+    const int S = BM / n_tok, HP = BN / hd;
+    return (size_t)(BM * X3_ATT_TS + S * HP * n_tok * n_tok) * sizeof(float) <= (size_t)X3_NST * X3_STAGE;
+}
+
+// LN1 + qkv projection + softmax attention in one launch: att3 (A3 of width D) from x3 (A3 of width D)
+int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
+                            int n_tok, int heads, unsigned short* att3, hipStream_t s) {
+    if (!x3_attention_fusable(n_tok, D, heads) || !A3 || !W3 || !stats || !att3 || M <= 0 || M % n_tok) return MPL_E_INVALID;
+    const int N = 3 * D, rpt = x3_rows_per_tile(n_tok);
+    const char* w3 = reinterpret_cast<const char*>(W3);
+    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (D / BK) * X3_W);
+    X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att3),
+             nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_x3_dbg.load()};
+    return launch_x3<X3_EPI_ATT, true, 3>(a, s);
 }
 
 }  // namespace mpl

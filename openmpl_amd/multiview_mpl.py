@@ -258,9 +258,10 @@ class MultiView_MPL(nn.Module):
         return self
 
     def _x3_supported(self) -> bool:
-        """The split-operand GEMMs need every FPT Linear shape to have a split layout (out features a multiple of 136,
-        in features of 32: widths 544 and 1088, i.e. every view-token model at DIM 32); mpl_split_bf16x3_bytes decides."""
-        if self.no_transformer_fpt or len(self.blocks) == 0:
+        """The split-operand engine needs every FPT Linear shape to have a split layout (out features a multiple of 136,
+        in features of 544: widths 544 and 1088, i.e. every view-token model at DIM 32; mpl_split_bf16x3_bytes decides)
+        and fuses the attention for up to 32 tokens per sequence."""
+        if self.no_transformer_fpt or len(self.blocks) == 0 or self.FPT_blocks_view_keypoint_tokens or self.num_views > 32:
             return False
         lib = cabi.load()
         b = self.blocks[0]
@@ -342,8 +343,8 @@ class MultiView_MPL(nn.Module):
         key = tuple(map(torch.Tensor.data_ptr, plist))
         bf16 = self.matmul_precision == "bf16" and not self._dp_replica
         x3 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
-        if bf16 or x3:    # derived copies go stale on in-place updates too
-            key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b)[2:12:2])
+        if bf16 or x3:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
+            key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent
@@ -389,10 +390,11 @@ class MultiView_MPL(nn.Module):
             elif x3:
                 lib = cabi.load()
                 ptrs += [0, 0, 0, 0]
-                for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight):
-                    n, k = t.shape
+                for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
+                    n, k = lin.weight.shape
                     c3 = torch.empty(lib.mpl_split_bf16x3_bytes(n, k), dtype=torch.uint8, device=device)
-                    cabi.check(lib.mpl_split_bf16x3(t.data_ptr(), n, k, c3.data_ptr(),
+                    cabi.check(lib.mpl_split_bf16x3(lin.weight.data_ptr(), lin.bias.data_ptr(), _ptr(ln.weight if ln else None),
+                                                    _ptr(ln.bias if ln else None), n, k, c3.data_ptr(),
                                                     torch.cuda.current_stream(device).cuda_stream), "mpl_split_bf16x3")
                     w16_keep.append(c3)
                     ptrs.append(c3.data_ptr())

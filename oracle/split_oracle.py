@@ -1,13 +1,19 @@
-"""CPU restatement of the split-operand layout and arithmetic of openmpl_amd/csrc/x3_gemm.hip.
+"""CPU restatement of the split-operand layout and arithmetic of openmpl_amd/csrc/x3_gemm.hip (engine v2).
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): used by tests/ to check (a) that the three bf16 parts written by
-mpl_split_bf16x3 are byte-for-byte what the definition says, in MFMA fragment order, and (b) that the six-product
-sum the kernels accumulate is at least as accurate as an fp32 product.  This is not a restatement of the reference
-(the reference is plain fp32 PyTorch, oracle/mpl_oracle.py); it pins the build's own derived operand.
+mpl_split_bf16x3 are byte-for-byte what the definition says, in MFMA fragment order, with the fold vectors behind them,
+and (b) that the six-product sum the kernels accumulate is at least as accurate as an fp32 product.  This is not a
+restatement of the reference (the reference is plain fp32 PyTorch, oracle/mpl_oracle.py); it pins the build's own
+derived operand.
 
     x = hi + mid + lo,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (round to nearest even)
-    W3[N/136 groups][K/32 k-tiles][9 column tiles][3 parts][64 lanes][8 bf16];
-    lane = 16 * kq + li holds W[g*136 + tile*16 + li][kt*32 + 8*kq + j], j = 0..7 (zero where tile*16 + li >= 136)
+    K = 136 G columns (G a multiple of 4), KT = K / 32 k-tiles, k-permuted so that a producer's two adjacent 16-column
+    output tiles are one consumer fragment:
+        k-tile t < 4G:        lane quarter kq, element j  <->  column 136 (t//4) + 32 (t%4) + 16 (j//4) + 4 kq + j%4
+        k-tile t = 4G + u:    lane quarter kq, element j  <->  column 136 (4u + kq) + 128 + j     (the 8-column tails)
+    W3[N/136 groups][KT][9 slots][3 parts][64 lanes][8 bf16], slot s = column tile (0,1,2,3,8,4,5,6,7)[s];
+    lane = 16 kq + li holds (gamma o W)[g*136 + tile*16 + li][col(t, kq, j)] (zero where tile*16 + li >= 136);
+    then c[N] = bias + W . beta and s[N] = sum_k fl32(gamma_k W_nk) as fp32 (both from fp64 sums).
 """
 import numpy as np
 import torch
@@ -32,18 +38,70 @@ def bf16_bits(x: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
 
 
-def split_operand(W: np.ndarray) -> np.ndarray:
-    """uint16 array of the bytes mpl_split_bf16x3 must produce for an nn.Linear weight W[N][K]."""
+SLOT_TILE = (0, 1, 2, 3, 8, 4, 5, 6, 7)
+
+
+def x3_col(t: int, kq: int, j: int, G: int) -> int:
+    if t < 4 * G:
+        return 136 * (t // 4) + 32 * (t % 4) + 16 * (j // 4) + 4 * kq + (j % 4)
+    return 136 * (4 * (t - 4 * G) + kq) + 128 + j
+
+
+def k_permutation(K: int) -> np.ndarray:
+    """cols[t, kq, j] = source column of element j of lane quarter kq in k-tile t; a permutation of range(K)."""
+    assert K % 544 == 0
+    G, KT = K // 136, K // 32
+    cols = np.array([[[x3_col(t, kq, j, G) for j in range(8)] for kq in range(4)] for t in range(KT)])
+    assert sorted(cols.reshape(-1).tolist()) == list(range(K))
+    return cols
+
+
+def split_operand(W: np.ndarray, gamma: np.ndarray = None) -> np.ndarray:
+    """uint16 array of the W3 bytes mpl_split_bf16x3 must produce for an nn.Linear weight W[N][K] (gamma folded)."""
     N, K = W.shape
-    assert N % 136 == 0 and K % 32 == 0
-    G, KT = N // 136, K // 32
-    Wp = np.zeros((G, 144, K), dtype=np.float32)
-    Wp[:, :136] = W.reshape(G, 136, K)
-    parts = split3(Wp)                                   # each [G][144][K]
-    out = np.zeros((G, KT, 9, 3, 64, 8), dtype=np.uint16)
-    for p, part in enumerate(parts):
-        b = bf16_bits(part).reshape(G, 9, 16, KT, 4, 8)  # [g][tile][li][kt][kq][j]
-        out[:, :, :, p] = b.transpose(0, 3, 1, 4, 2, 5).reshape(G, KT, 9, 64, 8)   # lane = kq*16 + li
+    assert N % 136 == 0 and K % 544 == 0
+    Gn, KT = N // 136, K // 32
+    Wf = np.asarray(W, dtype=np.float32)
+    if gamma is not None:
+        Wf = (Wf * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    Wp = np.zeros((Gn, 144, K), dtype=np.float32)
+    Wp[:, :136] = Wf.reshape(Gn, 136, K)
+    cols = k_permutation(K)                              # [KT][4][8]
+    out = np.zeros((Gn, KT, 9, 3, 64, 8), dtype=np.uint16)
+    for p, part in enumerate(split3(Wp)):                # each [Gn][144][K]
+        b = bf16_bits(part)[:, :, cols]                  # [g][c][kt][kq][j]
+        b = b.reshape(Gn, 9, 16, KT, 4, 8)               # [g][tile][li][kt][kq][j]
+        b = b.transpose(0, 3, 1, 4, 2, 5).reshape(Gn, KT, 9, 64, 8)   # lane = kq*16 + li
+        out[:, :, :, p] = b[:, :, list(SLOT_TILE)]
+    return out
+
+
+def fold_vectors(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None):
+    """(c, s) fp32 vectors stored behind W3."""
+    W = np.asarray(W, dtype=np.float32)
+    c = np.asarray(bias, dtype=np.float64).copy()
+    s = np.zeros(W.shape[0], dtype=np.float64)
+    if gamma is not None:
+        c += W.astype(np.float64) @ np.asarray(beta, dtype=np.float64)
+        s = (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32).astype(np.float64).sum(1)
+    return c.astype(np.float32), s.astype(np.float32)
+
+
+def split_rows(X: np.ndarray, rpt: int = 64) -> np.ndarray:
+    """uint16 A3 operand [tiles][4 row groups][KT][3][64][8] of fp32 rows X[M][K] (rows >= rpt of a tile are zero)."""
+    M, K = X.shape
+    KT = K // 32
+    tiles = -(-M // rpt)
+    Xp = np.zeros((tiles, 64, K), dtype=np.float32)
+    for t in range(tiles):
+        n = min(rpt, M - t * rpt)
+        Xp[t, :n] = X[t * rpt: t * rpt + n]
+    cols = k_permutation(K)
+    out = np.zeros((tiles, 4, KT, 3, 64, 8), dtype=np.uint16)
+    for p, part in enumerate(split3(Xp)):
+        b = bf16_bits(part)[:, :, cols]                  # [tile][row][kt][kq][j]
+        b = b.reshape(tiles, 4, 16, KT, 4, 8)            # [tile][rg][li][kt][kq][j]
+        out[:, :, :, p] = b.transpose(0, 1, 3, 4, 2, 5).reshape(tiles, 4, KT, 64, 8)
     return out
 
 

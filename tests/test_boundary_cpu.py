@@ -130,10 +130,15 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
     assert ctypes.sizeof(cabi.BlockWeights) == 160 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
-    # split operands of the fp32-on-bf16-cores GEMMs: 27 KiB per (136-column group, 32-deep k-tile); 0 = unsupported
-    assert lib.mpl_split_bf16x3_bytes(1632, 544) == 12 * 17 * 27 * 1024
-    assert lib.mpl_split_bf16x3_bytes(544, 1088) == 4 * 34 * 27 * 1024
+    # split operands of the fp32-on-bf16-cores GEMMs: 27 KiB per (136-column group, 32-deep k-tile) + the two fold
+    # vectors (c, s: N floats each); 0 = unsupported
+    assert lib.mpl_split_bf16x3_bytes(1632, 544) == 12 * 17 * 27 * 1024 + 8 * 1632
+    assert lib.mpl_split_bf16x3_bytes(544, 1088) == 4 * 34 * 27 * 1024 + 8 * 544
     assert lib.mpl_split_bf16x3_bytes(96, 32) == 0 and lib.mpl_split_bf16x3_bytes(544, 48) == 0
+    assert lib.mpl_split_bf16x3_bytes(544, 64) == 0       # K must be a multiple of 544 (4 column groups of 136)
+    # split activations: 3 KiB per (16-row group, k-tile), row tiles padded to 64 rows
+    assert lib.mpl_ln_linear_x3_workspace_bytes(4096, 544) == 64 * 4 * 17 * 3072
+    assert lib.mpl_ln_linear_x3_workspace_bytes(65, 1088) == 2 * 4 * 34 * 3072
 
 
 def test_detrng_is_stable():

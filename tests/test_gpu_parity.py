@@ -317,6 +317,22 @@ def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
     return y
 
 
+def _x3_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln):
+    nbytes = lib.mpl_split_bf16x3_bytes(N, K)
+    assert nbytes == (N // 136) * (K // 32) * 27 * 1024 + 8 * N
+    W3 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None,
+                                    bed.data_ptr() if ln else None, N, K, W3.data_ptr(), _stream()), "mpl_split_bf16x3")
+    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
+    wsb = lib.mpl_ln_linear_x3_workspace_bytes(M, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    cabi.check(lib.mpl_ln_linear_x3(Ad.data_ptr(), M, K, 1 if ln else 0, 1e-6, W3.data_ptr(), N, epi,
+                                    Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None, Y.data_ptr(),
+                                    so.data_ptr() if ln else None, ws.data_ptr(), wsb, _stream()), "mpl_ln_linear_x3")
+    return Y
+
+
 @pytest.mark.parametrize("M,K,N,epi,ln", [
     (4096, 544, 1632, cabi.EPI_BIAS, True),
     (4096, 544, 544, cabi.EPI_BIAS_RESIDUAL, False),
@@ -324,11 +340,13 @@ def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
     (77, 1088, 544, cabi.EPI_BIAS_RESIDUAL, False),
     (3, 544, 544, cabi.EPI_BIAS, False),
     (130, 1088, 3264, cabi.EPI_BIAS, True),
-    (640, 64, 136, cabi.EPI_BIAS_GELU, False),
+    (640, 2176, 1088, cabi.EPI_BIAS_RESIDUAL, False),
+    (8192, 544, 1088, cabi.EPI_BIAS_GELU, True),
 ])
 def test_split_operand_linear_is_fp32_accurate(M, K, N, epi, ln):
-    """mpl_split_bf16x3 + mpl_ln_linear_x3 against an fp64 evaluation: the split-operand GEMM must be as accurate as
-    fp32 arithmetic -- its error may not exceed the native fp32 MFMA kernel's by more than rounding noise."""
+    """mpl_split_bf16x3 + mpl_ln_linear_x3 against an fp64 evaluation: the split-operand GEMM (with the LayerNorm
+    folded into the weight operand) must be as accurate as fp32 arithmetic -- its error may not exceed the native fp32
+    MFMA kernel's (which normalises first, like the reference) by more than rounding noise."""
     lib = cabi.load()
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g) * 1.7 + 0.3
@@ -337,34 +355,75 @@ def test_split_operand_linear_is_fp32_accurate(M, K, N, epi, ln):
     gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
     ref = _fp64_linear(A, W, b, R, gam, bet, epi, ln)
     Ad, Wd, bd, Rd, gd, bed = (t.to(DEV) for t in (A, W, b, R, gam, bet))
-    nbytes = lib.mpl_split_bf16x3_bytes(N, K)
-    assert nbytes == (N // 136) * (K // 32) * 27 * 1024
-    W3 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), N, K, W3.data_ptr(), _stream()), "mpl_split_bf16x3")
-    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
     errs = {}
-    for tag in ("x3", "mfma"):
-        Y = torch.full((M, N), float("nan"), device=DEV)
-        args = (Ad.data_ptr(), M, K, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-6)
-        tail = (bd.data_ptr(), N, epi, Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None, Y.data_ptr(),
-                so.data_ptr() if ln else None, _stream())
-        rc = lib.mpl_ln_linear_x3(*args, W3.data_ptr(), *tail) if tag == "x3" else lib.mpl_ln_linear(*args, Wd.data_ptr(), *tail)
-        cabi.check(rc, tag)
-        torch.cuda.synchronize()
-        errs[tag] = mpl_oracle.rel_errors(Y.cpu(), ref)
+    Y = _x3_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    errs["x3"] = mpl_oracle.rel_errors(Y.cpu(), ref)
+    Y2 = torch.full((M, N), float("nan"), device=DEV)
+    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
+    cabi.check(lib.mpl_ln_linear(Ad.data_ptr(), M, K, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-6,
+                                 Wd.data_ptr(), bd.data_ptr(), N, epi, Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None,
+                                 Y2.data_ptr(), so.data_ptr() if ln else None, _stream()), "mpl_ln_linear")
+    torch.cuda.synchronize()
+    errs["mfma"] = mpl_oracle.rel_errors(Y2.cpu(), ref)
     print("M=%d K=%d N=%d: split %.2e/%.2e  fp32 MFMA %.2e/%.2e" % ((M, K, N) + errs["x3"] + errs["mfma"]))
     assert errs["x3"][0] <= 3e-6 and errs["x3"][1] <= 1e-6
     assert errs["x3"][1] <= 1.5 * errs["mfma"][1] + 1e-8, "split-operand GEMM is less accurate than the fp32 MFMA GEMM"
 
 
+@pytest.mark.parametrize("shift,scale", [(0.0, 1.0), (5.0, 1.0), (-40.0, 2.0), (0.0, 1e-20), (0.0, 1e15)])
+def test_folded_layernorm_is_robust_to_offset_and_scale(shift, scale):
+    """The LayerNorm folded into the split GEMM computes rstd * (x.W'^T - mean * s) + c: rows whose mean dwarfs their
+    spread lose sqrt(1 + (mean/sigma)^2) of precision to the cancellation -- the result must stay inside the 1e-4
+    contract even for |mean| = 40 sigma -- and operand magnitudes from 1e-20 to 1e15 (split parts far from the bf16
+    subnormal / overflow range, x3_gemm.hip header) must not change the accuracy at all."""
+    lib = cabi.load()
+    M, K, N = 256, 544, 1632
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K, generator=g) + shift) * scale
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    ref = _fp64_linear(A, W, b, None, gam, bet, cabi.EPI_BIAS, True) if scale > 1e-10 else None
+    if ref is None:   # eps = 1e-6 dominates the variance of 1e-20-sized rows: compare to the same formula in fp64
+        a = A.double()
+        a = (a - a.mean(-1, keepdim=True)) / torch.sqrt(a.var(-1, unbiased=False, keepdim=True) + 1e-6) * gam.double() + bet.double()
+        ref = a @ W.double().T + b.double()
+    Ad, Wd, bd, gd, bed = (t.to(DEV) for t in (A, W, b, gam, bet))
+    Y = _x3_linear(lib, Ad, Wd, bd, gd, bed, None, M, K, N, cabi.EPI_BIAS, True)
+    torch.cuda.synchronize()
+    mx, nw = mpl_oracle.rel_errors(Y.cpu(), ref)
+    amp = (1.0 + abs(shift) ** 2) ** 0.5
+    print("shift %g scale %g: %.2e / %.2e (amplification bound %.1f)" % (shift, scale, mx, nw, amp))
+    assert mx <= 3e-6 * amp and nw <= 1e-6 * amp and mx < 1e-4
+
+
 def test_split_operand_shapes_are_validated():
     lib = cabi.load()
-    assert lib.mpl_split_bf16x3_bytes(544, 544) == 4 * 17 * 27 * 1024
-    for n, k in ((100, 544), (544, 40), (136, 32), (0, 64), (544, -32)):
+    assert lib.mpl_split_bf16x3_bytes(544, 544) == 4 * 17 * 27 * 1024 + 8 * 544
+    for n, k in ((100, 544), (544, 40), (136, 32), (0, 544), (544, -544), (544, 272), (544, 136)):
         assert lib.mpl_split_bf16x3_bytes(n, k) == 0
     x = torch.zeros(64, 544, device=DEV)
-    cabi_rc = lib.mpl_split_bf16x3(x.data_ptr(), 100, 544, x.data_ptr(), _stream())
+    cabi_rc = lib.mpl_split_bf16x3(x.data_ptr(), x.data_ptr(), None, None, 100, 544, x.data_ptr(), _stream())
     assert cabi_rc != 0
+    # a LayerNorm needs both its vectors
+    big = torch.zeros(lib.mpl_split_bf16x3_bytes(544, 544), dtype=torch.uint8, device=DEV)
+    W = torch.zeros(544, 544, device=DEV)
+    assert lib.mpl_split_bf16x3(W.data_ptr(), x.data_ptr(), x.data_ptr(), None, 544, 544, big.data_ptr(), _stream()) != 0
+    # workspace too small
+    assert lib.mpl_ln_linear_x3(x.data_ptr(), 64, 544, 0, 1e-6, big.data_ptr(), 544, 0, None, W.data_ptr(), None,
+                                W.data_ptr(), 16, _stream()) == -3
+
+
+def test_batch_rows_beyond_32bit_offsets_are_refused_not_wrapped():
+    """row counts that would overflow the kernels' 32-bit row arithmetic are refused loudly."""
+    lib = cabi.load()
+    x = torch.zeros(8, device=DEV)
+    blk = (cabi.BlockWeights * 1)()
+    sched = (C.c_uint8 * 1)(0)
+    rc = lib.mpl_block_stack(x.data_ptr(), 1 << 20, 1 << 11, 544, 8, blk, sched, 1, x.data_ptr(), 32, _stream())
+    assert rc == -2
 
 
 @pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2", "chosen_v8_b4_l2", "chosen_v5_b19_l2", "kptok_v3_b3_l2", "no_fpt_v3_b3_l2"])
@@ -412,17 +471,25 @@ def test_split_operand_bytes_match_the_definition():
     from oracle import split_oracle
     lib = cabi.load()
     g = torch.Generator().manual_seed(3)
-    for N, K in ((272, 64), (544, 544), (1632, 544)):
+    for N, K, ln in ((272, 544, False), (544, 544, True), (1632, 544, True), (544, 1088, False)):
         W = torch.randn(N, K, generator=g) * K ** -0.5
         W[0, 0], W[1, 1], W[2, 2] = 0.0, 1.0 + 2 ** -23, -255.99998
-        Wd = W.to(DEV)
+        bias = torch.randn(N, generator=g)
+        gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+        Wd, bd, gd, bed = (t.to(DEV) for t in (W, bias, gam, bet))
         dst = torch.zeros(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=DEV)
-        cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), N, K, dst.data_ptr(), _stream()), "mpl_split_bf16x3")
+        cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None,
+                                        bed.data_ptr() if ln else None, N, K, dst.data_ptr(), _stream()), "mpl_split_bf16x3")
         torch.cuda.synchronize()
-        got = dst.cpu().numpy().view(np.uint16)
-        want = split_oracle.split_operand(W.numpy()).reshape(-1)
+        raw = dst.cpu().numpy()
+        nw3 = (N // 136) * (K // 32) * 27 * 1024
+        got = raw[:nw3].view(np.uint16)
+        want = split_oracle.split_operand(W.numpy(), gam.numpy() if ln else None).reshape(-1)
         assert got.shape == want.shape
         assert np.array_equal(got, want), "N=%d K=%d: %d of %d bf16 words differ" % (N, K, int((got != want).sum()), want.size)
+        c, sv = split_oracle.fold_vectors(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
+        vec = raw[nw3:].view(np.float32)
+        assert np.array_equal(vec[:N], c) and np.array_equal(vec[N:], sv), "fold vectors differ"
 
 
 def test_split_operands_follow_in_place_weight_updates():

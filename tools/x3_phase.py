@@ -1,45 +1,45 @@
-"""Per-wave phase cycles of the split-operand GEMM k loop (MPL_X3_DBG=1): python tools/x3_phase.py [K]"""
-import os
-import sys
-
-os.environ["MPL_X3_DBG"] = "1"
-import torch
-
+"""Where a split-operand GEMM launch spends its time: per-wave shader-clock stamps (mpl_x3_debug_buffer) of the four
+GEMMs of one FPT block at the headline shape (M = 4096, D = 544).   python tools/x3_phase.py [D]"""
+import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from openmpl_amd import cabi  # noqa: E402
+import numpy as np, torch
+from openmpl_amd import cabi
 
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 544
-M, N = 4096, 544
 lib = cabi.load()
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 544
+M, dev = 4096, "cuda"
+st = lambda: torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
-st = torch.cuda.current_stream().cuda_stream
-A = torch.randn(M, K, generator=g).cuda()
-W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
-b = torch.randn(N, generator=g).cuda()
-R = torch.randn(M, N, generator=g).cuda()
-W3 = torch.empty(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device="cuda")
-cabi.check(lib.mpl_split_bf16x3(W.data_ptr(), N, K, W3.data_ptr(), st), "split")
-Y = torch.zeros(M, N, device="cuda")
-dbg = torch.zeros(256 * 8 * 16, device="cuda")
-for _ in range(3):
-    rc = lib.mpl_ln_linear_x3(A.data_ptr(), M, K, None, None, 1e-6, W3.data_ptr(), b.data_ptr(), N, 2, R.data_ptr(), Y.data_ptr(),
-                              dbg.data_ptr(), st)
-    assert rc == 0
+def operand(N, K, ln):
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
+    gam = (torch.rand(K, generator=g) + 0.5).to(dev); bet = (torch.randn(K, generator=g) * 0.1).to(dev)
+    o = torch.empty(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=dev)
+    cabi.check(lib.mpl_split_bf16x3(W.data_ptr(), b.data_ptr(), gam.data_ptr() if ln else None, bet.data_ptr() if ln else None, N, K, o.data_ptr(), st()), "split")
+    return o
+blk = cabi.BlockWeights()
+keep = [operand(3 * D, D, True), operand(D, D, False), operand(2 * D, D, True), operand(D, 2 * D, False)]
+blk.qkv_w3, blk.proj_w3, blk.fc1_w3, blk.fc2_w3 = (k.data_ptr() for k in keep)
+blks = (cabi.BlockWeights * 1)(blk)
+x = torch.randn(M, D, generator=g).to(dev)
+wsb = lib.mpl_block_stack_workspace_bytes(M // 4, 4, D)
+ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+dbg = torch.zeros(8 * 8 * 1024, dtype=torch.int64, device=dev)
+names = ["LN1+qkv+attention", "proj+residual", "LN2+fc1+GELU", "fc2+residual"]
+sched = (C.c_uint8 * 1)(0)
+def run(n_apps=1):
+    cabi.check(lib.mpl_block_stack(x.data_ptr(), M // 4, 4, D, 8, blks, sched, n_apps, ws.data_ptr(), wsb, st()), "stack")
+for _ in range(3): run()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
-    lib.mpl_ln_linear_x3(A.data_ptr(), M, K, None, None, 1e-6, W3.data_ptr(), b.data_ptr(), N, 2, R.data_ptr(), Y.data_ptr(), dbg.data_ptr(), st)
-e1.record()
-torch.cuda.synchronize()
-print('kernel (instrumented) %.1f us per launch' % (e0.elapsed_time(e1) * 50))
-d = dbg.view(256, 8, 16).cpu()
-n = d[..., 4:5].clamp(min=1)
-per = d[..., :4] / n
-names = ["batch-0 MFMA + DMA issue", "vmcnt/lgkmcnt waits", "barrier", "reads + split x batch-1"]
-for w in (0, 4):
-    print("wave %d: prologue %.0f | loop %.0f | epilogue values+stores issued %.0f | stores drained %.0f cycles" % (w, d[:, w, 5].mean(), d[:, w, 6].mean(), d[:, w, 7].mean(), d[:, w, 8].mean()))
-print("stages per wave: %d; s_memtime ticks are 100 MHz? -> raw units" % int(d[0, 0, 4]))
-for w in range(8):
-    print("wave %d (%d tiles): " % (w, 5 if w < 4 else 4) + " | ".join("%s %.0f" % (nm, per[:, w, i].mean()) for i, nm in enumerate(names))
-          + " | sum %.0f" % per[:, w].sum(-1).mean())
+# one launch at a time cannot be isolated through mpl_block_stack: every launch overwrites the stamps, so the buffer holds
+# the LAST GEMM (fc2) after a full block; the others are reached by stacks truncated with an invalid later operand
+for upto, name in ((4, names[3]),):
+    lib.mpl_x3_debug_buffer(dbg.data_ptr()); run(); torch.cuda.synchronize(); lib.mpl_x3_debug_buffer(None)
+    t = dbg.cpu().numpy().reshape(-1, 8)[:256 * 8, :7].astype(np.float64)
+    t0 = t[:, 0].min()
+    print("%-20s waves %d  entry spread %.0f | prologue %.0f | k loop %.0f (%.0f per stage) | epilogue to stores issued %.0f | drain %.0f | total %.0f  (shader-clock ticks, mean over waves; 100 MHz ticks if constant clock)"
+          % (name, len(t), (t[:, 0] - t0).max(), (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 1]).mean(), (t[:, 2] - t[:, 1]).mean() / (2 * D // 32),
+             (t[:, 3] - t[:, 2]).mean(), (t[:, 4] - t[:, 3]).mean(), (t[:, 4].max() - t0)))
+    nst = 2 * D // 32
+    for half, nm in ((slice(0, None, 8), "wave 0 (5 tiles)"), (slice(4, None, 8), "wave 4 (4 tiles)")):
+        print("   %s: per stage  DMA wait %.0f | lgkm + barrier %.0f | rest (issue MFMA + reads + DMA) %.0f"
+              % (nm, t[half, 5].mean() / nst, t[half, 6].mean() / nst, ((t[half, 2] - t[half, 1]) - t[half, 5] - t[half, 6]).mean() / nst))
