@@ -295,8 +295,11 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
         torch.cuda.synchronize()
         prof = cabi.profile_stop()
     gemm_ms, gemm_n = prof["gemm"]
-    fl, launches = gemm_flops_per_forward(flags, a.batch)
-    assert gemm_n == launches * n_prof, (gemm_n, launches)
+    fl, gemms = gemm_flops_per_forward(flags, a.batch)
+    # the split-operand engine runs ALL GEMMs of the block stack in ONE persistent launch (csrc/x3_gemm.hip,
+    # x3_stack_kernel); the fp32-MFMA engine (and MPL_X3_LAUNCHES=1) launch one kernel per GEMM
+    assert gemm_n % n_prof == 0 and gemm_n // n_prof in (1, gemms), (gemm_n, gemms)
+    launches = gemm_n // n_prof
     avg_launch_ms = gemm_ms / gemm_n
     alg = (fl / launches) / (avg_launch_ms * 1e-3) / 1e12          # fp32-algorithmic TFLOP/s of the mean launch
     kernel_ms = {k: round(t / n_prof, 4) for k, (t, n) in prof.items()}
@@ -342,16 +345,19 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     spt_ms, spt_n = prof["spt"]
     spt_fl = spt_flops_per_forward(flags, a.batch)
     spt_t = spt_fl / (spt_ms / max(1, spt_n) * 1e-3) / 1e12
-    kernels = [dict(kernel=gemm_kernel, launches_per_step=launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
-                    flops_per_launch=fl / launches, algorithmic_bytes_per_launch=round(alg_bytes),
+    kernels = [dict(kernel=gemm_kernel if launches > 1 else "x3_stack_kernel", launches_per_step=launches, gemms_per_launch=gemms // launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
+                    flops_per_launch=fl / launches, algorithmic_bytes_per_launch=round(alg_bytes * gemms / launches),
                     share_of_kernel_time=round(gemm_ms / sum(t for t, _ in prof.values()), 3)),
                dict(kernel="spt_kernel", launches_per_step=1, avg_launch_us=round(spt_ms / max(1, spt_n) * 1e3, 2),
                     flops_per_launch=spt_fl, bound="mfma", instruction="v_mfma_f32_16x16x4_f32 + VALU attention",
                     achieved=round(spt_t, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(spt_t / PEAK_FP32_MFMA_TFLOPS, 4),
                     share_of_kernel_time=round(spt_ms / sum(t for t, _ in prof.values()), 3))]
+    if launches == 1:
+        roof["kernel"] = "x3_stack_kernel"
+    alg_bytes *= gemms / launches
     roof.update(traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(avg_launch_ms * 1e3, 2),
-                launches_per_step=launches, flops_per_launch=fl / launches,
+                launches_per_step=launches, gemms_per_launch=gemms // launches, flops_per_launch=fl / launches,
                 algorithmic_bytes_per_launch=round(alg_bytes), kernels=kernels,
                 whole_forward_tflops=round(value / world * total_flop / 1e12, 2),
                 whole_forward_frac_of_fp32_peak=round(value / world * total_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -77,7 +77,8 @@ def _build_locked(verbose: bool) -> str:
     tag = ".%d" % os.getpid()
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", tag + ".o"))
-        cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MPL_HIPCC_FLAGS", "").split() + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

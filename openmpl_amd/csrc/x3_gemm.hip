@@ -58,7 +58,10 @@ constexpr int X3_A = 4 * X3_RG;              // A3 bytes per stage (64 rows)
 constexpr int X3_W = 27 * 1024;              // W3 bytes per k-tile of a 136-column group
 constexpr int X3_STAGE = X3_A + X3_W;        // 39936
 constexpr int X3_NST = 4;                    // ring depth (159744 B of LDS, one workgroup per CU)
-constexpr int X3_T0 = 5;                     // slots of waves 0..3; waves 4..7 take the other 4
+constexpr int X3_T0 = 5;
+#ifndef X3_CHAIN_WT
+#define X3_CHAIN_WT 1   // chain mode hand-offs: 1 = write-through stores + L1-bypassing loads, 0 = plain accesses + agent fences
+#endif                     // slots of waves 0..3; waves 4..7 take the other 4
 
 __host__ __device__ constexpr int x3_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
 
@@ -233,7 +236,9 @@ constexpr int X3_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k
 // (MI355X_MICROARCH.md, "Valid forms").  Kernel boundaries make plain accesses sufficient in the one-GEMM launches.
 template <bool WT>
 __device__ __forceinline__ void st16(void* p, const bf16x8& v) {
-    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    // (hand-written VMEM store: the compiler does not know the 2 wait states a > 64-bit store needs before a VALU write
+    // of its data registers -- s_nop 1 provides them)
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
     else *reinterpret_cast<bf16x8*>(p) = v;
 }
 template <bool WT>
@@ -345,6 +350,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = X3_NST;
     constexpr bool HAS_A = NTW == X3_T0;         // waves 0..3 (slots 0..4) bring the A pieces
+    constexpr bool WT = CHAIN && X3_CHAIN_WT;
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
@@ -401,7 +407,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         if ((ia_t % NPASS) == 0) {
             if (HAS_A) {
                 const unsigned keep = dma_m0_save();
-                if (CHAIN)
+                if (WT)
                     asm volatile(
                         "s_mov_b32 m0, %2\n\t"
                         "s_nop 0\n\t"
@@ -438,10 +444,11 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         if (tid == 0) {
             // one lane polls (relaxed, L2-bypassing); bounded so that a lost partner cannot hang the GPU: after ~2 s the
             // workgroup goes on with whatever is there and the result fails the parity tests instead
-            for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+            for (unsigned spin = 0; spin < (1u << 21); ++spin) {
                 if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
                 __builtin_amdgcn_s_sleep(2);
             }
+            if (!WT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
@@ -463,7 +470,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (2 * i < ns) {
-                    if (CHAIN) {   // written by the other workgroups of the team in this launch: L1-bypassing loads
+                    if (WT) {   // written by the other workgroups of the team in this launch: L1-bypassing loads
                         st_raw[i].x = __hip_atomic_load(sp + 4 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         st_raw[i].y = __hip_atomic_load(sp + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         st_raw[i].z = __hip_atomic_load(sp + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -704,7 +711,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        x3_attention<CHAIN>(Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+        x3_attention<WT>(Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
     } else {
         const int KTo = N / BK, Go = N / BN;
         float vals[NTW][4];
@@ -733,18 +740,18 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                     split3(x, hi, mid, lo);
                     const int pq = (slot0 ? 2 : 0) + q;
                     char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * g_out + pq)) * X3_RG + lane * 16;
-                    st16<CHAIN>(o, hi);
-                    st16<CHAIN>(o + 1024, mid);
-                    st16<CHAIN>(o + 2048, lo);
+                    st16<WT>(o, hi);
+                    st16<WT>(o + 1024, mid);
+                    st16<WT>(o + 2048, lo);
                 }
                 if (NTW == X3_T0 && kq < 2) {     // the half tile: 4 values per lane into the shared tail k-tile
                     const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
                     bf16x8 hi, mid, lo;
                     split3(x, hi, mid, lo);
                     char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8;
-                    st8<CHAIN>(o, hi);
-                    st8<CHAIN>(o + 1024, mid);
-                    st8<CHAIN>(o + 2048, lo);
+                    st8<WT>(o, hi);
+                    st8<WT>(o + 1024, mid);
+                    st8<WT>(o + 2048, lo);
                 }
             }
         }
@@ -780,7 +787,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 if (kq == 0) xch[128 + half * 64 + row_l] = q;
                 __syncthreads();
                 if (half == 0 && kq == 0 && row_ok)
-                    st_f2<CHAIN>(a.stats_out + ((size_t)row * Go + n0 / BN) * 2, mean, xch[128 + row_l] + xch[192 + row_l]);
+                    st_f2<WT>(a.stats_out + ((size_t)row * Go + n0 / BN) * 2, mean, xch[128 + row_l] + xch[192 + row_l]);
             }
         }
     }
@@ -788,7 +795,13 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         // arrive: every store of this workgroup has been acknowledged (write-through), nobody touches the ring any more
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (!WT) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (a.dbg) {   // bench-only: entry, loop start, loop end, stores issued, stores drained (shader clock), wait sums
         if (!t_st) t_st = __builtin_amdgcn_s_memtime();
