@@ -186,6 +186,9 @@ int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const 
  * wave (entry, k-loop start, k-loop end, stores issued, stores drained) at device_buffer[(block * 8 + wave) * 8 ..];
  * the buffer must hold 64 bytes per wave of the largest launch.  NULL (the default) switches it off. */
 int mpl_x3_debug_buffer(void *device_buffer);
+/* Diagnostics / A-B: 0 (default) = a block stack on split operands is ONE persistent launch (row-tile chains of
+ * workgroups, csrc/x3_gemm.hip x3_stack_kernel); 1 = one launch per GEMM.  Bitwise identical results. */
+int mpl_x3_stack_mode(int one_launch_per_gemm);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

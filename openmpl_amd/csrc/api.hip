@@ -64,6 +64,9 @@ StackWs carve_stack_ws(void* base, size_t M, size_t D) {
     return w;
 }
 
+std::atomic<bool> g_x3_per_gemm{getenv("MPL_X3_LAUNCHES") != nullptr};
+std::atomic<int> g_x3_stop{0};   // diagnostics: stop a stack after this many GEMMs (0 = run everything)
+
 // split-operand path (x3_gemm.hip): the activations between the GEMMs of a block live as split A3 operands
 struct X3Ws {
     unsigned short *x3, *att3, *hid3;
@@ -84,7 +87,7 @@ X3Ws carve_x3_ws(void* base, size_t M, size_t D, int rpt) {
     w.att3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt)));
     w.hid3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)(2 * D), rpt)));
     w.stats = reinterpret_cast<float*>(take(M * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
-    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt) * sizeof(unsigned)));
+    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt + 1024) * sizeof(unsigned)));   // + X3_MAX_WGS placement words
     w.bytes = off;
     return w;
 }
@@ -109,28 +112,32 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     int rc;
     if ((rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
     if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, s))) return rc;
-    // bench-only A/B switch: MPL_X3_LAUNCHES=1 runs one launch per GEMM (the same phases, kernel boundaries in between)
-    static const bool per_gemm = getenv("MPL_X3_LAUNCHES") != nullptr;
-    if (!per_gemm) {
+    // A/B switch (mpl_x3_stack_mode, or MPL_X3_LAUNCHES=1 in the environment): one launch per GEMM -- the same phases with
+    // kernel boundaries in between -- instead of the persistent row-tile chains
+    if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
         const unsigned short* ops[MPL_MAX_APPS * 4];
         if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
         for (int a = 0; a < n_apps; ++a) {
             const mpl_block_weights& b = blocks[schedule[a]];
             ops[4 * a + 0] = b.qkv_w3; ops[4 * a + 1] = b.proj_w3; ops[4 * a + 2] = b.fc1_w3; ops[4 * a + 3] = b.fc2_w3;
         }
-        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, s);
+        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), s);
     }
+    const int stop = g_x3_stop.load();
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if ((rc = launch_x3_qkv_attention(w.x3, b.qkv_w3, w.stats, eps, M, D, n_tok, H, w.att3, s))) return rc;
+        if (stop && 4 * a + 1 >= stop) return MPL_OK;
         if ((rc = launch_x3_gemm(w.att3, b.proj_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, D, rpt,
                                  MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
+        if (stop && 4 * a + 2 >= stop) return MPL_OK;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
         if ((rc = launch_x3_gemm(w.x3, b.fc1_w3, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid3, nullptr, M, 2 * D, D, rpt,
                                  MPL_EPI_BIAS_GELU, s)))
             return rc;
+        if (stop && 4 * a + 3 >= stop) return MPL_OK;
         if ((rc = launch_x3_gemm(w.hid3, b.fc2_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, 2 * D, rpt,
                                  MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
@@ -315,6 +322,12 @@ int mpl_split_bf16x3(const float* W, const float* bias, const float* ln_w, const
     clear_stale_hip_error();
     if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
     return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
+}
+
+int mpl_x3_stack_mode(int one_launch_per_gemm) {
+    g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
+    g_x3_stop.store(one_launch_per_gemm >> 8);
+    return MPL_OK;
 }
 
 int mpl_x3_debug_buffer(void* device_buffer) {

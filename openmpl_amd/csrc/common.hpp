@@ -87,7 +87,7 @@ int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, 
                    hipStream_t s);
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    hipStream_t s);
+                    int stop_after, hipStream_t s);
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
                             int n_tok, int heads, unsigned short* att3, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);

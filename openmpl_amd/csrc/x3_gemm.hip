@@ -58,7 +58,17 @@ constexpr int X3_A = 4 * X3_RG;              // A3 bytes per stage (64 rows)
 constexpr int X3_W = 27 * 1024;              // W3 bytes per k-tile of a 136-column group
 constexpr int X3_STAGE = X3_A + X3_W;        // 39936
 constexpr int X3_NST = 4;                    // ring depth (159744 B of LDS, one workgroup per CU)
+constexpr int X3_MAX_WGS = 1024;             // workgroups of x3_stack_kernel (one per CU: 256 on MI355X)
 constexpr int X3_T0 = 5;
+#ifndef X3_ABL
+#define X3_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads
+#endif
+#ifndef X3_STAGGER
+#define X3_STAGGER 1   // 1: the waves 4..7 request their DMA pieces three product rows later than the waves 0..3
+#endif
+#ifndef X3_PRIO
+#define X3_PRIO 0      // 1: static s_setprio 1 for the younger half (waves 4..7)
+#endif
 #ifndef X3_CHAIN_WT
 #define X3_CHAIN_WT 1   // chain mode hand-offs: 1 = write-through stores + L1-bypassing loads, 0 = plain accesses + agent fences
 #endif                     // slots of waves 0..3; waves 4..7 take the other 4
@@ -234,31 +244,33 @@ constexpr int X3_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k
 // ---- stores / loads of data that crosses workgroups INSIDE a launch (chain mode, see x3_stack_kernel): write-through
 // (sc0 sc1) stores and L1-bypassing (sc1) loads on both sides -- a valid hand-off for ANY placement of the workgroups
 // (MI355X_MICROARCH.md, "Valid forms").  Kernel boundaries make plain accesses sufficient in the one-GEMM launches.
-template <bool WT>
-__device__ __forceinline__ void st16(void* p, const bf16x8& v) {
-    // (hand-written VMEM store: the compiler does not know the 2 wait states a > 64-bit store needs before a VALU write
-    // of its data registers -- s_nop 1 provides them)
-    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    else *reinterpret_cast<bf16x8*>(p) = v;
+// `base` wave-uniform, `off` < 2 GiB.  wt: sc0 | sc1 = write-through to memory (the line leaves the writer's L2).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-template <bool WT>
-__device__ __forceinline__ void st8(void* p, const bf16x8& v) {      // the 4 low bf16 of a fragment
+__device__ __forceinline__ void st16(bool wt, void* base, unsigned off, const bf16x8& v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(w, x3_rsrc(base), off, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, x3_rsrc(base), off, 0, 0);
+}
+__device__ __forceinline__ void st8(bool wt, void* base, unsigned off, const bf16x8& v) {      // the 4 low bf16 of a fragment
     const u32x4 w = __builtin_bit_cast(u32x4, v);
     const u32x2 h = {w[0], w[1]};
-    if (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(h) : "memory");
-    else *reinterpret_cast<u32x2*>(p) = h;
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 0);
 }
-template <bool WT>
-__device__ __forceinline__ void st_f2(float* p, float x, float y) {
+__device__ __forceinline__ void st_f2(bool wt, float* base, unsigned off, float x, float y) {
     const u32x2 h = {__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)};
-    if (WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(h) : "memory");
-    else *reinterpret_cast<u32x2*>(p) = h;
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 0);
 }
-
+// L1-bypassing (sc1) loads the compiler tracks (buffer form; `base` wave-uniform, offsets < 2 GiB)
+__device__ __forceinline__ u32x4 ld16_l2(const void* base, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(x3_rsrc(base), off, 0, 16);
+}
 // Attention.forward :55-64 on the q | k | v tile T[64][X3_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
 // channels: S whole sequences of nt tokens (rows S*nt.. are padding); output written as A3 of width Dq for proj.
-template <bool WT>
-__device__ __forceinline__ void x3_attention(float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
+__device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
                                              int g_out, int Dq) {
     const int hd4 = hd >> 2;
     const int HP = BN / hd, nn = nt * nt;
@@ -295,6 +307,7 @@ __device__ __forceinline__ void x3_attention(float* T, float* SC, int tid, int n
     // P.V and the A3 fragments of the output rows: task = (row, quarter p, lane quarter kq) -> 8 values = the two
     // 4-column chunks 32p + 4kq and 32p + 16 + 4kq; tail tasks (row, kq < 2) -> 4 values at 128 + 4kq
     const int KTo = Dq / BK, Go = Dq / BN;
+    char* cbase = C3 + (size_t)tile_m * 4 * KTo * X3_RG;      // this row tile of the output operand (wave-uniform)
     auto pv4 = [&](int row, int c) -> float4 {
         float4 o = {0.f, 0.f, 0.f, 0.f};
         if (row < S * nt) {
@@ -320,10 +333,10 @@ __device__ __forceinline__ void x3_attention(float* T, float* SC, int tid, int n
         const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         bf16x8 hi, mid, lo;
         split3(x, hi, mid, lo);
-        char* o = C3 + (((size_t)tile_m * 4 + rg) * KTo + (4 * g_out + p)) * X3_RG + (kq * 16 + li) * 16;
-        st16<WT>(o, hi);
-        st16<WT>(o + 1024, mid);
-        st16<WT>(o + 2048, lo);
+        const unsigned o = (unsigned)((rg * KTo + (4 * g_out + p)) * X3_RG + (kq * 16 + li) * 16);
+        st16(WT, cbase, o, hi);
+        st16(WT, cbase, o + 1024, mid);
+        st16(WT, cbase, o + 2048, lo);
     }
     for (int t = tid; t < BM * 2; t += 512) {
         const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
@@ -332,10 +345,10 @@ __device__ __forceinline__ void x3_attention(float* T, float* SC, int tid, int n
         const float x[8] = {a.x, a.y, a.z, a.w, 0.f, 0.f, 0.f, 0.f};
         bf16x8 hi, mid, lo;
         split3(x, hi, mid, lo);
-        char* o = C3 + (((size_t)tile_m * 4 + rg) * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8;
-        st8<WT>(o, hi);
-        st8<WT>(o + 1024, mid);
-        st8<WT>(o + 2048, lo);
+        const unsigned o = (unsigned)((rg * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8);
+        st8(WT, cbase, o, hi);
+        st8(WT, cbase, o + 1024, mid);
+        st8(WT, cbase, o + 2048, lo);
     }
 }
 
@@ -350,7 +363,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = X3_NST;
     constexpr bool HAS_A = NTW == X3_T0;         // waves 0..3 (slots 0..4) bring the A pieces
-    constexpr bool WT = CHAIN && X3_CHAIN_WT;
+    constexpr bool WT = CHAIN;       // chain mode hand-offs: write-through stores (+ L1-bypassing loads): valid for any placement
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
@@ -407,7 +420,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         if ((ia_t % NPASS) == 0) {
             if (HAS_A) {
                 const unsigned keep = dma_m0_save();
-                if (WT)
+                if (CHAIN)
                     asm volatile(
                         "s_mov_b32 m0, %2\n\t"
                         "s_nop 0\n\t"
@@ -448,7 +461,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (!WT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
@@ -470,7 +482,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (2 * i < ns) {
-                    if (WT) {   // written by the other workgroups of the team in this launch: L1-bypassing loads
+                    if (CHAIN) {   // written by the other workgroups of the team in this launch: L1-bypassing loads
                         st_raw[i].x = __hip_atomic_load(sp + 4 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         st_raw[i].y = __hip_atomic_load(sp + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         st_raw[i].z = __hip_atomic_load(sp + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -484,11 +496,15 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
         }
         if (EPI == X3_EPI_RES) {
+            // fp32 rows this workgroup wrote itself (earlier GEMM of the stack) or a previous launch wrote; in chain mode
+            // read past the L1, which own stores do not refresh
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
                 int c = 16 * x3_slot_tile(slot0 + n) + 4 * kq;
                 c = c + 3 < BN ? c : 0;
-                rv[n] = ld4(a.R + (size_t)row * a.ldr + n0 + c);    // private to this workgroup (it wrote them itself)
+                const float* rp = a.R + (size_t)row * a.ldr + n0 + c;
+                if (CHAIN) rv[n] = __builtin_bit_cast(float4, ld16_l2(a.R + (size_t)m0 * a.ldr, (unsigned)((size_t)(rp - (a.R + (size_t)m0 * a.ldr)) * 4)));
+                else rv[n] = ld4(rp);
             }
         }
     };
@@ -538,6 +554,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         read_a(0, A0);
         read_b(0, B0);
     }
+    if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(1);
     const unsigned long long t_loop = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_vm = 0, t_bar = 0;      // bench-only: cycles at the counted DMA wait / at lgkmcnt + barrier
     unsigned slot_c = 0;
@@ -571,7 +588,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         }
         const bf16x8* bs = reinterpret_cast<const bf16x8*>(smem + slot_n + X3_A) + slot0 * 3 * 64 + lane;
         auto rd_b = [&](int n) {
-            if (more && n < NTW) {
+            if (more && n < NTW && !(X3_ABL & 1)) {
                 b_nxt[n][0] = bs[(n * 3 + 0) * 64];
                 b_nxt[n][1] = bs[(n * 3 + 1) * 64];
                 b_nxt[n][2] = bs[(n * 3 + 2) * 64];
@@ -580,12 +597,15 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[2], b_cur, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more && iw_t < T) {                      // stage t+NST into the slot of stage t
-            issue_w();
-            issue_a();
-        }
-        if (t == t_ops) epilogue_operands();
-        if (more && next_has_a) read_a(slot_n, a_nxt);
+        auto refill = [&]() {
+            if (more && iw_t < T && !((X3_ABL & 2) && t > 0)) {   // stage t+NST into the slot of stage t
+                issue_w();
+                issue_a();
+            }
+            if (t == t_ops) epilogue_operands();
+        };
+        if (!(X3_STAGGER && !HAS_A)) refill();
+        if (more && next_has_a && !(X3_ABL & 4)) read_a(slot_n, a_nxt);
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -599,6 +619,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         mfma_row(accp, a_cur[1], b_cur, 0);
         __builtin_amdgcn_sched_barrier(0);
         rd_b(2);
+        if (X3_STAGGER && !HAS_A) refill();
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -648,6 +669,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         }
     }
 
+    if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(0);
     // ------------------------------------------------------------------------------------------ epilogue
     const unsigned long long t_epi = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
     float mu = 0.f, rs = 1.f;
@@ -666,10 +688,10 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float d = st[2 * i] - mean;
-            m2 += (i < ns) ? st[2 * i + 1] + (float)BN * d * d : 0.f;
+            m2 += (i < ns) ? fmaf((float)BN * d, d, st[2 * i + 1]) : 0.f;
         }
         mu = mean;
-        rs = 1.0f / sqrtf(m2 / (float)K + a.eps);
+        rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
     }
     // acc[p][n][r] = C[row_l][colbase(p) + 16 tile(n) + 4 kq + r]
     auto tile_of = [&](int n) -> int { return x3_slot_tile(slot0 + n); };
@@ -686,9 +708,11 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // explicit fused operations: the same roundings in every instantiation of this function (chain phases and
+            // one-GEMM launches must agree bitwise, whatever the optimiser would contract)
             float t = acc[p][n][r];
-            if (LNF) t = rs * (t - mu * s4[r]);
-            t += c4[r];
+            if (LNF) t = fmaf(rs, fmaf(-mu, s4[r], t), c4[r]);
+            else t += c4[r];
             if (EPI == X3_EPI_GELU) t = gelu_erf(t);
             v[r] = ok ? t : 0.f;
         }
@@ -711,9 +735,10 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        x3_attention<WT>(Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+        x3_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
     } else {
         const int KTo = N / BK, Go = N / BN;
+        char* cbase = a.C3 + ((size_t)tm * 4 + rg) * KTo * X3_RG;   // this wave's row group of the output operand
         float vals[NTW][4];
 #pragma unroll
         for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
@@ -739,19 +764,19 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                     bf16x8 hi, mid, lo;
                     split3(x, hi, mid, lo);
                     const int pq = (slot0 ? 2 : 0) + q;
-                    char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * g_out + pq)) * X3_RG + lane * 16;
-                    st16<WT>(o, hi);
-                    st16<WT>(o + 1024, mid);
-                    st16<WT>(o + 2048, lo);
+                    const unsigned o = (unsigned)((4 * g_out + pq) * X3_RG + lane * 16);
+                    st16(WT, cbase, o, hi);
+                    st16(WT, cbase, o + 1024, mid);
+                    st16(WT, cbase, o + 2048, lo);
                 }
                 if (NTW == X3_T0 && kq < 2) {     // the half tile: 4 values per lane into the shared tail k-tile
                     const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
                     bf16x8 hi, mid, lo;
                     split3(x, hi, mid, lo);
-                    char* o = a.C3 + (((size_t)tm * 4 + rg) * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8;
-                    st8<WT>(o, hi);
-                    st8<WT>(o + 1024, mid);
-                    st8<WT>(o + 2048, lo);
+                    const unsigned o = (unsigned)((4 * Go + (g_out >> 2)) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8);
+                    st8(WT, cbase, o, hi);
+                    st8(WT, cbase, o + 1024, mid);
+                    st8(WT, cbase, o + 2048, lo);
                 }
             }
         }
@@ -787,7 +812,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 if (kq == 0) xch[128 + half * 64 + row_l] = q;
                 __syncthreads();
                 if (half == 0 && kq == 0 && row_ok)
-                    st_f2<WT>(a.stats_out + ((size_t)row * Go + n0 / BN) * 2, mean, xch[128 + row_l] + xch[192 + row_l]);
+                    st_f2(WT, a.stats_out + (size_t)m0 * Go * 2, (unsigned)(((row - m0) * Go + n0 / BN) * 8), mean, xch[128 + row_l] + xch[192 + row_l]);
             }
         }
     }
@@ -796,10 +821,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            if (!WT) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -849,7 +870,7 @@ struct X3StackArgs {
     char *x3, *att3, *hid3;
     float *x, *stats;
     unsigned* counters;          // one per row tile, zeroed before the launch
-    int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps;
+    int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
     float eps;
     unsigned long long* dbg;
     const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
@@ -863,13 +884,11 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
     int team, tn;
     {
         const int b = blockIdx.x;
-        if ((s.n_teams & 7) == 0) {   // blocks b, b+8, .. share an XCD: keep a team inside one (speed only, never needed)
-            team = (b & 7) + 8 * ((b >> 3) / G);
-            tn = (b >> 3) % G;
-        } else {
-            team = b / G;
-            tn = b % G;
-        }
+        // blocks b, b+8, .. share an XCD (observed, never relied on): a team takes blocks of one residue class.  Fewer than
+        // 8 teams: the launch still has 8 G blocks and the classes without a team leave at once.
+        team = (b & 7) + 8 * ((b >> 3) / G);
+        tn = (b >> 3) % G;
+        if (team >= s.n_teams) return;
     }
     auto vecs = [&](const char* w3, int N, int K) -> const float* {
         return reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
@@ -879,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
     // of all eight phase bodies alive across the loop (which spilled ~200 VGPRs).
     for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
         unsigned need = 0;           // arrivals that complete the phase whose output the next phase reads
-        for (int ph = 0; ph < 4 * s.n_apps; ++ph, need += G) {
+        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
             int tidp = tid, tile = tile0, tnp = tn;
             asm volatile("" : "+v"(tidp));
             asm volatile("" : "+s"(tile), "+s"(tnp));
@@ -895,14 +914,6 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
                     else x3_phase<X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
-                case 1: {
-                    const float* v = vecs(w[1], D, D);
-                    const X3Args a{s.att3, w[1], v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, D, s.rpt,
-                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
-                    if (wv < 4) x3_phase<X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
-                    break;
-                }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const X3Args a{s.x3, w[2], v, v + 2 * D, s.stats, nullptr, 0, nullptr, 0, s.hid3, nullptr, s.M, 2 * D, D, s.rpt,
@@ -911,10 +922,13 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
                     else x3_phase<X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
-                default: {
-                    const float* v = vecs(w[3], D, 2 * D);
-                    const X3Args a{s.hid3, w[3], v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, 2 * D, s.rpt,
-                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
+                default: {  // proj (ph & 3 == 1, A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
+                    const bool fc2 = (ph & 3) == 3;
+                    const int K = fc2 ? 2 * D : D;
+                    const char* w3 = fc2 ? w[3] : w[1];
+                    const float* v = vecs(w3, D, K);
+                    const X3Args a{fc2 ? s.hid3 : s.att3, w3, v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, K, s.rpt, s.n_tiles,
+                                   G, s.eps, 0, 0, s.dbg};
                     if (wv < 4) x3_phase<X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
                     else x3_phase<X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
@@ -957,7 +971,9 @@ int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, 
     const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
     X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, R, ldr, C, ldc, reinterpret_cast<char*>(C3), stats_out,
              M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load()};
-    const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0 && a.grid_m * a.grid_n > 256;
+    // two adjacent column groups per workgroup whenever the groups pair up (one A stage feeds two W stages): chosen by
+    // the SHAPE only, never by the row count, so that a row's arithmetic does not depend on the batch size
+    const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0;
     if (pair) a.grid_n /= 2;
     switch (epi) {
         case MPL_EPI_BIAS:
@@ -976,7 +992,7 @@ int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, 
 // The whole block stack in one launch (see x3_stack_kernel).  `ops` = n_apps x {qkv, proj, fc1, fc2} split operands.
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    hipStream_t s) {
+                    int stop_after, hipStream_t s) {
     if (!x || !ops || !x3 || !att3 || !hid3 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
         !x3_attention_fusable(n_tok, D, heads) || !x3_shape_ok(D, 2 * D) || M % n_tok)
         return MPL_E_INVALID;
@@ -1009,8 +1025,9 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     const int cap = resident[dev].load() / a.G;
     if (cap < 1) return MPL_E_UNSUPPORTED;
     a.n_teams = a.n_tiles < cap ? a.n_tiles : cap;
-    if (a.n_teams >= 8) a.n_teams &= ~7;    // whole XCD octets: a team then sits inside one XCD
+    if (a.n_teams * a.G > X3_MAX_WGS) a.n_teams = X3_MAX_WGS / a.G;
     a.n_apps = n_apps;
+    a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
     a.eps = eps;
     a.dbg = g_x3_dbg.load();
     for (int i = 0; i < n_apps; ++i)
@@ -1018,9 +1035,10 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
             if (!ops[4 * i + j]) return MPL_E_INVALID;
             a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
         }
+    // per-call state: the arrival counter of every row tile
     if (hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL(x3_stack_kernel, dim3(a.n_teams * a.G), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL(x3_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
     return hip_check_launch();
 }
 

@@ -34,7 +34,7 @@ torch.cuda.synchronize()
 # the LAST GEMM (fc2) after a full block; the others are reached by stacks truncated with an invalid later operand
 for upto, name in ((4, names[3]),):
     lib.mpl_x3_debug_buffer(dbg.data_ptr()); run(); torch.cuda.synchronize(); lib.mpl_x3_debug_buffer(None)
-    t = dbg.cpu().numpy().reshape(-1, 8)[:256 * 8, :7].astype(np.float64)
+    t = dbg.cpu().numpy().reshape(-1, 8)[:256 * 8, :8].astype(np.float64)
     t0 = t[:, 0].min()
     print("%-20s waves %d  entry spread %.0f | prologue %.0f | k loop %.0f (%.0f per stage) | epilogue to stores issued %.0f | drain %.0f | total %.0f  (shader-clock ticks, mean over waves; 100 MHz ticks if constant clock)"
           % (name, len(t), (t[:, 0] - t0).max(), (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 1]).mean(), (t[:, 2] - t[:, 1]).mean() / (2 * D // 32),
