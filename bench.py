@@ -306,7 +306,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
     io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
     weight_bytes = sum(p.numel() for p in model.parameters()) * 4
-    gemm_kernel = "x3_gemm_kernel" if split else "ln_gemm_ng_kernel"
+    gemm_kernel = ("x3_stack_kernel" if launches == 1 else "x3_gemm_kernel") if split else "ln_gemm_ng_kernel"
     # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
     # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
     traffic, traffic_src = None, None
@@ -322,10 +322,11 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     # algorithmic bytes of the mean GEMM launch: A + W operand + C (+ residual) once each
     M = a.batch * a.views
     w_bytes = 6.35 if split else 4.0        # split operand: 3 bf16 parts in 144/136-padded fragment order
-    alg_bytes = ((M * D * 4 + 3 * D * D * w_bytes + M * D * 4)            # LN1 + qkv + attention: x in, att out
-                 + (M * D * 4 + D * D * w_bytes + 2 * M * D * 4)           # proj: att in, x in/out
-                 + (M * D * 4 + 2 * D * D * w_bytes + M * 2 * D * 4)       # fc1: x in, hid out
-                 + (M * 2 * D * 4 + 2 * D * D * w_bytes + 2 * M * D * 4)) / 4.0   # fc2: hid in, x in/out
+    a_bytes = 6.0 if split else 4.0         # split engine: activations travel between the GEMMs as 3 bf16 parts
+    alg_bytes = ((M * D * a_bytes + 3 * D * D * w_bytes + M * D * a_bytes)                 # LN1 + qkv + attention: x in, att out
+                 + (M * D * a_bytes + D * D * w_bytes + 2 * M * D * 4 + (M * D * 6 if split else 0))    # proj: att in, x in/out (+ split x out)
+                 + (M * D * a_bytes + 2 * D * D * w_bytes + M * 2 * D * a_bytes)           # fc1: x in, hid out
+                 + (M * 2 * D * a_bytes + 2 * D * D * w_bytes + 2 * M * D * 4 + (M * D * 6 if split else 0))) / 4.0   # fc2: hid in, x in/out
     if split:
         # executed matrix-pipe work: 6 bf16 partial products per fp32 product on 144-column (9 x 16) tiles of 136
         ex = alg * 6.0 * 144.0 / 136.0
@@ -334,7 +335,9 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                     frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
                     arithmetic="fp32 GEMM: operands split exactly into 3 bf16 terms, 6 significant partial products per "
                                "fp32 product on the bf16 matrix cores (9 MFMA column tiles per 136 output columns), fp32 "
-                               "accumulation; `achieved` = algorithmic fp32 FLOPs x 6 x 144/136 = executed bf16 MFMA FLOP/s",
+                               "accumulation; `achieved` = algorithmic fp32 FLOPs x 6 x 144/136 = executed bf16 MFMA FLOP/s; "
+                               "one launch = every GEMM of the FPT block stack (persistent row-tile chains), its duration also "
+                               "contains the fused softmax attention, the operand splits and the LayerNorm statistics",
                     fp32_equivalent=dict(achieved=round(alg, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                                          frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                                          note="algorithmic fp32 FLOP/s against the fp32 matrix pipe this kernel does not use"))
@@ -345,16 +348,14 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     spt_ms, spt_n = prof["spt"]
     spt_fl = spt_flops_per_forward(flags, a.batch)
     spt_t = spt_fl / (spt_ms / max(1, spt_n) * 1e-3) / 1e12
-    kernels = [dict(kernel=gemm_kernel if launches > 1 else "x3_stack_kernel", launches_per_step=launches, gemms_per_launch=gemms // launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
-                    flops_per_launch=fl / launches, algorithmic_bytes_per_launch=round(alg_bytes * gemms / launches),
+    kernels = [dict(kernel=gemm_kernel, launches_per_step=launches, gemms_per_launch=gemms // launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
+                    flops_per_launch=fl / launches, algorithmic_bytes_per_launch=round(alg_bytes),
                     share_of_kernel_time=round(gemm_ms / sum(t for t, _ in prof.values()), 3)),
                dict(kernel="spt_kernel", launches_per_step=1, avg_launch_us=round(spt_ms / max(1, spt_n) * 1e3, 2),
                     flops_per_launch=spt_fl, bound="mfma", instruction="v_mfma_f32_16x16x4_f32 + VALU attention",
                     achieved=round(spt_t, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(spt_t / PEAK_FP32_MFMA_TFLOPS, 4),
                     share_of_kernel_time=round(spt_ms / sum(t for t, _ in prof.values()), 3))]
-    if launches == 1:
-        roof["kernel"] = "x3_stack_kernel"
     alg_bytes *= gemms / launches
     roof.update(traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(avg_launch_ms * 1e3, 2),
                 launches_per_step=launches, gemms_per_launch=gemms // launches, flops_per_launch=fl / launches,
