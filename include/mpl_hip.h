@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 4
+#define MPL_HIP_ABI_VERSION 5
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -76,10 +76,11 @@ typedef struct mpl_block_weights {
     const float *ln2_w, *ln2_b;
     const float *fc1_w, *fc1_b;
     const float *fc2_w, *fc2_b;
-    /* Optional bf16 copies ([out][in], round-to-nearest-even, see mpl_convert_bf16) of the four Linear weights.
-     * When all four are non-NULL in a block handed to mpl_block_stack / mpl_forward (FPT blocks only), that block's
-     * GEMMs run on the bf16 matrix cores (bf16 operands, fp32 accumulate; LayerNorm, softmax, GELU, residual and
-     * stored activations stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
+    /* Optional packed bf16 operands (mpl_pack_bf16) of the four Linear layers: qkv built with norm1 folded, fc1 with norm2
+     * folded, proj / fc2 plain.  When all four are non-NULL in every block of a stack whose shape the engine supports (D a
+     * multiple of 544, n_tok <= 32), the stack's GEMMs run on the bf16 matrix cores with bf16 operands and fp32
+     * accumulation (activations handed from GEMM to GEMM as bf16; LayerNorm statistics, softmax, GELU, the residual
+     * stream and the output stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
     const uint16_t *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;
     /* Optional split operands (mpl_split_bf16x3) of the four Linear layers: qkv built with norm1 folded, fc1 with norm2
      * folded, proj / fc2 plain.  When all four are non-NULL (and the *_w16 are NULL) in every block of a stack whose
@@ -163,9 +164,6 @@ int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *
                   const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
                   void *stream);
 
-/* dst[i] = bf16(src[i]) (round to nearest even): builds the optional *_w16 operands of mpl_block_weights. */
-int mpl_convert_bf16(const float *src, uint16_t *dst, size_t n, void *stream);
-
 /* Split operand of an nn.Linear layer (W[N][K], bias[N]) for the fp32-on-bf16-matrix-core GEMMs: three bf16 parts per
  * weight (hi + mid + lo == w exactly) in MFMA fragment order, followed by two fp32 vectors of N entries.  With
  * ln_w / ln_b != NULL the LayerNorm in front of the layer is folded in:  LN(x).W^T + b = rstd (x.(gamma o W)^T - mean s) + c,
@@ -181,6 +179,15 @@ int mpl_split_bf16x3(const float *W, const float *bias, const float *ln_w, const
 size_t mpl_ln_linear_x3_workspace_bytes(int M, int K);
 int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W3, int N, int epilogue,
                      const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same for the bf16 engine: ONE bf16 per weight (round to nearest even of gamma o W), K padded with zero k-tiles to a
+ * multiple of 96, the same fold vectors (s summed over the ROUNDED weights).  mpl_ln_linear_bf16: operands rounded to bf16
+ * (x before the folded LayerNorm is applied), products exact, fp32 accumulation; fp32 in, fp32 out. */
+size_t mpl_pack_bf16_bytes(int N, int K);
+int mpl_pack_bf16(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
+                  void *stream);
+int mpl_ln_linear_bf16(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W1, int N, int epilogue,
+                       const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Diagnostics (tools/x3_phase.py): when non-NULL, every split-operand GEMM launch writes five shader-clock stamps per
  * wave (entry, k-loop start, k-loop end, stores issued, stores drained) at device_buffer[(block * 8 + wave) * 8 ..];

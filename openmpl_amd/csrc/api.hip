@@ -83,35 +83,43 @@ X3Ws carve_x3_ws(void* base, size_t M, size_t D, int rpt) {
         off += align_up(bytes, 256);
         return p;
     };
-    w.x3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt)));
-    w.att3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt)));
-    w.hid3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)(2 * D), rpt)));
+    w.x3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt, 3)));
+    w.att3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt, 3)));
+    w.hid3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)(2 * D), rpt, 3)));
     w.stats = reinterpret_cast<float*>(take(M * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
     w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt + 1024) * sizeof(unsigned)));   // + X3_MAX_WGS placement words
     w.bytes = off;
     return w;
 }
 
-bool stack_uses_x3(const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps, int n_tok, int D, int H) {
-    if (!x3_attention_fusable(n_tok, D, H) || !x3_shape_ok(D, 2 * D)) return false;
+// 3 = every block carries split-fp32 operands, 1 = every block carries packed bf16 operands, 0 = neither (or the shape has
+// no packed layout): the stack then runs on the fp32 matrix instructions
+int stack_packed_parts(const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps, int n_tok, int D, int H) {
+    if (n_apps <= 0 || !x3_attention_fusable(n_tok, D, H) || !x3_shape_ok(D, 2 * D)) return 0;
+    int np = 0;
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        if (b.qkv_w16 || !(b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3)) return false;
+        const int bp = (b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16) ? 1 : ((b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3) ? 3 : 0);
+        if (bp == 0 || (np && bp != np)) return 0;
+        np = bp;
     }
-    return n_apps > 0;
+    return np;
 }
 
 // Block stack on split operands: per application LN1+qkv+attention | proj+residual | LN2+fc1+GELU | fc2+residual, the
 // activations handed from epilogue to k loop as A3 (x3 -> att3 -> x3 -> hid3 -> x3), x itself stays fp32 in place.
 int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
-                   int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
+                   int n_apps, void* ws, size_t ws_bytes, int np, hipStream_t s) {
     const int M = n_seq * n_tok, rpt = x3_rows_per_tile(n_tok);
     const X3Ws w = carve_x3_ws(ws, (size_t)M, (size_t)D, rpt);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     int rc;
     if ((rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
-    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, s))) return rc;
+    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, s))) return rc;
+    auto op = [&](const mpl_block_weights& b, int i) -> const uint16_t* {
+        return np == 3 ? (&b.qkv_w3)[i] : (&b.qkv_w16)[i];     // {qkv, proj, fc1, fc2} operands of the engine in use
+    };
     // A/B switch (mpl_x3_stack_mode, or MPL_X3_LAUNCHES=1 in the environment): one launch per GEMM -- the same phases with
     // kernel boundaries in between -- instead of the persistent row-tile chains
     if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
@@ -119,27 +127,27 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
         if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
         for (int a = 0; a < n_apps; ++a) {
             const mpl_block_weights& b = blocks[schedule[a]];
-            ops[4 * a + 0] = b.qkv_w3; ops[4 * a + 1] = b.proj_w3; ops[4 * a + 2] = b.fc1_w3; ops[4 * a + 3] = b.fc2_w3;
+            for (int i = 0; i < 4; ++i) ops[4 * a + i] = op(b, i);
         }
-        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), s);
+        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), np, s);
     }
     const int stop = g_x3_stop.load();
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
-        if ((rc = launch_x3_qkv_attention(w.x3, b.qkv_w3, w.stats, eps, M, D, n_tok, H, w.att3, s))) return rc;
+        if ((rc = launch_x3_qkv_attention(w.x3, op(b, 0), w.stats, eps, M, D, n_tok, H, w.att3, np, s))) return rc;
         if (stop && 4 * a + 1 >= stop) return MPL_OK;
-        if ((rc = launch_x3_gemm(w.att3, b.proj_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, D, rpt,
-                                 MPL_EPI_BIAS_RESIDUAL, s)))
+        if ((rc = launch_x3_gemm(w.att3, op(b, 1), false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, D, rpt,
+                                 MPL_EPI_BIAS_RESIDUAL, np, s)))
             return rc;
         if (stop && 4 * a + 2 >= stop) return MPL_OK;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
-        if ((rc = launch_x3_gemm(w.x3, b.fc1_w3, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid3, nullptr, M, 2 * D, D, rpt,
-                                 MPL_EPI_BIAS_GELU, s)))
+        if ((rc = launch_x3_gemm(w.x3, op(b, 2), true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid3, nullptr, M, 2 * D, D, rpt,
+                                 MPL_EPI_BIAS_GELU, np, s)))
             return rc;
         if (stop && 4 * a + 3 >= stop) return MPL_OK;
-        if ((rc = launch_x3_gemm(w.hid3, b.fc2_w3, false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, 2 * D, rpt,
-                                 MPL_EPI_BIAS_RESIDUAL, s)))
+        if ((rc = launch_x3_gemm(w.hid3, op(b, 3), false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, 2 * D, rpt,
+                                 MPL_EPI_BIAS_RESIDUAL, np, s)))
             return rc;
     }
     return MPL_OK;
@@ -152,8 +160,8 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
-    if (stack_uses_x3(blocks, schedule, n_apps, n_tok, D, H))
-        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, s);
+    if (const int np = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H))
+        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, s);
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
@@ -168,11 +176,9 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     const bool fusable = qkv_attention_fusable(n_tok, D, H);
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-            // bf16 matrix-core path for this block when the binding supplied bf16 weight copies (split operands take the
-        // block_stack_x3 route above)
-        const bool bf = b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16;
-        if (!bf && (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3)) return MPL_E_UNSUPPORTED;   // split operands this stack cannot use
-        const bool fused_att = fusable && !bf;
+            // packed operands (split fp32 / bf16) take the block_stack_x3 route above; here they cannot be used
+        if (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3 || b.qkv_w16 || b.proj_w16 || b.fc1_w16 || b.fc2_w16) return MPL_E_UNSUPPORTED;
+        const bool fused_att = fusable;
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         if (fused_att) {
@@ -180,20 +186,20 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
             if (rc) return rc;
         } else {
             rc = launch_ln_gemm(x, D, w.stats, b.ln1_w, b.ln1_b, eps, b.qkv_w, b.qkv_b, nullptr, 0, w.qkv, 3 * D, M,
-                                3 * D, D, MPL_EPI_BIAS, nullptr, s, bf ? b.qkv_w16 : nullptr);
+                                3 * D, D, MPL_EPI_BIAS, nullptr, s);
             if (rc) return rc;
             if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
         }
         rc = launch_ln_gemm(w.att, D, nullptr, nullptr, nullptr, 0.f, b.proj_w, b.proj_b, x, D, x, D, M, D, D,
-                            MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.proj_w16 : nullptr);
+                            MPL_EPI_BIAS_RESIDUAL, st_out, s);
         if (rc) return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
         if (!st_out && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
         rc = launch_ln_gemm(x, D, w.stats, b.ln2_w, b.ln2_b, eps, b.fc1_w, b.fc1_b, nullptr, 0, w.hid, 2 * D, M,
-                            2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s, bf ? b.fc1_w16 : nullptr);
+                            2 * D, D, MPL_EPI_BIAS_GELU, nullptr, s);
         if (rc) return rc;
         rc = launch_ln_gemm(w.hid, 2 * D, nullptr, nullptr, nullptr, 0.f, b.fc2_w, b.fc2_b, x, D, x, D, M, D,
-                            2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s, bf ? b.fc2_w16 : nullptr);
+                            2 * D, MPL_EPI_BIAS_RESIDUAL, st_out, s);
         if (rc) return rc;
         have_stats = st_out != nullptr;
     }
@@ -315,13 +321,22 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
                           (timing && !ln_w) ? stats : nullptr, s);
 }
 
-size_t mpl_split_bf16x3_bytes(int N, int K) { return x3_operand_bytes(N, K); }
+size_t mpl_split_bf16x3_bytes(int N, int K) { return x3_operand_bytes(N, K, 3); }
 
 int mpl_split_bf16x3(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst,
                      void* stream) {
     clear_stale_hip_error();
     if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
-    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
+    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 3, (hipStream_t)stream);
+}
+
+size_t mpl_pack_bf16_bytes(int N, int K) { return x3_operand_bytes(N, K, 1); }
+
+int mpl_pack_bf16(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst,
+                  void* stream) {
+    clear_stale_hip_error();
+    if (mpl_pack_bf16_bytes(N, K) == 0) return MPL_E_INVALID;
+    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 1, (hipStream_t)stream);
 }
 
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
@@ -335,13 +350,14 @@ int mpl_x3_debug_buffer(void* device_buffer) {
     return MPL_OK;
 }
 
-size_t mpl_ln_linear_x3_workspace_bytes(int M, int K) { return x3_act_bytes(M, K, 64); }
+size_t mpl_ln_linear_x3_workspace_bytes(int M, int K) { return x3_act_bytes(M, K, 64, 3); }
 
-int mpl_ln_linear_x3(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
-                     const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+static int ln_linear_packed(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
+                            const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, int np,
+                            void* stream) {
     clear_stale_hip_error();
-    if (!x || !W3 || !y || mpl_split_bf16x3_bytes(N, K) == 0 || M <= 0) return MPL_E_INVALID;
-    const size_t need = x3_act_bytes(M, K, 64);
+    if (!x || !W3 || !y || x3_operand_bytes(N, K, np) == 0 || M <= 0) return MPL_E_INVALID;
+    const size_t need = x3_act_bytes(M, K, 64, np);
     if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -350,13 +366,18 @@ int mpl_ln_linear_x3(const float* x, int M, int K, int has_ln, float eps, const 
         if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
     }
     unsigned short* a3 = reinterpret_cast<unsigned short*>(workspace);
-    if ((rc = launch_split_rows(x, M, K, K, 64, a3, s))) return rc;
-    return launch_x3_gemm(a3, W3, has_ln != 0, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
+    if ((rc = launch_split_rows(x, M, K, K, 64, a3, np, s))) return rc;
+    return launch_x3_gemm(a3, W3, has_ln != 0, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, np, s);
 }
 
-int mpl_convert_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
-    clear_stale_hip_error();
-    return launch_convert_bf16(src, dst, n, (hipStream_t)stream);
+int mpl_ln_linear_x3(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
+                     const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    return ln_linear_packed(x, M, K, has_ln, eps, W3, N, epilogue, residual, y, stats, workspace, workspace_bytes, 3, stream);
+}
+
+int mpl_ln_linear_bf16(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W1, int N, int epilogue,
+                       const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    return ln_linear_packed(x, M, K, has_ln, eps, W1, N, epilogue, residual, y, stats, workspace, workspace_bytes, 1, stream);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {

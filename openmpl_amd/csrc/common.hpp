@@ -65,31 +65,30 @@ int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStr
 // the rows it produced, so the next LN-GEMM needs no statistics pass.
 int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
                    const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
-                   int epi, float* stats_out, hipStream_t s, const unsigned short* W16 = nullptr);
-// fp32 -> bf16 (RNE) copy of a weight tensor for the bf16 matrix-core path
-int launch_convert_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t s);
+                   int epi, float* stats_out, hipStream_t s);
 bool qkv_attention_fusable(int n_tok, int dim, int heads);
 int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
                             float eps, const float* W, const float* bias, int n_tok, int heads, float* att,
                             hipStream_t s);
-// fp32 GEMMs on the bf16 matrix cores (3-way bf16 operand split, both operands pre-split in fragment order), x3_gemm.hip
+// GEMMs on the bf16 matrix cores from packed operands in fragment order, x3_gemm.hip.  np = 3: fp32 arithmetic (every
+// operand the exact sum of three bf16 parts, six partial products per product); np = 1: bf16 operands, one product.
 bool x3_shape_ok(int N, int K);
-size_t x3_operand_bytes(int N, int K);            // W3 + fold vectors; 0 when the shape has no split layout
-size_t x3_act_bytes(int M, int K, int rpt);       // A3 of M rows, K columns, rpt rows per row tile
+size_t x3_operand_bytes(int N, int K, int np);            // packed weights + fold vectors; 0 when the shape has no layout
+size_t x3_act_bytes(int M, int K, int rpt, int np);       // packed activations of M rows, K columns, rpt rows per row tile
 int x3_rows_per_tile(int n_tok);
 void x3_set_debug_buffer(unsigned long long* p);   // bench-only: per-wave phase stamps of every x3 GEMM launch
 bool x3_attention_fusable(int n_tok, int dim, int heads);
 int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
-                        unsigned short* dst, hipStream_t s);
-int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, hipStream_t s);
+                        unsigned short* dst, int np, hipStream_t s);
+int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, hipStream_t s);
 int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
-                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi,
+                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi, int np,
                    hipStream_t s);
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    int stop_after, hipStream_t s);
+                    int stop_after, int np, hipStream_t s);
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
-                            int n_tok, int heads, unsigned short* att3, hipStream_t s);
+                            int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
 // y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]

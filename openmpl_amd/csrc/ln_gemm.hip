@@ -803,184 +803,13 @@ int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, co
 }
 
 
-// ------------------------------------------------------------------------------------------
-// bf16 matrix-core variant (BASELINE.json configs[2], "CMU Panoptic ... bf16"): C = epi(LN(A) . W16^T + b) with
-// v_mfma_f32_16x16x32_bf16 -- bf16 operands, fp32 accumulate; LayerNorm, bias, GELU, residual and the stored
-// activations stay fp32.  A (fp32) is staged exactly as in the fp32 kernel and rounded to bf16 when the fragment is
-// built (after LayerNorm); W16 is a bf16 copy of the nn.Linear weight ([N][K], derived data owned by the binding).
-// One MFMA covers a whole 32-deep k-tile, so a k-tile costs a wave 9 MFMAs instead of 72: the kernel is bound by
-// staging, not by the matrix pipe.  Stage (18 KiB): A 64 x 128 B (swizzled) | W 9 column tiles x 1 KiB
-// ([16 rows][32 bf16], one DMA piece each, lane-linear = fragment order) | 1 KiB gamma, beta.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BF_SUB_B = NT * 1024;                 // 9216
-constexpr int BF_GB = SUB_A + BF_SUB_B;             // 17408
-constexpr int BF_STAGE = BF_GB + 1024;              // 18432
-constexpr int BF_NST = 2;
-
-template <int EPI, bool LN>
-__global__ __launch_bounds__(256, 2) void ln_gemm_bf16_kernel(const float* __restrict__ A, int lda,
-                                                               const float* __restrict__ stats,
-                                                               const float* __restrict__ ln_w,
-                                                               const float* __restrict__ ln_b,
-                                                               const unsigned short* __restrict__ W16,
-                                                               const float* __restrict__ bias, const float* R, int ldr,
-                                                               float* C, int ldc, int M, int N, int K, int grid_m,
-                                                               int grid_n, float eps, float* stats_out) {
-    __shared__ __attribute__((aligned(1024))) char smem[BF_NST * BF_STAGE];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, kq = lane >> 4;
-    int tm, tn;
-    {
-        const int b = blockIdx.x;
-        if ((grid_m & 7) == 0) {
-            const int per = grid_m >> 3;
-            const int xcd = b & 7, i = b >> 3;
-            tm = xcd * per + (i % per);
-            tn = i / per;
-        } else {
-            tm = b % grid_m;
-            tn = b / grid_m;
-        }
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const float* At = A + (size_t)m0 * lda;   // tile row base in the 64-bit DMA base (per-lane offsets tile relative)
-    float mu = 0.f, rs = 1.f;
-    if (LN) {
-        int m = m0 + wave * 16 + li;
-        m = m < M ? m : M - 1;
-        const int sl = (K % BN == 0) ? BN : K, ns = K / sl;
-        ln_combine(stats + (size_t)m * ns * 2, ns, sl, K, eps, mu, rs);
-        asm volatile("" : "+v"(mu), "+v"(rs));
-    }
-    if (!LN) {
-        for (int i = tid; i < BF_NST * 256; i += 256) reinterpret_cast<float*>(smem + (i >> 8) * BF_STAGE + BF_GB)[i & 255] = 0.f;
-        __syncthreads();
-    }
-    // DMA pieces per k-tile: 8 (A) + 9 (W16 column tiles) + 1 (gamma/beta).  wave w: A pieces w, w+4; W pieces w, w+4
-    // (+ piece 8 on wave 0); gamma/beta on wave 3.
-    unsigned voA[2], voW[3];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int r = (a * 4 + wave) * 8 + (lane >> 3);
-        int m = m0 + r;
-        m = m < M ? m : M - 1;
-        voA[a] = (unsigned)(((size_t)(m - m0) * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * sizeof(float));
-        asm volatile("" : "+v"(voA[a]));
-    }
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        int q = b * 4 + wave;
-        q = q < NT ? q : NT - 1;
-        int n = n0 + q * 16 + (lane >> 2);
-        n = n < N ? n : N - 1;
-        voW[b] = (unsigned)(((size_t)n * K + 8 * (lane & 3)) * sizeof(unsigned short));
-        asm volatile("" : "+v"(voW[b]));
-    }
-    const float* gb_src = ((lane & 8) ? ln_b : ln_w) + 4 * (lane & 7);
-    const bool w_extra = wave == 0, gb_on = LN && wave == 3;
-    const int per = 2 + 2 + (w_extra ? 1 : 0) + (gb_on ? 1 : 0);   // pieces of this wave per k-tile
-    const int T = K / BK;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const float* W16f = reinterpret_cast<const float*>(W16);   // dma16_fast only needs a byte address
-    auto issue = [&](int t) {
-        const unsigned keep = dma_m0_save();
-        const unsigned st = lds0 + (unsigned)((t % BF_NST) * BF_STAGE);
-        const int k0 = t * BK;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) dma16_fast(voA[a], At + k0, st + (unsigned)((a * 4 + wave) * 1024));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) dma16_fast(voW[b], W16f + k0 / 2, st + (unsigned)(SUB_A + (b * 4 + wave) * 1024));
-        if (w_extra) dma16_fast(voW[2], W16f + k0 / 2, st + (unsigned)(SUB_A + 8 * 1024));
-        if (gb_on) dma16(gb_src + k0, st + (unsigned)BF_GB);
-        dma_m0_restore(keep);
-    };
-    f32x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float rv[NT][4];
-    const int t_res = T >= 2 ? T - 2 : 0;
-    issue(0);
-    const int swz = (li >> 1) & 7;
-    for (int t = 0; t < T; ++t) {
-        int allow = 0;                                      // 2-stage ring: only this stage's pieces are in flight
-        if (EPI == MPL_EPI_BIAS_RESIDUAL && t > t_res) allow += RES_LOADS;
-        wait_vm(allow);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 1 < T) issue(t + 1);
-        if (EPI == MPL_EPI_BIAS_RESIDUAL && t == t_res) load_residual(rv, R, ldr, M, N, m0 + wave * 16 + 4 * kq, n0, li);
-        const char* st = smem + (t % BF_NST) * BF_STAGE;
-        // A fragment of 16x16x32: lane (i, kq) holds A[i][8 kq .. 8 kq + 7] = logical 16-B columns 2kq, 2kq+1
-        const float* as = reinterpret_cast<const float*>(st) + (wave * 16 + li) * BK;
-        float4 a0 = ld4(as + (((2 * kq) ^ swz) << 2)), a1 = ld4(as + (((2 * kq + 1) ^ swz) << 2));
-        bf16x8 bfrag[NT];
-        const bf16x8* bs = reinterpret_cast<const bf16x8*>(st + SUB_A) + (li * 4 + kq);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bfrag[n] = bs[n * 64];
-        if (LN) {
-            const float* gb = reinterpret_cast<const float*>(st + BF_GB);
-            const float4 g0 = ld4(gb + 8 * kq), g1 = ld4(gb + 8 * kq + 4), e0 = ld4(gb + 32 + 8 * kq), e1 = ld4(gb + 36 + 8 * kq);
-            a0.x = (a0.x - mu) * rs * g0.x + e0.x; a0.y = (a0.y - mu) * rs * g0.y + e0.y;
-            a0.z = (a0.z - mu) * rs * g0.z + e0.z; a0.w = (a0.w - mu) * rs * g0.w + e0.w;
-            a1.x = (a1.x - mu) * rs * g1.x + e1.x; a1.y = (a1.y - mu) * rs * g1.y + e1.y;
-            a1.z = (a1.z - mu) * rs * g1.z + e1.z; a1.w = (a1.w - mu) * rs * g1.w + e1.w;
-        }
-        bf16x8 af;
-        af[0] = (__bf16)a0.x; af[1] = (__bf16)a0.y; af[2] = (__bf16)a0.z; af[3] = (__bf16)a0.w;
-        af[4] = (__bf16)a1.x; af[5] = (__bf16)a1.y; af[6] = (__bf16)a1.z; af[7] = (__bf16)a1.w;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[n], acc[n], 0, 0, 0);
-    }
-    store_tile_epilogue<EPI>(acc, bias, rv, C, ldc, M, N, m0 + wave * 16 + 4 * kq, n0, li, stats_out, N / BN);
-}
-
-template <int EPI, bool LN>
-static int launch_bf16(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b,
-                       const unsigned short* W16, const float* bias, const float* R, int ldr, float* C, int ldc, int M,
-                       int N, int K, float eps, float* stats_out, hipStream_t s) {
-    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
-    ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((ln_gemm_bf16_kernel<EPI, LN>), dim3(gm * gn), dim3(256), 0, s, A, lda, stats, ln_w, ln_b, W16, bias,
-                       R, ldr, C, ldc, M, N, K, gm, gn, eps, stats_out);
-    return hip_check_launch();
-}
-
-// fp32 -> bf16 (round to nearest even) copy of a weight tensor: the derived operand of the bf16 kernels
-__global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (__bf16)src[i];
-}
-
-int launch_convert_bf16(const float* src, unsigned short* dst, size_t n, hipStream_t s) {
-    if (!src || !dst || n == 0) return MPL_E_INVALID;
-    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(convert_bf16_kernel, dim3(grid), dim3(256), 0, s, src, reinterpret_cast<__bf16*>(dst), n);
-    return hip_check_launch();
-}
-
 int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_w, const float* ln_b, float eps,
                    const float* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K,
-                   int epi, float* stats_out, hipStream_t s, const unsigned short* W16) {
+                   int epi, float* stats_out, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda & 3)) return MPL_E_INVALID;
     const bool ln = ln_w != nullptr;
     if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-    if (W16) {   // bf16 matrix cores (operands rounded to bf16, fp32 accumulate)
-        if (stats_out && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
-#define MPL_BF(E)                                                                                                     \
-    case E:                                                                                                           \
-        return ln ? launch_bf16<E, true>(A, lda, stats, ln_w, ln_b, W16, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s) \
-                  : launch_bf16<E, false>(A, lda, stats, ln_w, ln_b, W16, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s);
-        switch (epi) {
-            MPL_BF(MPL_EPI_BIAS)
-            MPL_BF(MPL_EPI_BIAS_GELU)
-            MPL_BF(MPL_EPI_BIAS_RESIDUAL)
-            default:
-                return MPL_E_INVALID;
-        }
-#undef MPL_BF
-    }
     static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
     if (stats_out && !timing && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
 #define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s

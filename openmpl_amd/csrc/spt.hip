@@ -260,42 +260,72 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         __syncthreads();
         stamp(0);
 
-        // ---- attention: thread per (row, head); 17 scores in registers (:55-64)
-        for (int pr = tid; pr < ROWS * SH && !(p.abl & 1); pr += NTHR) {
-            const int r = pr >> 3, h = pr & 7;
-            const int sq = r / SJ;
-            const float* kb = Q + (sq * SJ) * QS + SD + 4 * h;
-            const float4 q = ld4(Q + r * QS + 4 * h);
-            float sc[SJ];
-            float mx = -INFINITY;
+        // ---- attention (:55-64): thread = (sequence, head, group of 4-5 query rows) -- exactly 16 x 8 x 4 = 512 tasks.
+        // Every K and V row of the (sequence, head) is read from LDS ONCE per thread and used for all its query rows
+        // (the scores of 5 rows x 17 keys stay in registers): 34 ds_read_b128 per thread instead of 34 per (row, head)
+        // = 145 per thread.  The four row groups of a (sequence, head) sit in adjacent lanes and read the same
+        // addresses (broadcast); a 16-lane ds_read_b128 group touches 4 heads x 16 B: conflict free.
+        if (!(p.abl & 1)) {
+            const int rgp = tid & 3, h = (tid >> 2) & 7, sq = tid >> 5;
+            const int r0 = rgp == 0 ? 0 : 1 + 4 * rgp;          // rows 0..4 | 5..8 | 9..12 | 13..16 of the sequence
+            const int nr = rgp == 0 ? 5 : 4;
+            float* qb = Q + (sq * SJ) * QS + 4 * h;              // q rows (overwritten with the output), k at +SD, v at +2 SD
+            // two passes of up to 3 and 2 rows (the scores of 3 rows x 17 keys fit the register budget next to the
+            // prefetched weight fragments): K and V are read twice per thread, 68 reads
 #pragma unroll
-            for (int j = 0; j < SJ; ++j) {
-                const float4 k = ld4(kb + j * QS);
-                sc[j] = 0.5f * (fmaf(q.x, k.x, q.y * k.y) + fmaf(q.z, k.z, q.w * k.w));  // hd^-0.5 = 0.5
-                mx = fmaxf(mx, sc[j]);
-            }
-            float l = 0.f;
+            for (int half = 0; half < 2; ++half) {
+                constexpr int NRW = 3;
+                const int rb = r0 + 3 * half, cnt = half == 0 ? 3 : nr - 3;      // 3 | 2 (or 1) rows
+                float4 q[NRW];
 #pragma unroll
-            for (int j = 0; j < SJ; ++j) {
-                sc[j] = __expf(sc[j] - mx);
-                l += sc[j];
-            }
-            float inv = 1.0f / l;
-            if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales query row r
-                const int b = b0 + sq;
-                inv *= (b < p.B) ? pose[((size_t)b * SJ + (r - sq * SJ)) * 3 + 2] : 0.f;
-            }
-            float4 o = {0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < NRW; ++i) q[i] = ld4(qb + (rb + (i < cnt ? i : 0)) * QS);
+                float sc[NRW][SJ];
 #pragma unroll
-            for (int j = 0; j < SJ; ++j) {
-                const float4 v = ld4(kb + j * QS + SD);
-                const float pj = sc[j] * inv;
-                o.x = fmaf(pj, v.x, o.x);
-                o.y = fmaf(pj, v.y, o.y);
-                o.z = fmaf(pj, v.z, o.z);
-                o.w = fmaf(pj, v.w, o.w);
+                for (int j = 0; j < SJ; ++j) {
+                    if ((j & 3) == 0) asm volatile("" ::: "memory");   // keep the unrolled K / V loads from being hoisted en bloc
+                    const float4 k = ld4(qb + j * QS + SD);
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i)
+                        sc[i][j] = 0.5f * (fmaf(q[i].x, k.x, q[i].y * k.y) + fmaf(q[i].z, k.z, q[i].w * k.w));  // hd^-0.5 = 0.5
+                }
+                float inv[NRW];
+#pragma unroll
+                for (int i = 0; i < NRW; ++i) {
+                    float mx = sc[i][0];
+#pragma unroll
+                    for (int j = 1; j < SJ; ++j) mx = fmaxf(mx, sc[i][j]);
+                    float l = 0.f;
+#pragma unroll
+                    for (int j = 0; j < SJ; ++j) {
+                        sc[i][j] = __expf(sc[i][j] - mx);
+                        l += sc[i][j];
+                    }
+                    inv[i] = 1.0f / l;
+                    if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales query row r
+                        const int b = b0 + sq;
+                        inv[i] *= (b < p.B && i < cnt) ? pose[((size_t)b * SJ + (rb + i)) * 3 + 2] : 0.f;
+                    }
+                }
+                float4 o[NRW];
+#pragma unroll
+                for (int i = 0; i < NRW; ++i) o[i] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < SJ; ++j) {
+                    if ((j & 3) == 0) asm volatile("" ::: "memory");
+                    const float4 v = ld4(qb + j * QS + 2 * SD);
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) {
+                        const float pj = sc[i][j] * inv[i];
+                        o[i].x = fmaf(pj, v.x, o[i].x);
+                        o[i].y = fmaf(pj, v.y, o[i].y);
+                        o[i].z = fmaf(pj, v.z, o[i].z);
+                        o[i].w = fmaf(pj, v.w, o[i].w);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NRW; ++i)
+                    if (i < cnt) st4(qb + (rb + i) * QS, o[i]);   // overwrite q (only this thread ever reads these q rows)
             }
-            st4(Q + r * QS + 4 * h, o);  // overwrite q (only this thread ever reads it)
         }
         __syncthreads();
         stamp(1);

@@ -83,15 +83,31 @@ __host__ __device__ inline int x3_col(int t, int kq, int j, int G) {
 
 bool x3_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 * BN) == 0; }
 
-size_t x3_operand_bytes(int N, int K) {
+// NP = parts per operand element: 3 = fp32 as the exact sum of three bf16 (the fp32 engine), 1 = one bf16 (the bf16
+// engine, BASELINE.json configs[2]).  A STAGE of the k loop is 3 KiB per 16-row group of A and 27 KiB of W either way:
+// one k-tile of 32 in three parts, or three consecutive k-tiles in one part (K padded with zero k-tiles to a multiple of
+// 96) -- so both engines share the ring, the DMA schedule and the fragment reads, and differ in which fragments an MFMA
+// pairs (six part products of one k-tile / three k-tiles) and in how an epilogue packs its output.
+__host__ __device__ constexpr int x3_stages(int K, int NP) { return NP == 3 ? K / BK : (K / BK + 2) / 3; }
+// byte offset of (k-tile t, part p) inside the strip of a 16-row group of an A operand
+__host__ __device__ constexpr unsigned x3_frag_off(int t, int p, int NP) { return NP == 3 ? (unsigned)(t * X3_RG + p * 1024) : (unsigned)(t * 1024); }
+
+size_t x3_operand_bytes(int N, int K, int NP) {
     if (!x3_shape_ok(N, K)) return 0;
-    return (size_t)(N / BN) * (K / BK) * X3_W + (size_t)2 * N * sizeof(float);
+    return (size_t)(N / BN) * x3_stages(K, NP) * X3_W + (size_t)2 * N * sizeof(float);
 }
 
-size_t x3_act_bytes(int M, int K, int rpt) {
+size_t x3_act_bytes(int M, int K, int rpt, int NP) {
     if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
     const size_t tiles = ((size_t)M + rpt - 1) / rpt;
-    return tiles * 4 * (K / BK) * X3_RG;
+    return tiles * 4 * x3_stages(K, NP) * X3_RG;
+}
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const float (&x)[8]) {      // round to nearest even
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)x[i];
+    return v;
 }
 
 // 8 fp32 -> hi / mid / lo packed bf16 (RNE at every step; the residuals are exact in fp32)
@@ -110,36 +126,43 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& 
 }
 
 // ---------------------------------------------------------------------------------------------- weight operand
+template <int NP>
 __global__ __launch_bounds__(256) void split_w3_kernel(const float* __restrict__ W, const float* __restrict__ gamma, int N,
                                                         int K, bf16x8* __restrict__ dst, size_t total) {
-    const int KT = K / BK, G = K / BN;
+    const int G = K / BN, KS = x3_stages(K, NP), KTA = NP == 3 ? KS : 3 * KS;   // k-tiles incl. the zero padding of NP = 1
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int lane = (int)(idx & 63);
         const int slot = (int)((idx >> 6) % NT);
-        const int kt = (int)((idx / (64 * NT)) % KT);
-        const int g = (int)(idx / ((size_t)64 * NT * KT));
+        const int kt = (int)((idx / (64 * NT)) % KTA);
+        const int g = (int)(idx / ((size_t)64 * NT * KTA));
         const int li = lane & 15, kq = lane >> 4;
         const int c = x3_slot_tile(slot) * 16 + li;
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             x[j] = 0.f;
-            if (c < BN) {
+            if (c < BN && kt < K / BK) {
                 const int k = x3_col(kt, kq, j, G);
                 const float w = W[(size_t)(g * BN + c) * K + k];
                 x[j] = gamma ? w * gamma[k] : w;           // LayerNorm gain folded into the weight (one fp32 rounding)
             }
         }
-        bf16x8 hi, mid, lo;
-        split3(x, hi, mid, lo);
-        bf16x8* o = dst + ((size_t)(g * KT + kt) * 27 + slot * 3) * 64 + lane;
-        o[0] = hi;
-        o[64] = mid;
-        o[128] = lo;
+        if (NP == 3) {
+            bf16x8 hi, mid, lo;
+            split3(x, hi, mid, lo);
+            bf16x8* o = dst + ((size_t)(g * KS + kt) * 27 + slot * 3) * 64 + lane;
+            o[0] = hi;
+            o[64] = mid;
+            o[128] = lo;
+        } else {
+            dst[((size_t)(g * KS + kt / 3) * 27 + slot * 3 + kt % 3) * 64 + lane] = to_bf16x8(x);
+        }
     }
 }
 
-// fold vectors: c_n = bias_n + sum_k beta_k W_nk,  s_n = sum_k fl32(gamma_k W_nk)  (fp64 sums, one wave per n)
+// fold vectors: c_n = bias_n + sum_k beta_k W_nk,  s_n = sum_k of the (gamma_k W_nk) the operand holds -- fl32 for the
+// split operand, bf16 for the bf16 operand (fp64 sums, one wave per n)
+template <int NP>
 __global__ __launch_bounds__(256) void fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ bias,
                                                             int N, int K, float* __restrict__ cvec, float* __restrict__ svec) {
@@ -149,7 +172,8 @@ __global__ __launch_bounds__(256) void fold_vectors_kernel(const float* __restri
     if (gamma) {
         for (int k = lane; k < K; k += 64) {
             const float w = W[(size_t)n * K + k];
-            s += (double)(w * gamma[k]);
+            const float wg = w * gamma[k];
+            s += NP == 3 ? (double)wg : (double)(float)(__bf16)wg;
             c += (double)w * (double)beta[k];
         }
 #pragma unroll
@@ -164,53 +188,68 @@ __global__ __launch_bounds__(256) void fold_vectors_kernel(const float* __restri
     }
 }
 
-int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
-                        unsigned short* dst, hipStream_t s) {
-    if (!W || !dst || !bias || !x3_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr))) return MPL_E_INVALID;
-    const size_t total = (size_t)(N / BN) * (K / BK) * NT * 64;
+template <int NP>
+static int launch_pack(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
+                       hipStream_t s) {
+    const int KS = x3_stages(K, NP), KTA = NP == 3 ? KS : 3 * KS;
+    const size_t total = (size_t)(N / BN) * KTA * NT * 64;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_w3_kernel, dim3(grid), dim3(256), 0, s, W, ln_w, N, K, reinterpret_cast<bf16x8*>(dst), total);
-    float* vec = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * (K / BK) * X3_W);
-    hipLaunchKernelGGL(fold_vectors_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, vec, vec + N);
+    hipLaunchKernelGGL(split_w3_kernel<NP>, dim3(grid), dim3(256), 0, s, W, ln_w, N, K, reinterpret_cast<bf16x8*>(dst), total);
+    float* vec = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * KS * X3_W);
+    hipLaunchKernelGGL(fold_vectors_kernel<NP>, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, vec, vec + N);
     return hip_check_launch();
+}
+
+int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
+                        unsigned short* dst, int np, hipStream_t s) {
+    if (!W || !dst || !bias || !x3_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr)) || (np != 1 && np != 3))
+        return MPL_E_INVALID;
+    return np == 3 ? launch_pack<3>(W, N, K, ln_w, ln_b, bias, dst, s) : launch_pack<1>(W, N, K, ln_w, ln_b, bias, dst, s);
 }
 
 // ---------------------------------------------------------------------------------------------- activation operand
 // fp32 rows -> A3 (used for the rows that enter a block stack from outside: the SPT output, the unit-test entry)
+template <int NP>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int M, int K, int ldx, int rpt,
-                                                          bf16x8* __restrict__ dst, size_t total) {
-    const int KT = K / BK, G = K / BN;
+                                                          char* __restrict__ dst, size_t total) {
+    const int G = K / BN, KS = x3_stages(K, NP), KTA = NP == 3 ? KS : 3 * KS;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int lane = (int)(idx & 63);
-        const int kt = (int)((idx >> 6) % KT);
-        const size_t rgi = idx / ((size_t)64 * KT);          // tile * 4 + row group
+        const int kt = (int)((idx >> 6) % KTA);
+        const size_t rgi = idx / ((size_t)64 * KTA);          // tile * 4 + row group
         const int li = lane & 15, kq = lane >> 4;
         const int rl = (int)(rgi & 3) * 16 + li;
         const size_t row = (rgi >> 2) * rpt + rl;
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = 0.f;
-        if (rl < rpt && row < (size_t)M) {
+        if (rl < rpt && row < (size_t)M && kt < K / BK) {
             const float* src = X + row * ldx;
             const int c0 = x3_col(kt, kq, 0, G), c4 = x3_col(kt, kq, 4, G);
             const float4 p = ld4(src + c0), q = ld4(src + c4);
             x[0] = p.x; x[1] = p.y; x[2] = p.z; x[3] = p.w; x[4] = q.x; x[5] = q.y; x[6] = q.z; x[7] = q.w;
         }
-        bf16x8 hi, mid, lo;
-        split3(x, hi, mid, lo);
-        bf16x8* o = dst + (rgi * KT + kt) * 3 * 64 + lane;
-        o[0] = hi;
-        o[64] = mid;
-        o[128] = lo;
+        char* o = dst + rgi * KS * X3_RG + lane * 16;
+        if (NP == 3) {
+            bf16x8 hi, mid, lo;
+            split3(x, hi, mid, lo);
+            *reinterpret_cast<bf16x8*>(o + x3_frag_off(kt, 0, 3)) = hi;
+            *reinterpret_cast<bf16x8*>(o + x3_frag_off(kt, 1, 3)) = mid;
+            *reinterpret_cast<bf16x8*>(o + x3_frag_off(kt, 2, 3)) = lo;
+        } else {
+            *reinterpret_cast<bf16x8*>(o + x3_frag_off(kt, 0, 1)) = to_bf16x8(x);
+        }
     }
 }
 
-int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, hipStream_t s) {
-    if (!X || !dst || x3_act_bytes(M, K, rpt) == 0 || (ldx & 3)) return MPL_E_INVALID;
+int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, hipStream_t s) {
+    if (!X || !dst || x3_act_bytes(M, K, rpt, np) == 0 || (ldx & 3) || (np != 1 && np != 3)) return MPL_E_INVALID;
     const size_t tiles = ((size_t)M + rpt - 1) / rpt;
-    const size_t total = tiles * 4 * (K / BK) * 64;
+    const int KS = x3_stages(K, np), KTA = np == 3 ? KS : 3 * KS;
+    const size_t total = tiles * 4 * KTA * 64;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<bf16x8*>(dst), total);
+    if (np == 3) hipLaunchKernelGGL(split_rows_kernel<3>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total);
+    else hipLaunchKernelGGL(split_rows_kernel<1>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total);
     return hip_check_launch();
 }
 
@@ -270,6 +309,42 @@ __device__ __forceinline__ u32x4 ld16_l2(const void* base, unsigned off) {
 }
 // Attention.forward :55-64 on the q | k | v tile T[64][X3_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
 // channels: S whole sequences of nt tokens (rows S*nt.. are padding); output written as A3 of width Dq for proj.
+// pack 8 fp32 values of one fragment lane and store them as k-tile t of the strip at `base` (+ lane offset `lo`)
+template <int NP>
+__device__ __forceinline__ void emit_frag(bool wt, char* base, int t, unsigned lo, const float (&x)[8]) {
+    if (NP == 3) {
+        bf16x8 hi, mid, l3;
+        split3(x, hi, mid, l3);
+        st16(wt, base, x3_frag_off(t, 0, 3) + lo, hi);
+        st16(wt, base, x3_frag_off(t, 1, 3) + lo, mid);
+        st16(wt, base, x3_frag_off(t, 2, 3) + lo, l3);
+    } else {
+        st16(wt, base, x3_frag_off(t, 0, 1) + lo, to_bf16x8(x));
+    }
+}
+// the same for the 4 values (8 bytes) a lane contributes to the shared tail k-tile
+template <int NP>
+__device__ __forceinline__ void emit_tail(bool wt, char* base, int t, unsigned lo, const float (&x)[8]) {
+    if (NP == 3) {
+        bf16x8 hi, mid, l3;
+        split3(x, hi, mid, l3);
+        st8(wt, base, x3_frag_off(t, 0, 3) + lo, hi);
+        st8(wt, base, x3_frag_off(t, 1, 3) + lo, mid);
+        st8(wt, base, x3_frag_off(t, 2, 3) + lo, l3);
+    } else {
+        st8(wt, base, x3_frag_off(t, 0, 1) + lo, to_bf16x8(x));
+    }
+}
+// NP = 1: the k-tiles that pad the strip of row group `rg_strip` to whole stages are zero (read by the next GEMM)
+template <int NP>
+__device__ __forceinline__ void zero_pad_tiles(bool wt, char* strip, int Kout, int lane) {
+    if (NP == 1) {
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = Kout / BK; t < 3 * x3_stages(Kout, 1); ++t) st16(wt, strip, x3_frag_off(t, 0, 1) + lane * 16, to_bf16x8(z));
+    }
+}
+
+template <int NP>
 __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
                                              int g_out, int Dq) {
     const int hd4 = hd >> 2;
@@ -306,8 +381,9 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
     __syncthreads();
     // P.V and the A3 fragments of the output rows: task = (row, quarter p, lane quarter kq) -> 8 values = the two
     // 4-column chunks 32p + 4kq and 32p + 16 + 4kq; tail tasks (row, kq < 2) -> 4 values at 128 + 4kq
-    const int KTo = Dq / BK, Go = Dq / BN;
-    char* cbase = C3 + (size_t)tile_m * 4 * KTo * X3_RG;      // this row tile of the output operand (wave-uniform)
+    const int Go = Dq / BN;
+    const int strip = x3_stages(Dq, NP) * X3_RG;                 // bytes of one row group of the output operand
+    char* cbase = C3 + (size_t)tile_m * 4 * strip;               // this row tile of the output operand (wave-uniform)
     auto pv4 = [&](int row, int c) -> float4 {
         float4 o = {0.f, 0.f, 0.f, 0.f};
         if (row < S * nt) {
@@ -331,25 +407,16 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
         const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        bf16x8 hi, mid, lo;
-        split3(x, hi, mid, lo);
-        const unsigned o = (unsigned)((rg * KTo + (4 * g_out + p)) * X3_RG + (kq * 16 + li) * 16);
-        st16(WT, cbase, o, hi);
-        st16(WT, cbase, o + 1024, mid);
-        st16(WT, cbase, o + 2048, lo);
+        emit_frag<NP>(WT, cbase, 4 * g_out + p, (unsigned)(rg * strip + (kq * 16 + li) * 16), x);
     }
     for (int t = tid; t < BM * 2; t += 512) {
         const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 128 + 4 * kq);
         const float x[8] = {a.x, a.y, a.z, a.w, 0.f, 0.f, 0.f, 0.f};
-        bf16x8 hi, mid, lo;
-        split3(x, hi, mid, lo);
-        const unsigned o = (unsigned)((rg * KTo + (4 * Go + (g_out >> 2))) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8);
-        st8(WT, cbase, o, hi);
-        st8(WT, cbase, o + 1024, mid);
-        st8(WT, cbase, o + 2048, lo);
+        emit_tail<NP>(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(rg * strip + ((g_out & 3) * 16 + li) * 16 + kq * 8), x);
     }
+    if (NP == 1 && g_out == 0 && tid < 256) zero_pad_tiles<NP>(WT, cbase + (tid >> 6) * strip, Dq, tid & 63);
 }
 
 // One GEMM of one workgroup tile (tm, tn): everything a wave does for its NTW slots starting at slot `slot0`.
@@ -358,7 +425,7 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
 // arrivals, the A operand of this phase may be read once it reaches `chain_need`, and this workgroup arrives when its
 // outputs are written.  The W operand does not depend on the other workgroups: its first stages are requested BEFORE
 // the wait.
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
+template <int NP, int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
 __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = X3_NST;
@@ -371,7 +438,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     // NPASS = 2: two ADJACENT 136-column groups (tn counts pairs); NPASS = 3: the q, k, v slices of one group
     const int m0 = tm * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
     const int Dq = N / 3;
-    const int KT = K / BK;
+    const int KT = x3_stages(K, NP);             // stages per pass (k-tiles of 32 in three parts / triples of k-tiles)
     const int T = NPASS * KT;
     auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
     const unsigned long long t_entry = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -594,9 +661,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 b_nxt[n][2] = bs[(n * 3 + 2) * 64];
             }
         };
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[2], b_cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
         auto refill = [&]() {
             if (more && iw_t < T && !((X3_ABL & 2) && t > 0)) {   // stage t+NST into the slot of stage t
                 issue_w();
@@ -604,30 +668,55 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
             if (t == t_ops) epilogue_operands();
         };
-        if (!(X3_STAGGER && !HAS_A)) refill();
-        if (more && next_has_a && !(X3_ABL & 4)) read_a(slot_n, a_nxt);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[0], b_cur, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_b(0);
-        if (!next_has_a) rd_b(4);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[1], b_cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_b(1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[1], b_cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_b(2);
-        if (X3_STAGGER && !HAS_A) refill();
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[0], b_cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_b(3);
-        if (next_has_a) rd_b(4);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(accp, a_cur[0], b_cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NP == 3) {
+            mfma_row(accp, a_cur[2], b_cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(X3_STAGGER && !HAS_A)) refill();
+            if (more && next_has_a && !(X3_ABL & 4)) read_a(slot_n, a_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[0], b_cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(0);
+            if (!next_has_a) rd_b(4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[1], b_cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[1], b_cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(2);
+            if (X3_STAGGER && !HAS_A) refill();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[0], b_cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(3);
+            if (next_has_a) rd_b(4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[0], b_cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // bf16 engine: the three fragments of a stage are three consecutive k-tiles, one product each
+            mfma_row(accp, a_cur[0], b_cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(X3_STAGGER && !HAS_A)) refill();
+            if (more && next_has_a && !(X3_ABL & 4)) read_a(slot_n, a_nxt);
+            rd_b(0);
+            if (!next_has_a) rd_b(4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[1], b_cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(1);
+            rd_b(2);
+            if (X3_STAGGER && !HAS_A) refill();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(accp, a_cur[2], b_cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(3);
+            if (next_has_a) rd_b(4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         slot_c = slot_n;
     };
     if constexpr (NPASS == 1) {
@@ -735,10 +824,10 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        x3_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+        x3_attention<NP>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
     } else {
-        const int KTo = N / BK, Go = N / BN;
-        char* cbase = a.C3 + ((size_t)tm * 4 + rg) * KTo * X3_RG;   // this wave's row group of the output operand
+        const int Go = N / BN;
+        char* cbase = a.C3 + ((size_t)tm * 4 + rg) * x3_stages(N, NP) * X3_RG;   // this wave's row group of the output operand
         float vals[NTW][4];
 #pragma unroll
         for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
@@ -761,23 +850,13 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 for (int q = 0; q < 2; ++q) {
                     const float x[8] = {vals[2 * q][0], vals[2 * q][1], vals[2 * q][2], vals[2 * q][3],
                                         vals[2 * q + 1][0], vals[2 * q + 1][1], vals[2 * q + 1][2], vals[2 * q + 1][3]};
-                    bf16x8 hi, mid, lo;
-                    split3(x, hi, mid, lo);
-                    const int pq = (slot0 ? 2 : 0) + q;
-                    const unsigned o = (unsigned)((4 * g_out + pq) * X3_RG + lane * 16);
-                    st16(WT, cbase, o, hi);
-                    st16(WT, cbase, o + 1024, mid);
-                    st16(WT, cbase, o + 2048, lo);
+                    emit_frag<NP>(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
                 }
                 if (NTW == X3_T0 && kq < 2) {     // the half tile: 4 values per lane into the shared tail k-tile
                     const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
-                    bf16x8 hi, mid, lo;
-                    split3(x, hi, mid, lo);
-                    const unsigned o = (unsigned)((4 * Go + (g_out >> 2)) * X3_RG + ((g_out & 3) * 16 + li) * 16 + kq * 8);
-                    st8(WT, cbase, o, hi);
-                    st8(WT, cbase, o + 1024, mid);
-                    st8(WT, cbase, o + 2048, lo);
+                    emit_tail<NP>(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
                 }
+                if (NP == 1 && g_out == 0 && HAS_A) zero_pad_tiles<NP>(WT, cbase, N, lane);
             }
         }
         if (a.dbg) t_st = __builtin_amdgcn_s_memtime();
@@ -835,7 +914,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     }
 }
 
-template <int EPI, bool LNF, int NPASS>
+template <int NP, int EPI, bool LNF, int NPASS>
 __global__ __launch_bounds__(512, 2) void x3_gemm_kernel(const X3Args a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -853,8 +932,8 @@ __global__ __launch_bounds__(512, 2) void x3_gemm_kernel(const X3Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) x3_phase<EPI, LNF, NPASS, X3_T0, false>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else x3_phase<EPI, LNF, NPASS, NT - X3_T0, false>(a, smem, tid, wave, X3_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) x3_phase<NP, EPI, LNF, NPASS, X3_T0, false>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else x3_phase<NP, EPI, LNF, NPASS, NT - X3_T0, false>(a, smem, tid, wave, X3_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -876,6 +955,7 @@ struct X3StackArgs {
     const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
 };
 
+template <int NP>
 __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
@@ -891,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
         if (team >= s.n_teams) return;
     }
     auto vecs = [&](const char* w3, int N, int K) -> const float* {
-        return reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
+        return reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(K, NP) * X3_W);
     };
     // One loop over the 4 * n_apps GEMM phases of a row tile.  Every phase starts from OPAQUE copies of the thread id and
     // the tile index: nothing derived from them is loop invariant, so the compiler does not keep the address arithmetic
@@ -910,16 +990,16 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
                     const float* v = vecs(w[0], 3 * D, D);
                     const X3Args a{s.x3, w[0], v, v + 3 * D, s.stats, nullptr, 0, nullptr, 0, s.att3, nullptr, s.M, 3 * D, D, s.rpt,
                                    s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg};
-                    if (wv < 4) x3_phase<X3_EPI_ATT, true, 3, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    if (wv < 4) x3_phase<NP, X3_EPI_ATT, true, 3, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<NP, X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const X3Args a{s.x3, w[2], v, v + 2 * D, s.stats, nullptr, 0, nullptr, 0, s.hid3, nullptr, s.M, 2 * D, D, s.rpt,
                                    s.n_tiles, G, s.eps, 0, 0, s.dbg};
-                    if (wv < 4) x3_phase<X3_EPI_GELU, true, 2, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    if (wv < 4) x3_phase<NP, X3_EPI_GELU, true, 2, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<NP, X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (ph & 3 == 1, A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -929,8 +1009,8 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
                     const float* v = vecs(w3, D, K);
                     const X3Args a{fc2 ? s.hid3 : s.att3, w3, v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, K, s.rpt, s.n_tiles,
                                    G, s.eps, 0, 0, s.dbg};
-                    if (wv < 4) x3_phase<X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                    if (wv < 4) x3_phase<NP, X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else x3_phase<NP, X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
             }
@@ -938,7 +1018,7 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
     }
 }
 
-template <int EPI, bool LNF, int NPASS>
+template <int NP, int EPI, bool LNF, int NPASS>
 static int launch_x3(const X3Args& a, hipStream_t s) {
     constexpr int LDS = X3_NST * X3_STAGE;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
@@ -946,70 +1026,84 @@ static int launch_x3(const X3Args& a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)x3_gemm_kernel<EPI, LNF, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute((const void*)x3_gemm_kernel<NP, EPI, LNF, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess)
             return MPL_E_LAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
     ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL((x3_gemm_kernel<EPI, LNF, NPASS>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((x3_gemm_kernel<NP, EPI, LNF, NPASS>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);
     return hip_check_launch();
 }
 
-// C (fp32, optional) and / or C3 (A3 of width N, optional) = epi( LN?(A) . W^T + bias ) from split operands.
-// ln: the weight operand was built with LayerNorm folded (launch_split_bf16x3 with ln_w) and `stats` holds the slice
-// partials of the K-wide rows behind A3.  rpt = rows per row tile of A3 (and of C3).
-int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
-                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi,
-                   hipStream_t s) {
-    if (M <= 0 || !A3 || !W3 || (!C && !C3) || !x3_shape_ok(N, K) || rpt <= 0 || rpt > BM) return MPL_E_INVALID;
-    if (ln && !stats) return MPL_E_INVALID;
-    if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-    if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
-    if (C3 && N % (4 * BN)) return MPL_E_INVALID;           // an A3 output must itself be a valid operand width
-    const char* w3 = reinterpret_cast<const char*>(W3);
-    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (K / BK) * X3_W);
-    X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, R, ldr, C, ldc, reinterpret_cast<char*>(C3), stats_out,
-             M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load()};
+// C (fp32, optional) and / or C3 (operand of width N for the next GEMM, optional) = epi( LN?(A) . W^T + bias ) from
+// packed operands (np = 3: split fp32, np = 1: bf16).  ln: the weight operand was built with LayerNorm folded
+// (launch_split_bf16x3 with ln_w) and `stats` holds the slice partials of the K-wide rows behind A3.  rpt = rows per
+// row tile of A3 (and of C3).
+template <int NP>
+static int launch_x3_gemm_np(const X3Args& a0, bool ln, int epi, hipStream_t s) {
+    X3Args a = a0;
     // two adjacent column groups per workgroup whenever the groups pair up (one A stage feeds two W stages): chosen by
     // the SHAPE only, never by the row count, so that a row's arithmetic does not depend on the batch size
     const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0;
     if (pair) a.grid_n /= 2;
     switch (epi) {
         case MPL_EPI_BIAS:
-            if (pair) return ln ? launch_x3<X3_EPI_BIAS, true, 2>(a, s) : launch_x3<X3_EPI_BIAS, false, 2>(a, s);
-            return ln ? launch_x3<X3_EPI_BIAS, true, 1>(a, s) : launch_x3<X3_EPI_BIAS, false, 1>(a, s);
+            if (pair) return ln ? launch_x3<NP, X3_EPI_BIAS, true, 2>(a, s) : launch_x3<NP, X3_EPI_BIAS, false, 2>(a, s);
+            return ln ? launch_x3<NP, X3_EPI_BIAS, true, 1>(a, s) : launch_x3<NP, X3_EPI_BIAS, false, 1>(a, s);
         case MPL_EPI_BIAS_GELU:
-            if (pair) return ln ? launch_x3<X3_EPI_GELU, true, 2>(a, s) : launch_x3<X3_EPI_GELU, false, 2>(a, s);
-            return ln ? launch_x3<X3_EPI_GELU, true, 1>(a, s) : launch_x3<X3_EPI_GELU, false, 1>(a, s);
+            if (pair) return ln ? launch_x3<NP, X3_EPI_GELU, true, 2>(a, s) : launch_x3<NP, X3_EPI_GELU, false, 2>(a, s);
+            return ln ? launch_x3<NP, X3_EPI_GELU, true, 1>(a, s) : launch_x3<NP, X3_EPI_GELU, false, 1>(a, s);
         case MPL_EPI_BIAS_RESIDUAL:
-            return ln ? launch_x3<X3_EPI_RES, true, 1>(a, s) : launch_x3<X3_EPI_RES, false, 1>(a, s);
+            return ln ? launch_x3<NP, X3_EPI_RES, true, 1>(a, s) : launch_x3<NP, X3_EPI_RES, false, 1>(a, s);
         default:
             return MPL_E_INVALID;
     }
 }
 
-// The whole block stack in one launch (see x3_stack_kernel).  `ops` = n_apps x {qkv, proj, fc1, fc2} split operands.
-int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
-                    unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    int stop_after, hipStream_t s) {
-    if (!x || !ops || !x3 || !att3 || !hid3 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
-        !x3_attention_fusable(n_tok, D, heads) || !x3_shape_ok(D, 2 * D) || M % n_tok)
-        return MPL_E_INVALID;
+int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
+                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi, int np,
+                   hipStream_t s) {
+    if (M <= 0 || !A3 || !W3 || (!C && !C3) || !x3_shape_ok(N, K) || rpt <= 0 || rpt > BM || (np != 1 && np != 3)) return MPL_E_INVALID;
+    if (ln && !stats) return MPL_E_INVALID;
+    if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
+    if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
+    if (C3 && N % (4 * BN)) return MPL_E_INVALID;           // an operand output must itself be a valid operand width
+    const char* w3 = reinterpret_cast<const char*>(W3);
+    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(K, np) * X3_W);
+    const X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, R, ldr, C, ldc, reinterpret_cast<char*>(C3), stats_out,
+                   M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load()};
+    return np == 3 ? launch_x3_gemm_np<3>(a, ln, epi, s) : launch_x3_gemm_np<1>(a, ln, epi, s);
+}
+
+// The whole block stack in one launch (see x3_stack_kernel).  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands.
+template <int NP>
+static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
     constexpr int LDS = X3_NST * X3_STAGE;
     static std::atomic<bool> attr_set[64];
-    static std::atomic<int> resident[64];   // workgroups of this kernel the device holds at once
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)x3_stack_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MPL_E_LAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL(x3_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
+    return hip_check_launch();
+}
+
+int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
+                    unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
+                    int stop_after, int np, hipStream_t s) {
+    if (!x || !ops || !x3 || !att3 || !hid3 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
+        !x3_attention_fusable(n_tok, D, heads) || !x3_shape_ok(D, 2 * D) || M % n_tok || (np != 1 && np != 3))
+        return MPL_E_INVALID;
+    static std::atomic<int> resident[64];   // workgroups of this kernel the device holds at once (0 = not asked yet)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)x3_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return MPL_E_LAUNCH;
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)x3_stack_kernel, 512, LDS) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
-            return MPL_E_LAUNCH;
-        resident[dev].store(cus);            // the 156 KiB ring admits one workgroup per CU whatever the API answers
-        attr_set[dev].store(true, std::memory_order_release);
+    if (!resident[dev].load(std::memory_order_acquire)) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+        resident[dev].store(cus, std::memory_order_release);   // the 156 KiB ring admits exactly one workgroup per CU
     }
     X3StackArgs a;
     a.x3 = reinterpret_cast<char*>(x3);
@@ -1037,9 +1131,7 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
         }
     // per-call state: the arrival counter of every row tile
     if (hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
-    ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL(x3_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
-    return hip_check_launch();
+    return np == 3 ? launch_stack_np<3>(a, dev, s) : launch_stack_np<1>(a, dev, s);
 }
 
 // rows per tile for the fused attention: whole sequences of n_tok tokens in at most 64 rows
@@ -1055,14 +1147,15 @@ bool x3_attention_fusable(int n_tok, int dim, int heads) {
 
 // LN1 + qkv projection + softmax attention in one launch: att3 (A3 of width D) from x3 (A3 of width D)
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
-                            int n_tok, int heads, unsigned short* att3, hipStream_t s) {
-    if (!x3_attention_fusable(n_tok, D, heads) || !A3 || !W3 || !stats || !att3 || M <= 0 || M % n_tok) return MPL_E_INVALID;
+                            int n_tok, int heads, unsigned short* att3, int np, hipStream_t s) {
+    if (!x3_attention_fusable(n_tok, D, heads) || !A3 || !W3 || !stats || !att3 || M <= 0 || M % n_tok || (np != 1 && np != 3))
+        return MPL_E_INVALID;
     const int N = 3 * D, rpt = x3_rows_per_tile(n_tok);
     const char* w3 = reinterpret_cast<const char*>(W3);
-    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * (D / BK) * X3_W);
+    const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(D, np) * X3_W);
     X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att3),
              nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_x3_dbg.load()};
-    return launch_x3<X3_EPI_ATT, true, 3>(a, s);
+    return np == 3 ? launch_x3<3, X3_EPI_ATT, true, 3>(a, s) : launch_x3<1, X3_EPI_ATT, true, 3>(a, s);
 }
 
 }  // namespace mpl

@@ -247,12 +247,14 @@ class MultiView_MPL(nn.Module):
             bf16 terms (csrc/x3_gemm.hip: at least as accurate as an fp32 multiply, 2.7x less matrix-pipe time on
             gfx950); other widths (KPTOK, D = 32) use the native fp32 MFMA kernels;
         "fp32_mfma" -- native fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere;
-        "bf16" -- bf16 operands (one rounding to bf16), fp32 accumulate: BASELINE.json configs[2].
+        "bf16" -- the same engine with ONE bf16 per operand element: operands rounded to bf16 (activations when a GEMM
+            epilogue hands them to the next GEMM, weights with the LayerNorm gain folded in), exact products, fp32
+            accumulation; statistics, softmax, GELU and the residual stream stay fp32: BASELINE.json configs[2].
         The split / bf16 weight copies are derived data, rebuilt whenever a parameter's storage or version changes."""
         if precision not in ("fp32", "fp32_mfma", "bf16"):
             raise ValueError("matmul precision must be 'fp32', 'fp32_mfma' or 'bf16'")
-        if precision == "bf16" and self.FPT_blocks_view_keypoint_tokens:
-            raise NotImplementedError("bf16 matrix-core path covers the view-token FPT blocks (K a multiple of 32 and 8)")
+        if precision == "bf16" and not self._x3_supported():
+            raise NotImplementedError("the bf16 engine covers the view-token FPT blocks (widths 544 / 1088, up to 32 views)")
         self.matmul_precision = precision
         self._hip_cache = {}
         return self
@@ -341,7 +343,7 @@ class MultiView_MPL(nn.Module):
         cache stays valid under in-place updates; it is rebuilt whenever any storage address changes."""
         plist = self._param_list()
         key = tuple(map(torch.Tensor.data_ptr, plist))
-        bf16 = self.matmul_precision == "bf16" and not self._dp_replica
+        bf16 = self.matmul_precision == "bf16" and not self._dp_replica and self._x3_supported()
         x3 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
         if bf16 or x3:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
@@ -379,23 +381,17 @@ class MultiView_MPL(nn.Module):
         w16_keep = []
         for l, b in enumerate(self.blocks):
             ptrs = [_ptr(t) for t in self._block_ptrs(b)]
-            if bf16:
+            if bf16 or x3:
                 lib = cabi.load()
-                for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight):
-                    c16 = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
-                    cabi.check(lib.mpl_convert_bf16(t.data_ptr(), c16.data_ptr(), t.numel(),
-                                                    torch.cuda.current_stream(device).cuda_stream), "mpl_convert_bf16")
-                    w16_keep.append(c16)
-                    ptrs.append(c16.data_ptr())
-            elif x3:
-                lib = cabi.load()
-                ptrs += [0, 0, 0, 0]
+                nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else (lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3)
+                if x3:
+                    ptrs += [0, 0, 0, 0]
                 for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
                     n, k = lin.weight.shape
-                    c3 = torch.empty(lib.mpl_split_bf16x3_bytes(n, k), dtype=torch.uint8, device=device)
-                    cabi.check(lib.mpl_split_bf16x3(lin.weight.data_ptr(), lin.bias.data_ptr(), _ptr(ln.weight if ln else None),
-                                                    _ptr(ln.bias if ln else None), n, k, c3.data_ptr(),
-                                                    torch.cuda.current_stream(device).cuda_stream), "mpl_split_bf16x3")
+                    c3 = torch.empty(nbytes(n, k), dtype=torch.uint8, device=device)
+                    cabi.check(pack(lin.weight.data_ptr(), lin.bias.data_ptr(), _ptr(ln.weight if ln else None),
+                                    _ptr(ln.bias if ln else None), n, k, c3.data_ptr(),
+                                    torch.cuda.current_stream(device).cuda_stream), "pack operand")
                     w16_keep.append(c3)
                     ptrs.append(c3.data_ptr())
             fpt[l] = cabi.BlockWeights(*ptrs)

@@ -64,10 +64,6 @@ _BF16_PREFIXES = ()   # set by forward(fpt_matmul_bf16=True): Linear layers whos
 
 def _lin(x, sd, prefix):
     w = sd[prefix + ".weight"]
-    if _BF16_PREFIXES and prefix.startswith(_BF16_PREFIXES):
-        # emulation of the bf16 matrix-core path: operands rounded to bf16 (RNE), products and sums in >= fp32
-        x = x.to(torch.bfloat16).to(x.dtype)
-        w = w.to(torch.bfloat16).to(w.dtype)
     return F.linear(x, w, sd[prefix + ".bias"])
 
 
@@ -94,8 +90,43 @@ def mlp(x, sd, prefix):
     return _lin(F.gelu(_lin(x, sd, prefix + ".fc1")), sd, prefix + ".fc2")
 
 
+def _bf(t):
+    """Round to bf16 (nearest even) and back: the operand rounding of the bf16 engine."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _ln_linear_bf16(x, sd, ln_prefix, lin_prefix, eps):
+    """LayerNorm + Linear as openmpl_amd's bf16 engine computes it (csrc/x3_gemm.hip, NP = 1): the LayerNorm is folded
+    into the GEMM, LN(x).W^T + b = rstd (x.(gamma o W)^T - mean s) + c, with the operands x and gamma o W rounded to bf16,
+    s summed over the rounded weights, products and sums exact (here: in the evaluation dtype)."""
+    W, b = sd[lin_prefix + ".weight"], sd[lin_prefix + ".bias"]
+    g, e = sd[ln_prefix + ".weight"], sd[ln_prefix + ".bias"]
+    mu = x.mean(-1, keepdim=True)
+    rs = 1.0 / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + eps)
+    Wp = _bf((W.float() * g.float()[None, :]).to(W.dtype))       # the kernel multiplies in fp32, then rounds to bf16
+    s = Wp.sum(1)
+    c = W @ e + b
+    return rs * (_bf(x) @ Wp.T - mu * s) + c
+
+
+def block_bf16(x, sd, prefix, num_heads):
+    """Block.forward with the FPT GEMMs as the bf16 engine runs them: statistics, softmax, GELU and the residual stream
+    in full precision; the four Linear layers see bf16 operands (activations rounded when handed to the next GEMM)."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    qkv = _ln_linear_bf16(x, sd, prefix + ".norm1", prefix + ".attn.qkv", LN_EPS_BLOCK)
+    qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    att = ((qkv[0] @ qkv[1].transpose(-2, -1)) * (hd ** -0.5)).softmax(dim=-1)
+    y = (att @ qkv[2]).transpose(1, 2).reshape(B, N, C)
+    x = x + _bf(y) @ _bf(sd[prefix + ".attn.proj.weight"]).T + sd[prefix + ".attn.proj.bias"]
+    h = F.gelu(_ln_linear_bf16(x, sd, prefix + ".norm2", prefix + ".mlp.fc1", LN_EPS_BLOCK))
+    return x + _bf(h) @ _bf(sd[prefix + ".mlp.fc2.weight"]).T + sd[prefix + ".mlp.fc2.bias"]
+
+
 def block(x, sd, prefix, num_heads, row_weights=None):
     """Block.forward, multiview_mpl.py:84-92 (DropPath/Dropout are identity in eval)."""
+    if _BF16_PREFIXES and prefix.startswith(_BF16_PREFIXES) and row_weights is None:
+        return block_bf16(x, sd, prefix, num_heads)
     x = x + attention(_ln(x, sd, prefix + ".norm1", LN_EPS_BLOCK), sd, prefix + ".attn", num_heads, row_weights)
     x = x + mlp(_ln(x, sd, prefix + ".norm2", LN_EPS_BLOCK), sd, prefix + ".mlp")
     return x
@@ -235,8 +266,8 @@ def forward(sd: Dict[str, torch.Tensor], flags: Optional[dict], poses: Sequence[
     ``sd`` may carry the ``features.`` prefix of MultiView_MPL_G (multiview_mpl.py:552).
     Returns (B,J,3) -- or ((B,J,3), [x1,x2]) for the kadkhod head.
 
-    ``fpt_matmul_bf16`` emulates MultiView_MPL.set_matmul_precision("bf16"): the four Linear layers of every FPT
-    block see bf16-rounded operands (fp32-or-better accumulation), everything else is unchanged.
+    ``fpt_matmul_bf16`` emulates MultiView_MPL.set_matmul_precision("bf16") with the engine's own rounding points
+    (block_bf16): the four Linear layers of every FPT block see bf16-rounded operands, everything else is unchanged.
     """
     global _BF16_PREFIXES
     _BF16_PREFIXES = ("blocks.",) if fpt_matmul_bf16 else ()

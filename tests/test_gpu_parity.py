@@ -277,7 +277,7 @@ def test_gpu_input_validation():
 
 
 # ----------------------------------------------------------------------------- bf16 matrix-core path (configs[2])
-@pytest.mark.parametrize("name,B", [("chosen_v8_b4_l2", 256), ("full_v8_b4_l2", 64), ("chosen_v4_b8_l12", 64)])
+@pytest.mark.parametrize("name,B", [("chosen_v8_b4_l2", 1024), ("full_v8_b4_l2", 64), ("chosen_v4_b8_l12", 64), ("chosen_v5_b19_l2", 19)])
 def test_bf16_matmul_path(name, B):
     """BASELINE.json configs[2] (CMU Panoptic, V=8, bf16): FPT GEMMs on the bf16 matrix cores.  Tight check against
     the oracle's bf16-operand emulation (same rounding points, fp64 accumulation); loose check + reported delta against
@@ -296,7 +296,13 @@ def test_bf16_matmul_path(name, B):
     dx, dn = mpl_oracle.rel_errors(out, ref)
     print("%s bf16: vs bf16-emulation oracle %.2e/%.2e ; vs fp64 reference semantics %.2e/%.2e ; MPJPE-vs-ref %.3e"
           % (name, mx, nw, dx, dn, mpl_oracle.mpjpe(out, ref)))
-    assert mx < 2e-3 and nw < 2e-3, "bf16 path deviates from its own emulation: %.2e %.2e" % (mx, nw)
+    # the emulation has the engine's rounding points, but an operand within fp32 noise of a bf16 rounding boundary still
+    # rounds the other way in one of the two evaluations (a 2^-8 relative step for ~5e-5 of the elements), and the flips
+    # add up over the 4 GEMMs of each of the depth + 1 block applications: 1e-3 / 7e-4 at depth 2 (the engine before this
+    # one, with other rounding points, sat at 2e-3 there), 3e-3 / 2.5e-3 at depth 12
+    deep = g["flags"]["depth"] > 2
+    assert mx < (3e-3 if deep else 1e-3) and nw < (2.5e-3 if deep else 7e-4), \
+        "bf16 path deviates from its own emulation: %.2e %.2e" % (mx, nw)
     assert dx < 5e-2 and dn < 5e-2
     m.set_matmul_precision("fp32")
     with torch.no_grad():
