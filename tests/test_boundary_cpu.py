@@ -124,8 +124,11 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     cfg = cabi.Config(17, 32, 12, 8, 4, 2, cabi.F_POS3D_LEARN, 0)
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 544
     M, D = 1024 * 4, 544
-    want = M * D * 4 + M * 3 * D * 4 + M * D * 4 + M * 2 * D * 4 + M * 2 * (D // 136) * 4   # xs|qkv|att|hid|LN partials
-    assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == want
+    # fp32-MFMA engine: xs | qkv | att | hid | LN partials;  packed-operand engines: xs | x3 | att3 | hid3 (6 B per
+    # element, 64-row tiles) | LN partials | one arrival counter per row tile (+ 1024 spare words): the larger one
+    want32 = M * D * 4 + M * 3 * D * 4 + M * D * 4 + M * 2 * D * 4 + M * 2 * (D // 136) * 4
+    want3 = M * D * 4 + 4 * M * D * 6 + M * 2 * (D // 136) * 4 + (M // 64 + 1024) * 4
+    assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == max(want32, want3)
     cfg.flags |= cabi.F_RAYS_TOKEN
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
     assert ctypes.sizeof(cabi.BlockWeights) == 160 and ctypes.sizeof(cabi.SptSet) == 48
@@ -139,6 +142,9 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     # split activations: 3 KiB per (16-row group, k-tile), row tiles padded to 64 rows
     assert lib.mpl_ln_linear_x3_workspace_bytes(4096, 544) == 64 * 4 * 17 * 3072
     assert lib.mpl_ln_linear_x3_workspace_bytes(65, 1088) == 2 * 4 * 34 * 3072
+    # bf16 operands: one bf16 per element, K padded to whole stages of three k-tiles (544 -> 18 k-tiles = 6 stages)
+    assert lib.mpl_pack_bf16_bytes(1632, 544) == 12 * 6 * 27 * 1024 + 8 * 1632
+    assert lib.mpl_pack_bf16_bytes(544, 1088) == 4 * 12 * 27 * 1024 + 8 * 544 and lib.mpl_pack_bf16_bytes(544, 100) == 0
 
 
 def test_detrng_is_stable():
