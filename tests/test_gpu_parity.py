@@ -183,11 +183,26 @@ def test_kptok_large_view_stress():
         out = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn])
     ref = mpl_oracle.forward(sd, flags, P, R, Cn, dtype=torch.float64)
     _assert_close(out, ref, "kptok V=31")
+    # configs[4] at its full batch (256 poses = 134 912 tokens): the first and last 4 poses against the fp64 oracle
+    # (the whole batch would take the CPU oracle minutes), the rest through batch-split invariance (bitwise)
+    p, r, c = detrng.make_inputs(256, 31, seed=5)
+    P, R, Cn = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    with torch.no_grad():
+        big = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn])
+        for sl in (slice(0, 4), slice(252, 256), slice(100, 131)):
+            part = m([x[sl].contiguous().to(DEV) for x in P], rays=[x[sl].contiguous().to(DEV) for x in R],
+                     centers=[x[sl].contiguous().to(DEV) for x in Cn])
+            assert torch.equal(big[sl], part), "kptok: batch slice changed results"
+    for sl in (slice(0, 4), slice(252, 256)):
+        ref = mpl_oracle.forward(sd, flags, [x[sl] for x in P], [x[sl] for x in R], [x[sl] for x in Cn], dtype=torch.float64)
+        _assert_close(big[sl], ref, "kptok V=31 B=256")
 
 
-@pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 1024), ("full_v4_b8_l12", 256)])
+@pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 1024), ("full_v4_b8_l12", 1024), ("chosen_v8_b4_l2", 1024),
+                                    ("chosen_v31_b2_l12", 256)])
 def test_full_size_batch_against_oracle(name, B):
-    """BASELINE.json configs[1] (V=4, J=17, batch 1024, fp32): HIP vs the oracle (fp32 CPU and fp64 CPU)."""
+    """BASELINE.json configs[1] (V=4, J=17, batch 1024, fp32; both shipped flag sets), configs[2]'s shape in fp32 (V=8,
+    batch 1024) and configs[4] (V=31, batch 256) at FULL size: HIP vs the oracle (fp32 CPU and fp64 CPU)."""
     m, g = _model(name)
     V = g["flags"]["num_views"]
     p, r, c = detrng.make_inputs(B, V, seed=2024)
