@@ -50,10 +50,38 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
+// narrow rows (K = 32: the joints x views grid, 135 k rows at V = 31, B = 256): 8 lanes per row, one float4 each, so a
+// wave covers 8 rows with one coalesced 1-KiB read instead of one row with half its lanes idle; same two-pass
+// arithmetic, reductions over the 8 lanes of a row
+__global__ __launch_bounds__(256) void row_stats32_kernel(const float* __restrict__ x, int M, int ldx, float* __restrict__ stats) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int row = t >> 3, c = t & 7;
+    const bool ok = row < M;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = ld4(x + (size_t)row * ldx + 4 * c);
+    float s = (v.x + v.y) + (v.z + v.w);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float mean = s / 32.0f;
+    const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+    float ss = (a * a + b * b) + (cc * cc + d * d);
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    if (ok && c == 0) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = ss;
+    }
+}
+
 int launch_row_stats(const float* x, int M, int K, int ldx, float* stats, hipStream_t s) {
     if (M <= 0 || (K & 3)) return MPL_E_INVALID;
     ProfScope prof(MPL_K_ROW_STATS, s);
-    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, K, ldx, ln_slice_len(K), stats);
+    if (K == 32 && (ldx & 3) == 0)
+        hipLaunchKernelGGL(row_stats32_kernel, dim3((int)(((size_t)M * 8 + 255) / 256)), dim3(256), 0, s, x, M, ldx, stats);
+    else
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, K, ldx, ln_slice_len(K), stats);
     return hip_check_launch();
 }
 

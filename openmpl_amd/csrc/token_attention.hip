@@ -158,60 +158,131 @@ __global__ __launch_bounds__(256) void token_attention_lds_kernel(const float* _
 // ---------------------------------------------------------------------------------------------
 // Long sequences with a tiny head (the joints x views token grid, FPT_blocks_view_keypoint_tokens :261-266:
 // n_tok = 17 V up to 527 tokens, D = 32, hd = 4): one workgroup per (sequence, head) keeps that head's K and V
-// rows in LDS (n_tok x hd floats each) and every thread owns query rows, streaming the keys twice (max pass,
-// then exp / accumulate pass) -- two-pass softmax like the reference, no score matrix anywhere.
+// rows in LDS (n_tok x hd floats each).  A thread owns up to R = 3 query rows AT ONCE (t, t + 256, t + 512), so a K / V
+// row is read from LDS once for all of them (uniform address: a broadcast), and the softmax is the streaming form over
+// chunks of 16 keys: chunk scores in registers, running maximum m and normaliser l per row, the accumulators rescaled
+// only when a chunk raises the maximum -- one exp per score, one pass over K and V.  (Round 1: one query row at a time,
+// two passes, three LDS reads per (row, key): LDS-instruction bound, 504 us per launch at V = 31, B = 256.)
+// Same result as the reference's softmax(-1) up to the rounding of the (mathematically exact) rescaling.
+// NR query rows of one thread (i0, i0 + 256, ..) against all keys of the head
+template <int HD4, int NR>
+__device__ __forceinline__ void attend_rows(const float* __restrict__ base, size_t ld, const float* Ks, const float* Vs,
+                                            int n_tok, int i0, int stride, float scale, float* __restrict__ out_row0,
+                                            size_t out_ld) {
+    constexpr int HD = 4 * HD4, CH = 16;
+    float4 q[NR][HD4], o[NR][HD4];
+    float m[NR], l[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = i0 + stride * r;
+        const int ic = i < n_tok ? i : n_tok - 1;
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) {
+            q[r][c] = ld4(base + ic * ld + 4 * c);
+            q[r][c].x *= scale; q[r][c].y *= scale; q[r][c].z *= scale; q[r][c].w *= scale;   // (q k) scale = (q scale) k up to rounding
+            o[r][c] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        m[r] = -INFINITY;
+        l[r] = 0.f;
+    }
+    for (int j0 = 0; j0 < n_tok; j0 += CH) {
+        float sc[NR][CH];
+        const bool full = j0 + CH <= n_tok;          // uniform: only the last chunk is ragged
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = (full || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
+            float4 k[HD4];
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) k[c] = ld4(Ks + j * HD + 4 * c);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float s = q[r][0].x * k[0].x;
+                s = fmaf(q[r][0].y, k[0].y, s);
+                s = fmaf(q[r][0].z, k[0].z, s);
+                s = fmaf(q[r][0].w, k[0].w, s);
+#pragma unroll
+                for (int c = 1; c < HD4; ++c) {
+                    s = fmaf(q[r][c].x, k[c].x, s);
+                    s = fmaf(q[r][c].y, k[c].y, s);
+                    s = fmaf(q[r][c].z, k[c].z, s);
+                    s = fmaf(q[r][c].w, k[c].w, s);
+                }
+                sc[r][jj] = (full || j0 + jj < n_tok) ? s : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float mc = sc[r][0];
+#pragma unroll
+            for (int jj = 1; jj < CH; ++jj) mc = fmaxf(mc, sc[r][jj]);
+            // rescale what has been accumulated under the old maximum (factor 1 when the chunk does not raise it)
+            const float mn = fmaxf(m[r], mc);
+            const float f = __expf(m[r] - mn);
+            l[r] *= f;
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) { o[r][c].x *= f; o[r][c].y *= f; o[r][c].z *= f; o[r][c].w *= f; }
+            m[r] = mn;
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) sc[r][jj] = __expf(sc[r][jj] - mn);
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = (full || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
+            float4 v[HD4];
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) v[c] = ld4(Vs + j * HD + 4 * c);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float e = sc[r][jj];
+                l[r] += e;
+#pragma unroll
+                for (int c = 0; c < HD4; ++c) {
+                    o[r][c].x = fmaf(e, v[c].x, o[r][c].x);
+                    o[r][c].y = fmaf(e, v[c].y, o[r][c].y);
+                    o[r][c].z = fmaf(e, v[c].z, o[r][c].z);
+                    o[r][c].w = fmaf(e, v[c].w, o[r][c].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = i0 + stride * r;
+        if (i >= n_tok) continue;
+        const float inv = 1.0f / l[r];
+        float* op = out_row0 + (size_t)i * out_ld;
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) st4(op + 4 * c, float4{o[r][c].x * inv, o[r][c].y * inv, o[r][c].z * inv, o[r][c].w * inv});
+    }
+}
+
 template <int HD4>
 __global__ __launch_bounds__(256) void token_attention_long_kernel(const float* __restrict__ qkv,
                                                                     float* __restrict__ out, int n_tok, int D, int H,
                                                                     float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int HD = 4 * HD4;
+    constexpr int HD = 4 * HD4, R = 3;
+    const int nthr = blockDim.x;                     // 64 * ceil(n_tok / 192): every wave gets the same number of row slots
     const int sq = blockIdx.x / H, h = blockIdx.x % H;
     const size_t ld = (size_t)3 * D;
     const float* base = qkv + (size_t)sq * n_tok * ld + (size_t)h * HD;
     float* Ks = sm;
     float* Vs = sm + (size_t)n_tok * HD;
-    for (int i = threadIdx.x; i < n_tok * HD4; i += 256) {
+    for (int i = threadIdx.x; i < n_tok * HD4; i += nthr) {
         const int r = i / HD4, c = i % HD4;
         st4(Ks + r * HD + 4 * c, ld4(base + r * ld + D + 4 * c));
         st4(Vs + r * HD + 4 * c, ld4(base + r * ld + 2 * D + 4 * c));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_tok; i += 256) {
-        float4 q[HD4];
-#pragma unroll
-        for (int c = 0; c < HD4; ++c) q[c] = ld4(base + i * ld + 4 * c);
-        auto score = [&](int j) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < HD4; ++c) {
-                const float4 k = ld4(Ks + j * HD + 4 * c);
-                s += fmaf(q[c].x, k.x, q[c].y * k.y) + fmaf(q[c].z, k.z, q[c].w * k.w);
-            }
-            return s * scale;
-        };
-        float mx = -INFINITY;
-        for (int j = 0; j < n_tok; ++j) mx = fmaxf(mx, score(j));
-        float l = 0.f;
-        float4 o[HD4];
-#pragma unroll
-        for (int c = 0; c < HD4; ++c) o[c] = float4{0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < n_tok; ++j) {
-            const float e = __expf(score(j) - mx);
-            l += e;
-#pragma unroll
-            for (int c = 0; c < HD4; ++c) {
-                const float4 v = ld4(Vs + j * HD + 4 * c);
-                o[c].x = fmaf(e, v.x, o[c].x);
-                o[c].y = fmaf(e, v.y, o[c].y);
-                o[c].z = fmaf(e, v.z, o[c].z);
-                o[c].w = fmaf(e, v.w, o[c].w);
-            }
-        }
-        const float inv = 1.0f / l;
-        float* op = out + ((size_t)sq * n_tok + i) * D + (size_t)h * HD;
-#pragma unroll
-        for (int c = 0; c < HD4; ++c) st4(op + 4 * c, float4{o[c].x * inv, o[c].y * inv, o[c].z * inv, o[c].w * inv});
+    float* orow = out + (size_t)sq * n_tok * D + (size_t)h * HD;
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));     // first query row of this wave
+    for (int w0 = wbase; w0 < n_tok; w0 += nthr * R) {
+        // row slots of this wave that hold at least one query row (wave-uniform): w0, w0 + nthr, w0 + 2 nthr
+        const int ns = (n_tok - w0 + nthr - 1) / nthr;
+        const int i0 = w0 + (int)(threadIdx.x & 63u);
+        if (ns >= 3) attend_rows<HD4, 3>(base, ld, Ks, Vs, n_tok, i0, nthr, scale, orow, (size_t)D);
+        else if (ns == 2) attend_rows<HD4, 2>(base, ld, Ks, Vs, n_tok, i0, nthr, scale, orow, (size_t)D);
+        else attend_rows<HD4, 1>(base, ld, Ks, Vs, n_tok, i0, nthr, scale, orow, (size_t)D);
     }
 }
 
@@ -224,12 +295,14 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
         const float sc = 1.0f / sqrtf((float)hd);
         ProfScope prof(MPL_K_ATTENTION, s);
         const size_t lds = (size_t)n_tok * hd * 8;
+        int waves = (n_tok + 191) / 192;             // three row slots per wave
+        waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
         if (hd == 4)
-            hipLaunchKernelGGL((token_attention_long_kernel<1>), dim3(n_seq * heads), dim3(256), lds, s, qkv, out, n_tok, dim,
-                               heads, sc);
+            hipLaunchKernelGGL((token_attention_long_kernel<1>), dim3(n_seq * heads), dim3(64 * waves), lds, s, qkv, out, n_tok,
+                               dim, heads, sc);
         else
-            hipLaunchKernelGGL((token_attention_long_kernel<2>), dim3(n_seq * heads), dim3(256), lds, s, qkv, out, n_tok, dim,
-                               heads, sc);
+            hipLaunchKernelGGL((token_attention_long_kernel<2>), dim3(n_seq * heads), dim3(64 * waves), lds, s, qkv, out, n_tok,
+                               dim, heads, sc);
         return hip_check_launch();
     }
     const float scale = 1.0f / sqrtf((float)hd);
