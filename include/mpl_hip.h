@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 5
+#define MPL_HIP_ABI_VERSION 6
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -123,6 +123,10 @@ typedef struct mpl_weights {
     const float *wmean_w, *wmean_b;                        /* weighted_mean Conv1d (1,V,1),(1) */
     const float *head_ln_w, *head_ln_b;                    /* head.0 (J*d) */
     const float *head_w, *head_b;                          /* head.1 (3J, J*d),(3J) */
+    uint32_t spt_packed;  /* != 0: EVERY block of every spt_set carries the operand of mpl_spt_pack in its qkv_w3 field: the
+                           * SPT Linear layers run as fp32 arithmetic on the bf16 matrix cores (spt3_kernel); 0: the fp32
+                           * matrix instructions read the nn.Linear weights in place */
+    uint32_t reserved;
 } mpl_weights;
 
 typedef struct mpl_inputs {
@@ -179,6 +183,12 @@ int mpl_split_bf16x3(const float *W, const float *bias, const float *ln_w, const
 size_t mpl_ln_linear_x3_workspace_bytes(int M, int K);
 int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W3, int N, int epilogue,
                      const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Split operand of ONE SPT block (d = 32: qkv 96x32, proj 32x32, fc1 64x32, fc2 32x64): the four weights as three bf16
+ * parts each in MFMA fragment order, mpl_spt_pack_bytes() = 48 KiB.  `block` is a HOST struct whose fp32 weight pointers
+ * are device addresses; the result goes into the qkv_w3 field of the block's entry in the DEVICE array of mpl_spt_set. */
+size_t mpl_spt_pack_bytes(void);
+int mpl_spt_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
 
 /* The same for the bf16 engine: ONE bf16 per weight (round to nearest even of gamma o W), K padded with zero k-tiles to a
  * multiple of 96, the same fold vectors (s summed over the ROUNDED weights).  mpl_ln_linear_bf16: operands rounded to bf16

@@ -14,7 +14,7 @@ from . import build as _build
 
 MPL_MAX_VIEWS = 32
 MPL_MAX_APPS = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # flag bits (mpl_hip.h MPL_F_*)
 F_MULTI_SPT = 1 << 0
@@ -63,7 +63,7 @@ class Weights(C.Structure):
                 ("view_norm_w", _fp), ("view_norm_b", _fp),
                 ("wmean_w", _fp), ("wmean_b", _fp),
                 ("head_ln_w", _fp), ("head_ln_b", _fp),
-                ("head_w", _fp), ("head_b", _fp)]
+                ("head_w", _fp), ("head_b", _fp), ("spt_packed", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Inputs(C.Structure):
@@ -73,7 +73,7 @@ class Inputs(C.Structure):
 
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
-           "mpl_ln_linear", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_ln_linear_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_ln_linear_x3_workspace_bytes", "mpl_ln_linear_x3", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
+           "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_ln_linear_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_ln_linear_x3_workspace_bytes", "mpl_ln_linear_x3", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
            "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
@@ -135,6 +135,10 @@ def load():
         lib.mpl_ln_linear.restype = C.c_int
         lib.mpl_ln_linear.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int, C.c_int, _fp,
                                       _fp, _fp, _fp]
+        lib.mpl_spt_pack_bytes.restype = C.c_size_t
+        lib.mpl_spt_pack_bytes.argtypes = []
+        lib.mpl_spt_pack.restype = C.c_int
+        lib.mpl_spt_pack.argtypes = [C.POINTER(BlockWeights), _fp, _fp]
         lib.mpl_pack_bf16_bytes.restype = C.c_size_t
         lib.mpl_pack_bf16_bytes.argtypes = [C.c_int, C.c_int]
         lib.mpl_pack_bf16.restype = C.c_int

@@ -294,7 +294,7 @@ int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !in || !xs) return MPL_E_INVALID;
-    return launch_spt(cfg, w, in, xs, (hipStream_t)stream);
+    return launch_spt(cfg, w, in, xs, w->spt_packed != 0, (hipStream_t)stream);
 }
 
 int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
@@ -328,6 +328,13 @@ int mpl_split_bf16x3(const float* W, const float* bias, const float* ln_w, const
     clear_stale_hip_error();
     if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
     return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 3, (hipStream_t)stream);
+}
+
+size_t mpl_spt_pack_bytes(void) { return spt_pack_bytes(); }
+
+int mpl_spt_pack(const mpl_block_weights* block, uint16_t* dst, void* stream) {
+    clear_stale_hip_error();
+    return launch_spt_pack(block, dst, (hipStream_t)stream);
 }
 
 size_t mpl_pack_bf16_bytes(int N, int K) { return x3_operand_bytes(N, K, 1); }
@@ -456,7 +463,7 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
     char* rest = reinterpret_cast<char*>(workspace) + align_up((size_t)B * V * D * sizeof(float), 256);
     const size_t rest_bytes = workspace_bytes - (size_t)(rest - reinterpret_cast<char*>(workspace));
 
-    if ((rc = launch_spt(cfg, w, in, xs, s))) return rc;
+    if ((rc = launch_spt(cfg, w, in, xs, w->spt_packed != 0, s))) return rc;
 
     if (!(cfg->flags & MPL_F_NO_FPT) && cfg->depth > 0) {
         // forward_features :420-423: the last block is applied twice

@@ -90,7 +90,11 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
                             int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
-int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s);
+// use_packed: every SPT block carries the split operand of mpl_spt_pack in qkv_w3 (spt3_kernel: Linear layers on the bf16
+// matrix cores); else the fp32-MFMA kernel reads the nn.Linear weights in place
+int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, int use_packed, hipStream_t s);
+size_t spt_pack_bytes();
+int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s);
 // y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,
                      hipStream_t s);

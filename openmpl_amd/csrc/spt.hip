@@ -163,32 +163,23 @@ __device__ __forceinline__ f32x4 tile_k32(const float4& a0, const float4& a1, co
     return c0 + c1;
 }
 
-__global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;
-    float* Q = smem + ROWS * XS;
+// Row order of the token matrix X in LDS.  TM = false: row = sequence * 17 + joint (the fp32-MFMA kernel); TM = true:
+// row = joint * 16 + sequence -- token-major: MFMA row tile j holds joint j of the 16 sequences, so a lane of a transposed
+// accumulator tile is one (sequence, head) and the attention needs no cross-lane traffic (spt3_kernel).
+template <bool TM>
+__device__ __forceinline__ void row_to_sj(int r, int& sq, int& j) {
+    if (TM) { j = r >> 4; sq = r & 15; }
+    else { sq = r / SJ; j = r - sq * SJ; }
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int view = blockIdx.x % p.V;
-    const int b0 = (blockIdx.x / p.V) * SEQ;
-    const mpl_spt_set set = p.sets[(p.flags & MPL_F_MULTI_SPT) ? view : 0];
-    const float* pose = p.poses[view];
-    const float* ray = p.rays[view];
-    const float* cen = p.centers[view];
-
-    // weights of the first Block application: issue the loads before anything else
-    BlockFrags F;
-    mpl_block_weights bw, bw_next;
-    if (p.n_apps > 0) {
-        bw = set.blocks[p.sched[0] & 0x7f];
-        load_qkv_frags(bw, F, li, kq);
-    }
-
-    // ---------------- phase 0: joint embedding (:355-396) ----------------
+// joint embedding (:355-396) of the workgroup's 16 sequences -> X
+template <bool TM>
+__device__ __forceinline__ void spt_embed(const SptParams& p, const mpl_spt_set& set, float* X, int tid, int b0,
+                                          const float* pose, const float* ray, const float* cen) {
     for (int idx = tid; idx < ROWS * SD; idx += NTHR) {
         const int r = idx >> 5, c = idx & 31;
-        const int sq = r / SJ, j = r - sq * SJ;
+        int sq, j;
+        row_to_sj<TM>(r, sq, j);
         const int b = b0 + sq;
         float x = 0.f;
         if (b < p.B) {
@@ -214,6 +205,114 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         }
         X[r * XS + c] = x;
     }
+}
+
+// Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...]
+template <bool TM>
+__device__ __forceinline__ void spt_epilogue(const SptParams& p, const float* X, int tid, int view, int b0, const float* pose,
+                                             const float* ray, const float* cen) {
+    // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
+    const bool to_rays = (p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);   // feature concat (:469-471)
+    const bool ray_tok = !(p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);  // token concat (:486-489)
+    const int cw = to_rays ? 2 * SD : SD;                 // channels per joint in the output row
+    const int Df = SJ * SD * ((p.flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
+    for (int r = tid; r < ROWS; r += NTHR) {
+        int sq, j;
+        row_to_sj<TM>(r, sq, j);
+        const int b = b0 + sq;
+        if (b >= p.B) continue;
+        const float* xr = X + r * XS;
+        float v[SD];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < SD; c += 4) {
+            const float4 t = ld4(xr + c);
+            v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+        const float mean = s * (1.0f / 32.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < SD; ++c) {
+            v[c] -= mean;
+            ss = fmaf(v[c], v[c], ss);
+        }
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
+        const float conf = pose[((size_t)b * SJ + j) * 3 + 2];
+        float dx = 0.f, dy = 0.f, dz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+        const bool need_dir = (p.flags & MPL_F_RAYS_TOKEN) ||
+                              (!(p.flags & MPL_F_POS3D_SPATIAL) && !(p.flags & MPL_F_POS3D_LEARN));
+        if (need_dir) {
+            const float* rr = ray + ((size_t)b * SJ + j) * 3;
+            const float* cc = cen + (size_t)b * 3;
+            dx = rr[0] - cc[0]; dy = rr[1] - cc[1]; dz = rr[2] - cc[2];
+            const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            nx = dx / nrm; ny = dy / nrm; nz = dz / nrm;
+        }
+        // 3D position term for channel c of this joint (:474-483)
+        auto pos3d = [=](int c) -> float {
+            if (p.flags & MPL_F_POS3D_SPATIAL) return p.pos3d_view[j * p.c3 + c];
+            if (p.flags & MPL_F_POS3D_LEARN) return p.pos3d_embed[j * p.c3 + c];
+            const float* wl = p.pos3d_lin_w + c * 3;
+            return p.pos3d_lin_b[c] + wl[0] * nx + wl[1] * ny + wl[2] * nz;
+        };
+        auto ray_emb = [=](int c) -> float {
+            const float* wr = p.ray_w + c * 3;
+            return p.ray_b[c] + wr[0] * dx + wr[1] * dy + wr[2] * dz;
+        };
+        float* orow = p.xs + ((size_t)b * p.V + view) * Df;
+        float* o1 = orow + j * cw;
+#pragma unroll
+        for (int c = 0; c < SD; c += 4) {
+            float t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y = v[c + q] * rstd * p.snorm_w[c + q] + p.snorm_b[c + q];
+                if (p.flags & MPL_F_CONF_IN_FPT) y += p.cfpt_w[c + q] * conf + p.cfpt_b[c + q];
+                t[q] = y + pos3d(c + q);
+            }
+            st4(o1 + c, float4{t[0], t[1], t[2], t[3]});
+        }
+        if (to_rays) {
+#pragma unroll
+            for (int c = 0; c < SD; c += 4) {
+                float t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = ray_emb(c + q) + pos3d(SD + c + q);
+                st4(o1 + SD + c, float4{t[0], t[1], t[2], t[3]});
+            }
+        } else if (ray_tok) {
+            float* o2 = orow + (SJ + j) * SD;
+#pragma unroll
+            for (int c = 0; c < SD; c += 4) st4(o2 + c, float4{ray_emb(c), ray_emb(c + 1), ray_emb(c + 2), ray_emb(c + 3)});
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* Q = smem + ROWS * XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int view = blockIdx.x % p.V;
+    const int b0 = (blockIdx.x / p.V) * SEQ;
+    const mpl_spt_set set = p.sets[(p.flags & MPL_F_MULTI_SPT) ? view : 0];
+    const float* pose = p.poses[view];
+    const float* ray = p.rays[view];
+    const float* cen = p.centers[view];
+
+    // weights of the first Block application: issue the loads before anything else
+    BlockFrags F;
+    mpl_block_weights bw, bw_next;
+    if (p.n_apps > 0) {
+        bw = set.blocks[p.sched[0] & 0x7f];
+        load_qkv_frags(bw, F, li, kq);
+    }
+
+    // ---------------- phase 0: joint embedding (:355-396) ----------------
+    spt_embed<false>(p, set, X, tid, b0, pose, ray, cen);
     __syncthreads();
 
     // ---------------- block applications (:405-410) ----------------
@@ -260,72 +359,42 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         __syncthreads();
         stamp(0);
 
-        // ---- attention (:55-64): thread = (sequence, head, group of 4-5 query rows) -- exactly 16 x 8 x 4 = 512 tasks.
-        // Every K and V row of the (sequence, head) is read from LDS ONCE per thread and used for all its query rows
-        // (the scores of 5 rows x 17 keys stay in registers): 34 ds_read_b128 per thread instead of 34 per (row, head)
-        // = 145 per thread.  The four row groups of a (sequence, head) sit in adjacent lanes and read the same
-        // addresses (broadcast); a 16-lane ds_read_b128 group touches 4 heads x 16 B: conflict free.
-        if (!(p.abl & 1)) {
-            const int rgp = tid & 3, h = (tid >> 2) & 7, sq = tid >> 5;
-            const int r0 = rgp == 0 ? 0 : 1 + 4 * rgp;          // rows 0..4 | 5..8 | 9..12 | 13..16 of the sequence
-            const int nr = rgp == 0 ? 5 : 4;
-            float* qb = Q + (sq * SJ) * QS + 4 * h;              // q rows (overwritten with the output), k at +SD, v at +2 SD
-            // two passes of up to 3 and 2 rows (the scores of 3 rows x 17 keys fit the register budget next to the
-            // prefetched weight fragments): K and V are read twice per thread, 68 reads
+        // ---- attention: thread per (row, head); 17 scores in registers (:55-64)
+        for (int pr = tid; pr < ROWS * SH && !(p.abl & 1); pr += NTHR) {
+            const int r = pr >> 3, h = pr & 7;
+            const int sq = r / SJ;
+            const float* kb = Q + (sq * SJ) * QS + SD + 4 * h;
+            const float4 q = ld4(Q + r * QS + 4 * h);
+            float sc[SJ];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                constexpr int NRW = 3;
-                const int rb = r0 + 3 * half, cnt = half == 0 ? 3 : nr - 3;      // 3 | 2 (or 1) rows
-                float4 q[NRW];
-#pragma unroll
-                for (int i = 0; i < NRW; ++i) q[i] = ld4(qb + (rb + (i < cnt ? i : 0)) * QS);
-                float sc[NRW][SJ];
-#pragma unroll
-                for (int j = 0; j < SJ; ++j) {
-                    if ((j & 3) == 0) asm volatile("" ::: "memory");   // keep the unrolled K / V loads from being hoisted en bloc
-                    const float4 k = ld4(qb + j * QS + SD);
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i)
-                        sc[i][j] = 0.5f * (fmaf(q[i].x, k.x, q[i].y * k.y) + fmaf(q[i].z, k.z, q[i].w * k.w));  // hd^-0.5 = 0.5
-                }
-                float inv[NRW];
-#pragma unroll
-                for (int i = 0; i < NRW; ++i) {
-                    float mx = sc[i][0];
-#pragma unroll
-                    for (int j = 1; j < SJ; ++j) mx = fmaxf(mx, sc[i][j]);
-                    float l = 0.f;
-#pragma unroll
-                    for (int j = 0; j < SJ; ++j) {
-                        sc[i][j] = __expf(sc[i][j] - mx);
-                        l += sc[i][j];
-                    }
-                    inv[i] = 1.0f / l;
-                    if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales query row r
-                        const int b = b0 + sq;
-                        inv[i] *= (b < p.B && i < cnt) ? pose[((size_t)b * SJ + (rb + i)) * 3 + 2] : 0.f;
-                    }
-                }
-                float4 o[NRW];
-#pragma unroll
-                for (int i = 0; i < NRW; ++i) o[i] = float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < SJ; ++j) {
-                    if ((j & 3) == 0) asm volatile("" ::: "memory");
-                    const float4 v = ld4(qb + j * QS + 2 * SD);
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i) {
-                        const float pj = sc[i][j] * inv[i];
-                        o[i].x = fmaf(pj, v.x, o[i].x);
-                        o[i].y = fmaf(pj, v.y, o[i].y);
-                        o[i].z = fmaf(pj, v.z, o[i].z);
-                        o[i].w = fmaf(pj, v.w, o[i].w);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NRW; ++i)
-                    if (i < cnt) st4(qb + (rb + i) * QS, o[i]);   // overwrite q (only this thread ever reads these q rows)
+            for (int j = 0; j < SJ; ++j) {
+                const float4 k = ld4(kb + j * QS);
+                sc[j] = 0.5f * (fmaf(q.x, k.x, q.y * k.y) + fmaf(q.z, k.z, q.w * k.w));  // hd^-0.5 = 0.5
+                mx = fmaxf(mx, sc[j]);
             }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < SJ; ++j) {
+                sc[j] = __expf(sc[j] - mx);
+                l += sc[j];
+            }
+            float inv = 1.0f / l;
+            if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales query row r
+                const int b = b0 + sq;
+                inv *= (b < p.B) ? pose[((size_t)b * SJ + (r - sq * SJ)) * 3 + 2] : 0.f;
+            }
+            float4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < SJ; ++j) {
+                const float4 v = ld4(kb + j * QS + SD);
+                const float pj = sc[j] * inv;
+                o.x = fmaf(pj, v.x, o.x);
+                o.y = fmaf(pj, v.y, o.y);
+                o.z = fmaf(pj, v.z, o.z);
+                o.w = fmaf(pj, v.w, o.w);
+            }
+            st4(Q + r * QS + 4 * h, o);  // overwrite q (only this thread ever reads it)
         }
         __syncthreads();
         stamp(1);
@@ -413,84 +482,315 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         return;
     }
     if (p.abl & 16) return;
-    // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
-    const bool to_rays = (p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);   // feature concat (:469-471)
-    const bool ray_tok = !(p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);  // token concat (:486-489)
-    const int cw = to_rays ? 2 * SD : SD;                 // channels per joint in the output row
-    const int Df = SJ * SD * ((p.flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
-    for (int r = tid; r < ROWS; r += NTHR) {
-        const int sq = r / SJ, j = r - sq * SJ;
-        const int b = b0 + sq;
-        if (b >= p.B) continue;
-        const float* xr = X + r * XS;
-        float v[SD];
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < SD; c += 4) {
-            const float4 t = ld4(xr + c);
-            v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
-            s += (t.x + t.y) + (t.z + t.w);
-        }
-        const float mean = s * (1.0f / 32.0f);
-        float ss = 0.f;
-#pragma unroll
-        for (int c = 0; c < SD; ++c) {
-            v[c] -= mean;
-            ss = fmaf(v[c], v[c], ss);
-        }
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
-        const float conf = pose[((size_t)b * SJ + j) * 3 + 2];
-        float dx = 0.f, dy = 0.f, dz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-        const bool need_dir = (p.flags & MPL_F_RAYS_TOKEN) ||
-                              (!(p.flags & MPL_F_POS3D_SPATIAL) && !(p.flags & MPL_F_POS3D_LEARN));
-        if (need_dir) {
-            const float* rr = ray + ((size_t)b * SJ + j) * 3;
-            const float* cc = cen + (size_t)b * 3;
-            dx = rr[0] - cc[0]; dy = rr[1] - cc[1]; dz = rr[2] - cc[2];
-            const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
-            nx = dx / nrm; ny = dy / nrm; nz = dz / nrm;
-        }
-        // 3D position term for channel c of this joint (:474-483)
-        auto pos3d = [=](int c) -> float {
-            if (p.flags & MPL_F_POS3D_SPATIAL) return p.pos3d_view[j * p.c3 + c];
-            if (p.flags & MPL_F_POS3D_LEARN) return p.pos3d_embed[j * p.c3 + c];
-            const float* wl = p.pos3d_lin_w + c * 3;
-            return p.pos3d_lin_b[c] + wl[0] * nx + wl[1] * ny + wl[2] * nz;
-        };
-        auto ray_emb = [=](int c) -> float {
-            const float* wr = p.ray_w + c * 3;
-            return p.ray_b[c] + wr[0] * dx + wr[1] * dy + wr[2] * dz;
-        };
-        float* orow = p.xs + ((size_t)b * p.V + view) * Df;
-        float* o1 = orow + j * cw;
-#pragma unroll
-        for (int c = 0; c < SD; c += 4) {
-            float t[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float y = v[c + q] * rstd * p.snorm_w[c + q] + p.snorm_b[c + q];
-                if (p.flags & MPL_F_CONF_IN_FPT) y += p.cfpt_w[c + q] * conf + p.cfpt_b[c + q];
-                t[q] = y + pos3d(c + q);
-            }
-            st4(o1 + c, float4{t[0], t[1], t[2], t[3]});
-        }
-        if (to_rays) {
-#pragma unroll
-            for (int c = 0; c < SD; c += 4) {
-                float t[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t[q] = ray_emb(c + q) + pos3d(SD + c + q);
-                st4(o1 + SD + c, float4{t[0], t[1], t[2], t[3]});
-            }
-        } else if (ray_tok) {
-            float* o2 = orow + (SJ + j) * SD;
-#pragma unroll
-            for (int c = 0; c < SD; c += 4) st4(o2 + c, float4{ray_emb(c), ray_emb(c + 1), ray_emb(c + 2), ray_emb(c + 3)});
-        }
-    }
+    spt_epilogue<false>(p, X, tid, view, b0, pose, ray, cen);
 }
 
-int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, hipStream_t s) {
+// =====================================================================================================================
+// spt3_kernel -- the same stage with the Linear layers on the bf16 matrix cores (fp32 arithmetic from exactly split
+// operands, as x3_gemm.hip: x = hi + mid + lo in bf16, six partial products per product, fp32 accumulation).
+//
+//   * token-major rows (row = joint * 16 + sequence) and the W fragment as FIRST MFMA operand: lane (s, kq) of an
+//     accumulator tile holds 4 consecutive columns of (joint j, sequence s) -- for the qkv tiles exactly the 4-dim vector
+//     of ONE head (h = 4 hg + kq).  Wave (hg, part) computes q, k, v of head group hg for the joints j = part (mod 4):
+//     q stays in registers, k / v go to LDS as K[j][h][s][4] (one ds_write_b128 per tile);
+//   * attention: the lane keeps its (sequence, head) and its <= 5 query joints; every K / V row is read once
+//     (contiguous 1-KiB wave reads) for all of them -- 34 ds_read_b128 per lane and block application instead of 145;
+//   * proj / fc1 / fc2: A fragments are read from LDS (attention output, LayerNorm-ed X, GELU output), split in
+//     registers (~45 VALU ops per fragment) and multiplied with weight fragments that the binding split once
+//     (mpl_spt_pack: 48 KiB per block, MFMA fragment order, prefetched one phase ahead); 1632 bf16 MFMAs of 16 cycles
+//     per block application instead of 2176 fp32 MFMAs of 32.
+// LDS: X[272][36] | K[17][8][16][4] | V[17][8][16][4] | ATT[272][36]; the MLP hidden HID[272][68] aliases K | V | ATT.
+constexpr int ATS = 36;                       // ATT row stride (floats)
+constexpr int HS = 68;                        // HID row stride (floats)
+constexpr int KV_F = SJ * SH * SEQ * 4;       // 8704 floats each
+constexpr int SPT3_LDS_BYTES = (ROWS * XS + 2 * KV_F + ROWS * ATS) * 4;   // 147968
+static_assert(ROWS * HS <= 2 * KV_F + ROWS * ATS, "HID does not fit its alias");
+constexpr int SPT_PACK_QKV = 0, SPT_PACK_PROJ = 18 * 1024, SPT_PACK_FC1 = 24 * 1024, SPT_PACK_FC2 = 36 * 1024;
+constexpr int SPT_PACK_BYTES = 48 * 1024;
+
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void spt_split3(const float (&x)[8], sbf16x8& hi, sbf16x8& mid, sbf16x8& lo) {
+    float r[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (__bf16)x[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i] - (float)hi[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mid[i] = (__bf16)r[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r2[i] = r[i] - (float)mid[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = (__bf16)r2[i];
+}
+
+// one thread per (fragment, lane): fragment f of the packed block = 8 consecutive k of one weight row, three parts
+__global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__ qkv_w, const float* __restrict__ proj_w,
+                                                        const float* __restrict__ fc1_w, const float* __restrict__ fc2_w,
+                                                        sbf16x8* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (tile-k unit) * 64 + lane; 16 units: 6 qkv, 2 proj, 4 fc1, 4 fc2
+    if (idx >= 16 * 64) return;
+    const int lane = idx & 63, u = idx >> 6, li = lane & 15, kq = lane >> 4;
+    const float* src;
+    if (u < 6) src = qkv_w + (size_t)(16 * u + li) * SD + 8 * kq;
+    else if (u < 8) src = proj_w + (size_t)(16 * (u - 6) + li) * SD + 8 * kq;
+    else if (u < 12) src = fc1_w + (size_t)(16 * (u - 8) + li) * SD + 8 * kq;
+    else src = fc2_w + (size_t)(16 * ((u - 12) >> 1) + li) * (2 * SD) + 32 * ((u - 12) & 1) + 8 * kq;   // [n][ks]
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[j];
+    sbf16x8 hi, mid, lo;
+    spt_split3(x, hi, mid, lo);
+    sbf16x8* o = dst + (size_t)u * 3 * 64 + lane;
+    o[0] = hi;
+    o[64] = mid;
+    o[128] = lo;
+}
+
+int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s) {
+    if (!bw_host || !dst || !bw_host->qkv_w || !bw_host->proj_w || !bw_host->fc1_w || !bw_host->fc2_w) return MPL_E_INVALID;
+    hipLaunchKernelGGL(spt_pack_kernel, dim3(4), dim3(256), 0, s, bw_host->qkv_w, bw_host->proj_w, bw_host->fc1_w, bw_host->fc2_w,
+                       reinterpret_cast<sbf16x8*>(dst));
+    return hip_check_launch();
+}
+
+size_t spt_pack_bytes() { return SPT_PACK_BYTES; }
+
+// acc(16 x 16, transposed) += sum of the six significant part products of A (hi, mid, lo) and W (hi, mid, lo)
+__device__ __forceinline__ f32x4 mfma6(const sbf16x8 (&w)[3], const sbf16x8& ah, const sbf16x8& am, const sbf16x8& al, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], al, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], ah, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], am, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], am, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], ah, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], ah, c, 0, 0, 0);
+    return c;
+}
+
+typedef const __attribute__((address_space(1))) sbf16x8* gwp;
+
+__global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* Kb = smem + ROWS * XS;
+    float* Vb = Kb + KV_F;
+    float* ATT = Vb + KV_F;
+    float* HID = Kb;                               // alias (K, V, ATT are dead between proj and the next qkv)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;      // li = sequence (row in tile), kq = k quarter / column quad
+    const int hg = wave & 1, part = wave >> 1;     // head group, joint class
+    const int view = blockIdx.x % p.V;
+    const int b0 = (blockIdx.x / p.V) * SEQ;
+    const mpl_spt_set set = p.sets[(p.flags & MPL_F_MULTI_SPT) ? view : 0];
+    const float* pose = p.poses[view];
+    const float* ray = p.rays[view];
+    const float* cen = p.centers[view];
+
+    spt_embed<true>(p, set, X, tid, b0, pose, ray, cen);
+    __syncthreads();
+
+    const int nj = part == 0 ? 5 : 4;              // joints part, part + 4, ... of this wave
+    auto load_w = [&](const unsigned short* pack, int byte_off, int unit, sbf16x8 (&w)[3]) {
+        gwp g = (gwp)(reinterpret_cast<const char*>(pack) + byte_off) + (size_t)unit * 3 * 64 + lane;
+        w[0] = g[0];
+        w[1] = g[64];
+        w[2] = g[128];
+    };
+    // LayerNorm-ed, split A fragment of row tile m (K = 32): lane (s, kq) holds k = 8 kq .. 8 kq + 7 of row 16 m + s
+    auto ln_frag = [&](int m, const float4& g0, const float4& g1, const float4& e0, const float4& e1, sbf16x8& ah, sbf16x8& am,
+                       sbf16x8& al) {
+        const float* xr = X + (m * 16 + li) * XS + 8 * kq;
+        float4 x0 = ::mpl::ld4(xr), x1 = ::mpl::ld4(xr + 4);
+        float sm = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float mean = sm * (1.0f / 32.0f);
+        x0.x -= mean; x0.y -= mean; x0.z -= mean; x0.w -= mean;
+        x1.x -= mean; x1.y -= mean; x1.z -= mean; x1.w -= mean;
+        float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
+                   ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
+        const float y[8] = {x0.x * rstd * g0.x + e0.x, x0.y * rstd * g0.y + e0.y, x0.z * rstd * g0.z + e0.z, x0.w * rstd * g0.w + e0.w,
+                            x1.x * rstd * g1.x + e1.x, x1.y * rstd * g1.y + e1.y, x1.z * rstd * g1.z + e1.z, x1.w * rstd * g1.w + e1.w};
+        spt_split3(y, ah, am, al);
+    };
+    auto raw_frag = [&](const float* rowp, sbf16x8& ah, sbf16x8& am, sbf16x8& al) {
+        const float4 x0 = ::mpl::ld4(rowp), x1 = ::mpl::ld4(rowp + 4);
+        const float y[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        spt_split3(y, ah, am, al);
+    };
+
+    mpl_block_weights bw;
+    for (int app = 0; app < p.n_apps; ++app) {
+        const bool weighted = (p.sched[app] & 0x80) != 0;
+        bw = set.blocks[p.sched[app] & 0x7f];
+        const unsigned short* pack = bw.qkv_w3;
+        // ---------------- qkv: this wave's q, k, v tiles (head group hg) of its joints
+        {
+            sbf16x8 wq[3][3];
+            float4 bq[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                load_w(pack, SPT_PACK_QKV, 2 * c + hg, wq[c]);
+                bq[c] = ld4(G(bw.qkv_b) + 32 * c + 16 * hg + 4 * kq);
+            }
+            const float4 g0 = ld4(G(bw.ln1_w) + 8 * kq), g1 = ld4(G(bw.ln1_w) + 8 * kq + 4);
+            const float4 e0 = ld4(G(bw.ln1_b) + 8 * kq), e1 = ld4(G(bw.ln1_b) + 8 * kq + 4);
+            float4 q[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                q[t] = float4{0.f, 0.f, 0.f, 0.f};
+                if (t < nj) {
+                    const int j = part + 4 * t;
+                    sbf16x8 ah, am, al;
+                    ln_frag(j, g0, g1, e0, e1, ah, am, al);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 cq = mfma6(wq[0], ah, am, al, z), ck = mfma6(wq[1], ah, am, al, z), cv = mfma6(wq[2], ah, am, al, z);
+                    q[t] = float4{cq[0] + bq[0].x, cq[1] + bq[0].y, cq[2] + bq[0].z, cq[3] + bq[0].w};
+                    const int h = 4 * hg + kq;
+                    st4(Kb + ((j * SH + h) * SEQ + li) * 4, float4{ck[0] + bq[1].x, ck[1] + bq[1].y, ck[2] + bq[1].z, ck[3] + bq[1].w});
+                    st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{cv[0] + bq[2].x, cv[1] + bq[2].y, cv[2] + bq[2].z, cv[3] + bq[2].w});
+                }
+            }
+            __syncthreads();
+            // ---------------- attention (:55-64): lane = (sequence li, head h), its <= 5 query joints against all 17 keys
+            {
+                const int h = 4 * hg + kq;
+                float sc[5][SJ];
+#pragma unroll
+                for (int j = 0; j < SJ; ++j) {
+                    const float4 k = ::mpl::ld4(Kb + ((j * SH + h) * SEQ + li) * 4);
+#pragma unroll
+                    for (int t = 0; t < 5; ++t)
+                        sc[t][j] = 0.5f * (fmaf(q[t].x, k.x, q[t].y * k.y) + fmaf(q[t].z, k.z, q[t].w * k.w));   // hd^-0.5 = 0.5
+                }
+                float inv[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    float mx = sc[t][0];
+#pragma unroll
+                    for (int j = 1; j < SJ; ++j) mx = fmaxf(mx, sc[t][j]);
+                    float l = 0.f;
+#pragma unroll
+                    for (int j = 0; j < SJ; ++j) {
+                        sc[t][j] = __expf(sc[t][j] - mx);
+                        l += sc[t][j];
+                    }
+                    inv[t] = 1.0f / l;
+                    if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales the query row
+                        const int b = b0 + li;
+                        inv[t] *= (b < p.B && t < nj) ? pose[((size_t)b * SJ + (part + 4 * t)) * 3 + 2] : 0.f;
+                    }
+                }
+                float4 o[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) o[t] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < SJ; ++j) {
+                    const float4 v = ::mpl::ld4(Vb + ((j * SH + h) * SEQ + li) * 4);
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) {
+                        const float pj = sc[t][j] * inv[t];
+                        o[t].x = fmaf(pj, v.x, o[t].x);
+                        o[t].y = fmaf(pj, v.y, o[t].y);
+                        o[t].z = fmaf(pj, v.z, o[t].z);
+                        o[t].w = fmaf(pj, v.w, o[t].w);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (t < nj) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
+            }
+        }
+        __syncthreads();
+        // ---------------- X += attn_out . Wproj^T + b : 17 x 2 tiles, dealt as contiguous ranges of the (m, n) list
+        {
+            sbf16x8 wp[2][3];
+            float4 bp[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                load_w(pack, SPT_PACK_PROJ, n, wp[n]);
+                bp[n] = ld4(G(bw.proj_b) + 16 * n + 4 * kq);
+            }
+            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+                sbf16x8 ah, am, al;
+                raw_frag(ATT + (m * 16 + li) * ATS + 8 * kq, ah, am, al);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int u = 2 * m + n;
+                    if (u < lo || u >= hi) continue;
+                    const f32x4 c = mfma6(wp[n], ah, am, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                    float* xd = X + (m * 16 + li) * XS + 16 * n + 4 * kq;
+                    const float4 x = ::mpl::ld4(xd);
+                    st4(xd, float4{x.x + (c[0] + bp[n].x), x.y + (c[1] + bp[n].y), x.z + (c[2] + bp[n].z), x.w + (c[3] + bp[n].w)});
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles
+        {
+            sbf16x8 w1[4][3];
+            float4 b1[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                load_w(pack, SPT_PACK_FC1, n, w1[n]);
+                b1[n] = ld4(G(bw.fc1_b) + 16 * n + 4 * kq);
+            }
+            const float4 g0 = ld4(G(bw.ln2_w) + 8 * kq), g1 = ld4(G(bw.ln2_w) + 8 * kq + 4);
+            const float4 e0 = ld4(G(bw.ln2_b) + 8 * kq), e1 = ld4(G(bw.ln2_b) + 8 * kq + 4);
+            const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 2; m <= ((hi - 1) >> 2); ++m) {
+                sbf16x8 ah, am, al;
+                ln_frag(m, g0, g1, e0, e1, ah, am, al);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int u = 4 * m + n;
+                    if (u < lo || u >= hi) continue;
+                    const f32x4 c = mfma6(w1[n], ah, am, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                    st4(HID + (m * 16 + li) * HS + 16 * n + 4 * kq,
+                        float4{gelu_erf(c[0] + b1[n].x), gelu_erf(c[1] + b1[n].y), gelu_erf(c[2] + b1[n].z), gelu_erf(c[3] + b1[n].w)});
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- X += Hid . W2^T + b : K = 64 (two k steps), 17 x 2 tiles
+        {
+            sbf16x8 w2[2][2][3];
+            float4 b2[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                load_w(pack, SPT_PACK_FC2, 2 * n, w2[n][0]);
+                load_w(pack, SPT_PACK_FC2, 2 * n + 1, w2[n][1]);
+                b2[n] = ld4(G(bw.fc2_b) + 16 * n + 4 * kq);
+            }
+            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+                sbf16x8 ah0, am0, al0, ah1, am1, al1;
+                raw_frag(HID + (m * 16 + li) * HS + 8 * kq, ah0, am0, al0);
+                raw_frag(HID + (m * 16 + li) * HS + 32 + 8 * kq, ah1, am1, al1);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int u = 2 * m + n;
+                    if (u < lo || u >= hi) continue;
+                    f32x4 c = mfma6(w2[n][0], ah0, am0, al0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    c = mfma6(w2[n][1], ah1, am1, al1, c);
+                    float* xd = X + (m * 16 + li) * XS + 16 * n + 4 * kq;
+                    const float4 x = ::mpl::ld4(xd);
+                    st4(xd, float4{x.x + (c[0] + b2[n].x), x.y + (c[1] + b2[n].y), x.z + (c[2] + b2[n].z), x.w + (c[3] + b2[n].w)});
+                }
+            }
+        }
+        __syncthreads();
+    }
+    spt_epilogue<true>(p, X, tid, view, b0, pose, ray, cen);
+}
+
+int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, int use_packed, hipStream_t s) {
     if (cfg->num_joints != SJ || cfg->dim != SD || cfg->heads != SH) return MPL_E_UNSUPPORTED;
     if (cfg->num_views < 1 || cfg->num_views > MPL_MAX_VIEWS || in->batch <= 0) return MPL_E_INVALID;
     if (cfg->in_chans != 2 && cfg->in_chans != 3) return MPL_E_INVALID;
@@ -542,7 +842,17 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     }
     const int grid = cfg->num_views * ((in->batch + SEQ - 1) / SEQ);
     ProfScope prof(MPL_K_SPT, s);
-    hipLaunchKernelGGL(spt_kernel, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);
+    if (use_packed) {
+        static std::atomic<bool> attr3[64];
+        if (!attr3[dev].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute((const void*)spt3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPT3_LDS_BYTES) != hipSuccess)
+                return MPL_E_LAUNCH;
+            attr3[dev].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(spt3_kernel, dim3(grid), dim3(NTHR), SPT3_LDS_BYTES, s, p);
+    } else {
+        hipLaunchKernelGGL(spt_kernel, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);
+    }
     return hip_check_launch();
 }
 

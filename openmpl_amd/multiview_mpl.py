@@ -345,8 +345,14 @@ class MultiView_MPL(nn.Module):
         key = tuple(map(torch.Tensor.data_ptr, plist))
         bf16 = self.matmul_precision == "bf16" and not self._dp_replica and self._x3_supported()
         x3 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
+        # the SPT Linear layers also run from split operands (fp32 arithmetic on the bf16 matrix cores) unless the native
+        # fp32 matrix instructions were asked for or this is a DataParallel replica
+        spt3 = self.matmul_precision != "fp32_mfma" and not self._dp_replica and not self.no_transformer_spt
         if bf16 or x3:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
+        if spt3:
+            stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
+            key = key + ("spt3",) + tuple(t._version for st in stacks for b in st for t in self._block_ptrs(b)[2:12:2])
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent
@@ -361,6 +367,7 @@ class MultiView_MPL(nn.Module):
         blob = torch.empty(n_sets * set_sz + max(1, n_sets * L) * blk_sz, dtype=torch.uint8, device=device)
         base = blob.data_ptr()
         sets = (cabi.SptSet * n_sets)()
+        spt_keep = []
         blks = (cabi.BlockWeights * max(1, n_sets * L))()
         for s in range(n_sets):
             multi = self.multiple_spatial_blocks
@@ -374,7 +381,15 @@ class MultiView_MPL(nn.Module):
             if L:
                 stack = self.Spatial_blocks[s] if multi else self.Spatial_blocks
                 for l, b in enumerate(stack):
-                    blks[s * L + l] = cabi.BlockWeights(*[_ptr(t) for t in self._block_ptrs(b)])
+                    bwl = cabi.BlockWeights(*[_ptr(t) for t in self._block_ptrs(b)])
+                    if spt3:
+                        lib = cabi.load()
+                        pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
+                        cabi.check(lib.mpl_spt_pack(C.byref(bwl), pk.data_ptr(), torch.cuda.current_stream(device).cuda_stream),
+                                   "mpl_spt_pack")
+                        spt_keep.append(pk)
+                        bwl.qkv_w3 = pk.data_ptr()
+                    blks[s * L + l] = bwl
         host = bytes(sets) + bytes(blks)
         blob.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
         fpt = (cabi.BlockWeights * max(1, len(self.blocks)))()
@@ -397,6 +412,7 @@ class MultiView_MPL(nn.Module):
             fpt[l] = cabi.BlockWeights(*ptrs)
         w = cabi.Weights()
         w.spt_sets = base
+        w.spt_packed = 1 if (spt3 and L > 0) else 0
         w.spatial_norm_w, w.spatial_norm_b = _ptr(self.Spatial_norm.weight), _ptr(self.Spatial_norm.bias)
         w.pos_3d_embed, w.pos_3d_view_coding = _ptr(self.pos_3d_embed), _ptr(self.pos_3d_view_coding)
         w.pos_3d_linear_w, w.pos_3d_linear_b = _ptr(self.pos_3d_linear.weight), _ptr(self.pos_3d_linear.bias)
@@ -411,7 +427,7 @@ class MultiView_MPL(nn.Module):
         if not (self.deep_head or self.head_kadkhod):
             w.head_ln_w, w.head_ln_b = _ptr(self.head[0].weight), _ptr(self.head[0].bias)
             w.head_w, w.head_b = _ptr(self.head[1].weight), _ptr(self.head[1].bias)
-        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks, w16_keep), cfg=self._config(), fpt_blocks=fpt)
+        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks, w16_keep, spt_keep), cfg=self._config(), fpt_blocks=fpt)
         # the struct blob and the derived copies were enqueued on the stream current NOW: a later forward on another
         # stream must not read them before that work has finished
         ent["ready"] = torch.cuda.Event()
