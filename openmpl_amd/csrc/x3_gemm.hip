@@ -63,6 +63,9 @@ constexpr int X3_T0 = 5;
 #ifndef X3_ABL
 #define X3_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads
 #endif
+#ifndef X3_WT_AUX
+#define X3_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (system scope write-through), 16 = sc1 (agent scope)
+#endif
 #ifndef X3_STAGGER
 #define X3_STAGGER 1   // 1: the waves 4..7 request their DMA pieces three product rows later than the waves 0..3
 #endif
@@ -289,18 +292,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void* base) {
 }
 __device__ __forceinline__ void st16(bool wt, void* base, unsigned off, const bf16x8& v) {
     const u32x4 w = __builtin_bit_cast(u32x4, v);
-    if (wt) __builtin_amdgcn_raw_buffer_store_b128(w, x3_rsrc(base), off, 0, 17);
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(w, x3_rsrc(base), off, 0, X3_WT_AUX);
     else __builtin_amdgcn_raw_buffer_store_b128(w, x3_rsrc(base), off, 0, 0);
 }
 __device__ __forceinline__ void st8(bool wt, void* base, unsigned off, const bf16x8& v) {      // the 4 low bf16 of a fragment
     const u32x4 w = __builtin_bit_cast(u32x4, v);
     const u32x2 h = {w[0], w[1]};
-    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 17);
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, X3_WT_AUX);
     else __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 0);
 }
 __device__ __forceinline__ void st_f2(bool wt, float* base, unsigned off, float x, float y) {
     const u32x2 h = {__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)};
-    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 17);
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, X3_WT_AUX);
     else __builtin_amdgcn_raw_buffer_store_b64(h, x3_rsrc(base), off, 0, 0);
 }
 // L1-bypassing (sc1) loads the compiler tracks (buffer form; `base` wave-uniform, offsets < 2 GiB)

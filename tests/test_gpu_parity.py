@@ -522,6 +522,9 @@ def test_split_operands_follow_in_place_weight_updates():
         base = m(P, rays=R, centers=Cn).clone()
         m.blocks[1].mlp.fc2.weight.mul_(1.25)
         m.blocks[0].attn.qkv.weight.add_(0.01)
+        m.blocks[1].norm2.weight.mul_(0.9)                       # folded into the fc1 operand
+        m.Spatial_blocks[0].mlp.fc1.weight.mul_(1.1)             # SPT operands (mpl_spt_pack) are derived data too
+        m.Spatial_blocks[1].attn.proj.weight.add_(0.02)
         upd = m(P, rays=R, centers=Cn)
     assert not torch.allclose(base, upd)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
@@ -532,3 +535,58 @@ def test_split_operands_follow_in_place_weight_updates():
     with torch.no_grad():
         again = m(P, rays=R, centers=Cn)
     assert torch.equal(again, base)
+
+
+def test_spt_engines_agree_and_packs_are_used():
+    """The SPT stage has two engines: the fp32 matrix instructions on the nn.Linear weights in place ("fp32_mfma",
+    DataParallel replicas) and fp32 arithmetic on the bf16 matrix cores from operands split by mpl_spt_pack (default).
+    Both must reproduce the reference's FPT input tap; the packed one must actually be selected by default."""
+    lib = cabi.load()
+    assert lib.mpl_spt_pack_bytes() == 48 * 1024
+    for name in ("chosen_v4_b8_l12", "full_v4_b8_l2", "conf_attnw_v3_b3_l2"):
+        if name not in SUPPORTED:
+            continue
+        m, g = _model(name)
+        poses, rays, centers = golden_inputs(g, DEV)
+        dev, B, poses, rays, centers = m._check_inputs(poses, rays, centers)
+        taps = {}
+        for prec in ("fp32", "fp32_mfma"):
+            m.set_matmul_precision(prec)
+            ent = m._marshal(dev)
+            assert bool(ent["weights"].spt_packed) == (prec == "fp32")
+            assert bool(ent["keep"][5]) == (prec == "fp32")
+            inp = cabi.Inputs()
+            inp.batch = B
+            for v in range(m.num_views):
+                inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
+            xs = torch.full((B, m.num_views, lib.mpl_fpt_width(C.byref(ent["cfg"]))), float("nan"), device=DEV)
+            cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), _stream()), "spt")
+            taps[prec] = xs.cpu().reshape(-1)
+            _assert_close(taps[prec], torch.from_numpy(g["tap_fpt_in"]).reshape(-1), name + " fpt_in " + prec, tol=2e-5)
+        mx, nw = mpl_oracle.rel_errors(taps["fp32"], taps["fp32_mfma"])
+        assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
+        m.set_matmul_precision("fp32")
+
+
+def test_block_stack_launch_modes_agree():
+    """mpl_x3_stack_mode: the persistent row-tile chains (default) and one launch per GEMM run the same phases; they agree
+    to rounding (<= 4 ulp per GEMM: the fc2 phase is scheduled differently by the compiler), each is deterministic, and the
+    chain kernel is insensitive to a timing perturbation (the debug stamps slow every wave down differently)."""
+    lib = cabi.load()
+    m, g = _model("chosen_v4_b8_l12")
+    P, R, Cn = _big_inputs(1024, 4, 9)
+    dbg = torch.zeros(8 * 8 * 1024, dtype=torch.int64, device=DEV)
+    outs = {}
+    try:
+        with torch.no_grad():
+            for tag, mode, stamps in (("chain", 0, False), ("chain2", 0, False), ("chain_dbg", 0, True), ("gemm", 1, False), ("gemm2", 1, False)):
+                lib.mpl_x3_stack_mode(mode)
+                lib.mpl_x3_debug_buffer(dbg.data_ptr() if stamps else None)
+                outs[tag] = m(P, rays=R, centers=Cn).clone()
+    finally:
+        lib.mpl_x3_stack_mode(0)
+        lib.mpl_x3_debug_buffer(None)
+    assert torch.equal(outs["chain"], outs["chain2"]) and torch.equal(outs["chain"], outs["chain_dbg"])
+    assert torch.equal(outs["gemm"], outs["gemm2"])
+    mx, nw = mpl_oracle.rel_errors(outs["chain"].cpu(), outs["gemm"].cpu())
+    assert mx < 5e-6 and nw < 2e-6, (mx, nw)
