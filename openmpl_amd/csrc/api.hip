@@ -115,8 +115,9 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     int rc;
-    if ((rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
-    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, s))) return rc;
+    // entry of the stack, one launch: the rows as packed operand, their LayerNorm slice partials, zeroed arrival counters
+    const int n_tiles = (M + rpt - 1) / rpt;
+    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, w.stats, w.counters, n_tiles, s))) return rc;
     auto op = [&](const mpl_block_weights& b, int i) -> const uint16_t* {
         return np == 3 ? (&b.qkv_w3)[i] : (&b.qkv_w16)[i];     // {qkv, proj, fc1, fc2} operands of the engine in use
     };
@@ -129,7 +130,7 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
             const mpl_block_weights& b = blocks[schedule[a]];
             for (int i = 0; i < 4; ++i) ops[4 * a + i] = op(b, i);
         }
-        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), np, s);
+        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), np, true, s);
     }
     const int stop = g_x3_stop.load();
     for (int a = 0; a < n_apps; ++a) {
@@ -373,7 +374,7 @@ static int ln_linear_packed(const float* x, int M, int K, int has_ln, float eps,
         if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
     }
     unsigned short* a3 = reinterpret_cast<unsigned short*>(workspace);
-    if ((rc = launch_split_rows(x, M, K, K, 64, a3, np, s))) return rc;
+    if ((rc = launch_split_rows(x, M, K, K, 64, a3, np, nullptr, nullptr, 0, s))) return rc;
     return launch_x3_gemm(a3, W3, has_ln != 0, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, np, s);
 }
 

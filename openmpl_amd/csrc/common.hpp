@@ -80,13 +80,14 @@ void x3_set_debug_buffer(unsigned long long* p);   // bench-only: per-wave phase
 bool x3_attention_fusable(int n_tok, int dim, int heads);
 int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
                         unsigned short* dst, int np, hipStream_t s);
-int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, hipStream_t s);
+int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, float* stats,
+                      unsigned* counters, int n_counters, hipStream_t s);
 int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
                    int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi, int np,
                    hipStream_t s);
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    int stop_after, int np, hipStream_t s);
+                    int stop_after, int np, bool counters_zeroed, hipStream_t s);
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
                             int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);

@@ -212,11 +212,39 @@ int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const f
 
 // ---------------------------------------------------------------------------------------------- activation operand
 // fp32 rows -> A3 (used for the rows that enter a block stack from outside: the SPT output, the unit-test entry)
+// fp32 rows -> packed operand (the rows that enter a block stack from outside: the SPT output, the unit-test entry).
+// One launch also does the two other things the entry of a stack needs: blocks >= nb_split compute the LayerNorm slice
+// partials {mean, M2} of the rows (one wave per row, two-pass: stats != NULL), and block 0 zeroes the arrival counters of
+// the persistent stack kernel (counters != NULL) -- three launches and a memset node in round 2a, one launch now.
 template <int NP>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int M, int K, int ldx, int rpt,
-                                                          char* __restrict__ dst, size_t total) {
+                                                          char* __restrict__ dst, size_t total, int nb_split,
+                                                          float* __restrict__ stats, unsigned* __restrict__ counters,
+                                                          int n_counters) {
+    if ((int)blockIdx.x >= nb_split) {
+        const int lane = threadIdx.x & 63;
+        const int row = ((int)blockIdx.x - nb_split) * 4 + (threadIdx.x >> 6);
+        if (row >= M) return;
+        const int ns = K / BN;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const float* xr = X + (size_t)row * ldx + sidx * BN;
+            const bool on = lane < BN / 4;                       // 34 float4 per 136-column slice
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (on) v = ld4(xr + 4 * lane);
+            const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)BN;
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            const float ss = wave_sum(on ? (a * a + b * b) + (c * c + d * d) : 0.f);
+            if (lane == 0) {
+                stats[((size_t)row * ns + sidx) * 2] = mean;
+                stats[((size_t)row * ns + sidx) * 2 + 1] = ss;
+            }
+        }
+        return;
+    }
+    if (blockIdx.x == 0 && counters)
+        for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0u;
     const int G = K / BN, KS = x3_stages(K, NP), KTA = NP == 3 ? KS : 3 * KS;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)nb_split * 256) {
         const int lane = (int)(idx & 63);
         const int kt = (int)((idx >> 6) % KTA);
         const size_t rgi = idx / ((size_t)64 * KTA);          // tile * 4 + row group
@@ -245,14 +273,22 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
-int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, hipStream_t s) {
+// stats / counters optional (see the kernel)
+int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, float* stats,
+                      unsigned* counters, int n_counters, hipStream_t s) {
     if (!X || !dst || x3_act_bytes(M, K, rpt, np) == 0 || (ldx & 3) || (np != 1 && np != 3)) return MPL_E_INVALID;
     const size_t tiles = ((size_t)M + rpt - 1) / rpt;
     const int KS = x3_stages(K, np), KTA = np == 3 ? KS : 3 * KS;
     const size_t total = tiles * 4 * KTA * 64;
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (np == 3) hipLaunchKernelGGL(split_rows_kernel<3>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total);
-    else hipLaunchKernelGGL(split_rows_kernel<1>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total);
+    const int nb_split = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const int grid = nb_split + (stats ? (M + 3) / 4 : 0);
+    ProfScope prof(MPL_K_ROW_STATS, s);
+    if (np == 3)
+        hipLaunchKernelGGL(split_rows_kernel<3>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total,
+                           nb_split, stats, counters, n_counters);
+    else
+        hipLaunchKernelGGL(split_rows_kernel<1>, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total,
+                           nb_split, stats, counters, n_counters);
     return hip_check_launch();
 }
 
@@ -1096,7 +1132,7 @@ static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
 
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    int stop_after, int np, hipStream_t s) {
+                    int stop_after, int np, bool counters_zeroed, hipStream_t s) {
     if (!x || !ops || !x3 || !att3 || !hid3 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
         !x3_attention_fusable(n_tok, D, heads) || !x3_shape_ok(D, 2 * D) || M % n_tok || (np != 1 && np != 3))
         return MPL_E_INVALID;
@@ -1132,8 +1168,9 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
             if (!ops[4 * i + j]) return MPL_E_INVALID;
             a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
         }
-    // per-call state: the arrival counter of every row tile
-    if (hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
+    // per-call state: the arrival counter of every row tile (the entry kernel of the stack has already zeroed them when
+    // it ran in front of this launch)
+    if (!counters_zeroed && hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     return np == 3 ? launch_stack_np<3>(a, dev, s) : launch_stack_np<1>(a, dev, s);
 }
 
