@@ -510,21 +510,6 @@ constexpr int SPT_PACK_BYTES = 48 * 1024;
 
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
 
-// GELU with erf from Abramowitz & Stegun 7.1.26 (|error| of erf <= 1.5e-7 in exact arithmetic, 6e-7 in fp32; the GELU
-// value is as close to the fp64 one as with an fp32 libm erf: 4.7e-7 vs 4.4e-7 max abs over [-6, 6]) on the hardware
-// reciprocal and exp2: ~16 instructions instead of the ~40 of erff -- the MLP activation is a third of the fc1 phase.
-__device__ __forceinline__ float gelu_as(float x) {
-    const float z = x * 0.70710678118654752440f, az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
-    const float er = copysignf(fmaf(-pl * t, e, 1.0f), z);
-    return 0.5f * x * (1.0f + er);
-}
-
 __device__ __forceinline__ void spt_split3(const float (&x)[8], sbf16x8& hi, sbf16x8& mid, sbf16x8& lo) {
     float r[8], r2[8];
 #pragma unroll

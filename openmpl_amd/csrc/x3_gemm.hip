@@ -60,6 +60,10 @@ constexpr int X3_STAGE = X3_A + X3_W;        // 39936
 constexpr int X3_NST = 4;                    // ring depth (159744 B of LDS, one workgroup per CU)
 constexpr int X3_MAX_WGS = 1024;             // workgroups of x3_stack_kernel (one per CU: 256 on MI355X)
 constexpr int X3_T0 = 5;
+#ifndef X3_DBG
+#define X3_DBG 0   // 1: per-wave s_memtime stamps for mpl_x3_debug_buffer (tools/chain_phase.py, tools/x3_phase.py build with
+                   // MPL_HIPCC_FLAGS=-DX3_DBG=1); 0: the stamps, their branches and ~14 SGPRs are compiled out of the k loops
+#endif
 #ifndef X3_ABL
 #define X3_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads
 #endif
@@ -317,6 +321,8 @@ void x3_set_debug_buffer(unsigned long long* p) { g_x3_dbg.store(p); }
 
 enum { X3_EPI_BIAS = 0, X3_EPI_GELU = 1, X3_EPI_RES = 2, X3_EPI_ATT = 3 };
 
+constexpr int X3_VEC = X3_NST * X3_STAGE;   // the 4 KiB of LDS above the ring: the epilogue vectors [pass][c | s][136] of a phase
+constexpr int X3_LDS_BYTES = X3_VEC + 4096;  // = 160 KiB
 constexpr int X3_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the attention epilogue
 
 // ---- stores / loads of data that crosses workgroups INSIDE a launch (chain mode, see x3_stack_kernel): write-through
@@ -383,41 +389,71 @@ __device__ __forceinline__ void zero_pad_tiles(bool wt, char* strip, int Kout, i
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
+// NT, HD4 > 0: tokens per sequence and head width / 4 known at compile time (the headline shape, 4 views and 68-wide
+// heads: every loop unrolls, a thread's 34 LDS reads of the score are in flight together and the softmax of a score row
+// -- it sits in four adjacent lanes -- is two cross-lane exchanges; the generic form spent 18 k cycles per qkv phase in
+// LDS latency chains).  NT = HD4 = 0: run-time sizes.
+template <int NP, int NT, int HD4>
+__device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt_rt, int hd_rt, int S, char* C3, int tile_m,
                                              int g_out, int Dq) {
+    const int nt = NT ? NT : nt_rt, hd = HD4 ? 4 * HD4 : hd_rt;
     const int hd4 = hd >> 2;
     const int HP = BN / hd, nn = nt * nt;
     const float scale = 1.0f / sqrtf((float)hd);
-    for (int t = tid; t < S * HP * nn; t += 512) {
-        const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
-        const float* q = T + (sq * nt + i) * X3_ATT_TS + hh * hd;
-        const float* k = T + (sq * nt + j) * X3_ATT_TS + BN + hh * hd;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int e = 0; e < hd4; ++e) {
-            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
-            s0 = fmaf(a.x, b.x, s0);
-            s1 = fmaf(a.y, b.y, s1);
-            s2 = fmaf(a.z, b.z, s2);
-            s3 = fmaf(a.w, b.w, s3);
+    if constexpr (NT == 4) {
+        for (int t = tid; t < S * HP * 16; t += 512) {
+            const int j = t & 3, i = (t >> 2) & 3, hh = (t >> 4) % HP, sq = t / (16 * HP);
+            const float* q = T + (sq * 4 + i) * X3_ATT_TS + hh * hd;
+            const float* k = T + (sq * 4 + j) * X3_ATT_TS + BN + hh * hd;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int e = 0; e < hd4; ++e) {
+                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+                s0 = fmaf(a.x, b.x, s0);
+                s1 = fmaf(a.y, b.y, s1);
+                s2 = fmaf(a.z, b.z, s2);
+                s3 = fmaf(a.w, b.w, s3);
+            }
+            const float sc = ((s0 + s1) + (s2 + s3)) * scale;
+            float mx = fmaxf(sc, __shfl_xor(sc, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            const float e = __expf(sc - mx);
+            float l = e + __shfl_xor(e, 1, 64);
+            l += __shfl_xor(l, 2, 64);
+            SC[t] = e * (1.0f / l);
         }
-        SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
-    }
-    __syncthreads();
-    for (int t = tid; t < S * HP * nt; t += 512) {
-        float* pr = SC + t * nt;
-        float mx = pr[0];
-        for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
-        float l = 0.f;
-        for (int j = 0; j < nt; ++j) {
-            const float e = __expf(pr[j] - mx);
-            pr[j] = e;
-            l += e;
+        __syncthreads();
+    } else {
+        for (int t = tid; t < S * HP * nn; t += 512) {
+            const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
+            const float* q = T + (sq * nt + i) * X3_ATT_TS + hh * hd;
+            const float* k = T + (sq * nt + j) * X3_ATT_TS + BN + hh * hd;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int e = 0; e < hd4; ++e) {
+                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+                s0 = fmaf(a.x, b.x, s0);
+                s1 = fmaf(a.y, b.y, s1);
+                s2 = fmaf(a.z, b.z, s2);
+                s3 = fmaf(a.w, b.w, s3);
+            }
+            SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
         }
-        const float inv = 1.0f / l;
-        for (int j = 0; j < nt; ++j) pr[j] *= inv;
+        __syncthreads();
+        for (int t = tid; t < S * HP * nt; t += 512) {
+            float* pr = SC + t * nt;
+            float mx = pr[0];
+            for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
+            float l = 0.f;
+            for (int j = 0; j < nt; ++j) {
+                const float e = __expf(pr[j] - mx);
+                pr[j] = e;
+                l += e;
+            }
+            const float inv = 1.0f / l;
+            for (int j = 0; j < nt; ++j) pr[j] *= inv;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // P.V and the A3 fragments of the output rows: task = (row, quarter p, lane quarter kq) -> 8 values = the two
     // 4-column chunks 32p + 4kq and 32p + 16 + 4kq; tail tasks (row, kq < 2) -> 4 values at 128 + 4kq
     const int Go = Dq / BN;
@@ -430,13 +466,26 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
             const int hh = c / hd;
             const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
             const float* v = T + (sq * nt) * X3_ATT_TS + 2 * BN + c;
-            for (int j = 0; j < nt; ++j) {
-                const float4 vv = ld4(v + j * X3_ATT_TS);
-                const float pj = pr[j];
-                o.x = fmaf(pj, vv.x, o.x);
-                o.y = fmaf(pj, vv.y, o.y);
-                o.z = fmaf(pj, vv.z, o.z);
-                o.w = fmaf(pj, vv.w, o.w);
+            if constexpr (NT == 4) {
+                const float4 p4 = ld4(pr);
+                const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 vv = ld4(v + j * X3_ATT_TS);
+                    o.x = fmaf(pj[j], vv.x, o.x);
+                    o.y = fmaf(pj[j], vv.y, o.y);
+                    o.z = fmaf(pj[j], vv.z, o.z);
+                    o.w = fmaf(pj[j], vv.w, o.w);
+                }
+            } else {
+                for (int j = 0; j < nt; ++j) {
+                    const float4 vv = ld4(v + j * X3_ATT_TS);
+                    const float pj = pr[j];
+                    o.x = fmaf(pj, vv.x, o.x);
+                    o.y = fmaf(pj, vv.y, o.y);
+                    o.z = fmaf(pj, vv.z, o.z);
+                    o.w = fmaf(pj, vv.w, o.w);
+                }
             }
         }
         return o;
@@ -480,7 +529,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     const int KT = x3_stages(K, NP);             // stages per pass (k-tiles of 32 in three parts / triples of k-tiles)
     const int T = NPASS * KT;
     auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
-    const unsigned long long t_entry = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_entry = (X3_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- DMA slots of this wave.  A3: waves 0..3 bring the 3 KiB of row group `wave`; W3: waves 4..7 pieces 4(w-4)..+3,
     // waves 0..2 pieces 16+3w..+2, wave 3 pieces 25, 26.  Source and destination of a run are contiguous: one M0 write.
@@ -554,6 +603,18 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         ia_slot += X3_STAGE;
         if (ia_slot == NST * X3_STAGE) ia_slot = 0;
     };
+    // ---- the epilogue vectors of this workgroup's columns (c, and s of a folded LayerNorm) into the spare 4 KiB of LDS,
+    // one LDS-DMA instruction per wave 0..3 at the FRONT of the queue (older than every counted piece): the epilogue
+    // then reads them at LDS latency instead of one global round trip per column tile
+    if (HAS_A) {
+        constexpr int NV = NPASS * 2 * (BN / 4);                   // float4s: [pass][c | s][34]
+        int idx = wave * 64 + lane;
+        const bool on = idx < NV && (LNF || !((idx / (BN / 4)) & 1));
+        idx = on ? idx : 0;
+        const int vp = idx / (2 * (BN / 4)), which = (idx / (BN / 4)) & 1, c4 = idx % (BN / 4);
+        const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
+        dma16(src, lds0 + (unsigned)(X3_VEC + wave * 1024));
+    }
     // ---- prologue: the first NST stages.  W first (chain mode: before the wait for the other workgroups), then A.
     // In-order queue of this wave after the prologue:  W(0) .. W(NST-1)  A(0) [A(k) of the later pass-0 stages].
 #pragma unroll
@@ -661,7 +722,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         read_b(0, B0);
     }
     if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(1);
-    const unsigned long long t_loop = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_loop = (X3_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_vm = 0, t_bar = 0;      // bench-only: cycles at the counted DMA wait / at lgkmcnt + barrier
     unsigned slot_c = 0;
     // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage
@@ -671,7 +732,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         const unsigned slot_n = slot_after(slot_c);
         const bool more = t + 1 < T;
         unsigned long long w0 = 0, w1 = 0;
-        if (a.dbg) w0 = __builtin_amdgcn_s_memtime();
+        if (X3_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
         if (more) {
             // own pieces of stage t+1 landed (stages t+2, t+3 may stay in flight); every fragment read of stage t has
             // returned: the barrier must not be passed before, the slot of stage t is refilled right after it.
@@ -686,11 +747,11 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             else if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
             else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
+            if (X3_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
+            if (X3_DBG && a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
         }
         const bf16x8* bs = reinterpret_cast<const bf16x8*>(smem + slot_n + X3_A) + slot0 * 3 * 64 + lane;
         auto rd_b = [&](int n) {
@@ -799,7 +860,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
 
     if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(0);
     // ------------------------------------------------------------------------------------------ epilogue
-    const unsigned long long t_epi = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_epi = (X3_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     float mu = 0.f, rs = 1.f;
     if (LNF) {
         float st[16];
@@ -826,12 +887,12 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     auto value4 = [&](int p, int n, float (&v)[4]) {
         const int cl = 16 * tile_of(n) + 4 * kq;
         const bool ok = cl + 3 < BN;
-        const int cg = colbase(p) + (ok ? cl : 0);
-        const float4 cv = ld4(a.cvec + cg);
+        const float* vecs = reinterpret_cast<const float*>(smem + X3_VEC) + p * 2 * BN + (ok ? cl : 0);
+        const float4 cv = ld4(vecs);
         const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         if (LNF) {
-            const float4 sv = ld4(a.svec + cg);
+            const float4 sv = ld4(vecs + BN);
             s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
         }
 #pragma unroll
@@ -841,7 +902,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             float t = acc[p][n][r];
             if (LNF) t = fmaf(rs, fmaf(-mu, s4[r], t), c4[r]);
             else t += c4[r];
-            if (EPI == X3_EPI_GELU) t = gelu_erf(t);
+            if (EPI == X3_EPI_GELU) t = gelu_as(t);
             v[r] = ok ? t : 0.f;
         }
     };
@@ -863,7 +924,8 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        x3_attention<NP>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+        if (a.att_ntok == 4 && a.att_hd == 68) x3_attention<NP, 4, 17>(WT, Tt, SC, tid, 4, 68, a.rpt / 4, a.C3, tm, n0 / BN, Dq);
+        else x3_attention<NP, 0, 0>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
     } else {
         const int Go = N / BN;
         char* cbase = a.C3 + ((size_t)tm * 4 + rg) * x3_stages(N, NP) * X3_RG;   // this wave's row group of the output operand
@@ -898,7 +960,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 if (NP == 1 && g_out == 0 && HAS_A) zero_pad_tiles<NP>(WT, cbase, N, lane);
             }
         }
-        if (a.dbg) t_st = __builtin_amdgcn_s_memtime();
+        if (X3_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
         if constexpr (EPI == X3_EPI_RES) {
             if (a.stats_out) {
                 // LayerNorm partials {mean, M2} of the 136-column slice of each row: a row's values sit in the 4 kq lanes
@@ -942,7 +1004,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (a.dbg) {   // bench-only: entry, loop start, loop end, stores issued, stores drained (shader clock), wait sums
+    if (X3_DBG && a.dbg) {   // bench-only: entry, loop start, loop end, stores issued, stores drained (shader clock), wait sums
         if (!t_st) t_st = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -1059,7 +1121,7 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
 
 template <int NP, int EPI, bool LNF, int NPASS>
 static int launch_x3(const X3Args& a, hipStream_t s) {
-    constexpr int LDS = X3_NST * X3_STAGE;
+    constexpr int LDS = X3_LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static std::atomic<bool> attr_set[64];   // set-once flags: a racing second hipFuncSetAttribute is harmless
     int dev = 0;
@@ -1118,7 +1180,7 @@ int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, 
 // The whole block stack in one launch (see x3_stack_kernel).  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands.
 template <int NP>
 static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
-    constexpr int LDS = X3_NST * X3_STAGE;
+    constexpr int LDS = X3_LDS_BYTES;
     static std::atomic<bool> attr_set[64];
     if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)x3_stack_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

@@ -1,0 +1,48 @@
+"""Per-phase time line of the persistent stack kernel (chain mode) at the headline shape: the stack is stopped after
+phase p (mpl_x3_stack_mode) so that the per-wave stamps of mpl_x3_debug_buffer are those of phase p.
+python tools/chain_phase.py [D] [n_blocks] [M]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from openmpl_amd import cabi
+
+lib = cabi.load()
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 544
+NB = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+M, dev = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), "cuda"
+st = lambda: torch.cuda.current_stream().cuda_stream
+g = torch.Generator().manual_seed(0)
+def operand(N, K, ln):
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
+    gam = (torch.rand(K, generator=g) + 0.5).to(dev); bet = (torch.randn(K, generator=g) * 0.1).to(dev)
+    o = torch.empty(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=dev)
+    cabi.check(lib.mpl_split_bf16x3(W.data_ptr(), b.data_ptr(), gam.data_ptr() if ln else None, bet.data_ptr() if ln else None, N, K, o.data_ptr(), st()), "split")
+    return o
+blk = cabi.BlockWeights()
+keep = [operand(3 * D, D, True), operand(D, D, False), operand(2 * D, D, True), operand(D, 2 * D, False)]
+blk.qkv_w3, blk.proj_w3, blk.fc1_w3, blk.fc2_w3 = (k.data_ptr() for k in keep)
+blks = (cabi.BlockWeights * 1)(blk)
+x = torch.randn(M, D, generator=g).to(dev)
+wsb = lib.mpl_block_stack_workspace_bytes(M // 4, 4, D)
+ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+dbg = torch.zeros(8 * 8 * 1024, dtype=torch.int64, device=dev)
+names = ["qkv+att", "proj+res", "fc1+gelu", "fc2+res"]
+sched = (C.c_uint8 * NB)(*([0] * NB))
+def run():
+    cabi.check(lib.mpl_block_stack(x.data_ptr(), M // 4, 4, D, 8, blks, sched, NB, ws.data_ptr(), wsb, st()), "stack")
+for _ in range(3): run()
+torch.cuda.synchronize()
+prev_end = None
+for stop in range(4 * (NB - 1) - 1, 4 * NB + 1):
+    lib.mpl_x3_stack_mode(stop << 8)
+    dbg.zero_()
+    lib.mpl_x3_debug_buffer(dbg.data_ptr()); run(); torch.cuda.synchronize(); lib.mpl_x3_debug_buffer(None)
+    t = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    t = t[t[:, 0] > 0]
+    ph = (stop - 1) & 3
+    nst = {0: 3, 1: 1, 2: 2, 3: 2}[ph] * (D // 32)
+    ent, loop, epi, sto, end = (t[:, i] for i in range(5))
+    print("stop %2d %-9s waves %4d | entry->loop %6.0f (min %6.0f max %6.0f) | k loop %7.0f (%5.0f/stage, %d stages) | epilogue %6.0f | drain %5.0f | total %7.0f | DMA wait/stage %4.0f  bar/stage %4.0f"
+          % (stop, names[ph], len(t), (loop - ent).mean(), (loop - ent).min(), (loop - ent).max(), (epi - loop).mean(), (epi - loop).mean() / nst, nst,
+             (sto - epi).mean(), (end - sto).mean(), (end - ent).mean(), t[:, 5].mean() / nst, t[:, 6].mean() / nst))
+lib.mpl_x3_stack_mode(0)
