@@ -35,6 +35,7 @@ def source_hash() -> str:
     """Content hash of everything the library is built from (mtimes do not survive the snapshot copy to a GPU box)."""
     import hashlib
     h = hashlib.sha256()
+    h.update(os.environ.get("MPL_HIPCC_FLAGS", "").encode())      # a build with other flags is another library
     for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
