@@ -533,8 +533,8 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
 
     // ---- DMA slots of this wave.  A3: waves 0..3 bring the 3 KiB of row group `wave`; W3: waves 4..7 pieces 4(w-4)..+3,
     // waves 0..2 pieces 16+3w..+2, wave 3 pieces 25, 26.  Source and destination of a run are contiguous: one M0 write.
-    const int w_first = wave >= 4 ? 4 * (wave - 4) : 16 + 3 * wave;
-    const int w_cnt = wave >= 4 ? 4 : (wave == 3 ? 2 : 3);
+    const int w_first = HAS_A ? 16 + 3 * wave : 4 * (wave - 4);
+    const int w_cnt = HAS_A ? (wave == 3 ? 2 : 3) : 4;
     unsigned voA = (unsigned)(lane * 16), voW = (unsigned)(lane * 16 + w_first * 1024);
     asm volatile("" : "+v"(voA), "+v"(voW));
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -602,6 +602,55 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         ++ia_t;
         ia_slot += X3_STAGE;
         if (ia_slot == NST * X3_STAGE) ia_slot = 0;
+    };
+    // The same requests for the steady state of the k loop (see `stage`): the pass of the W stage and whether the stage
+    // carries A are compile-time constants of the call site, the destination is the slot the current stage just released
+    // (stage t+NST lives where stage t lived): no dispatch, no ring arithmetic, no bookkeeping.
+    auto refill_fast = [&](auto wp_c, auto ai_c, unsigned slot) {
+        constexpr int g = decltype(wp_c)::value;
+        constexpr bool with_a = decltype(ai_c)::value;
+        const unsigned keep = dma_m0_save();
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:1024"
+            :
+            : "v"(voW), "s"(is_w[g]), "s"(lds0 + slot + (unsigned)(X3_A + w_first * 1024))
+            : "memory");
+        if (w_cnt > 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(is_w[g]) : "memory");
+        if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(is_w[g]) : "memory");
+        is_w[g] += X3_W;
+        if (with_a && HAS_A) {
+            if (CHAIN)
+                asm volatile(
+                    "s_mov_b32 m0, %2\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %0, %1 sc1\n\t"
+                    "global_load_lds_dwordx4 %0, %1 offset:1024 sc1\n\t"
+                    "global_load_lds_dwordx4 %0, %1 offset:2048 sc1"
+                    :
+                    : "v"(voA), "s"(is_a), "s"(lds0 + slot + (unsigned)(wave * X3_RG))
+                    : "memory");
+            else
+                asm volatile(
+                    "s_mov_b32 m0, %2\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %0, %1\n\t"
+                    "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                    "global_load_lds_dwordx4 %0, %1 offset:2048"
+                    :
+                    : "v"(voA), "s"(is_a), "s"(lds0 + slot + (unsigned)(wave * X3_RG))
+                    : "memory");
+        }
+        if (with_a) is_a += X3_RG;
+        dma_m0_restore(keep);
+    };
+    // generic bookkeeping <- the state after fast stages, before generic stage t_next
+    auto resync = [&](int t_next, unsigned slot) {
+        iw_t = ia_t = t_next + NST;
+        iw_g = iw_t % NPASS;
+        iw_slot = ia_slot = slot;
     };
     // ---- the epilogue vectors of this workgroup's columns (c, and s of a folded LayerNorm) into the spare 4 KiB of LDS,
     // one LDS-DMA instruction per wave 0..3 at the FRONT of the queue (older than every counted piece): the epilogue
@@ -675,7 +724,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
         }
     };
-    const int t_ops = T >= 8 ? T - 5 : 0;
+    const int t_ops = T >= 8 ? T - 4 : 0;       // always a generic stage (the fast ones end at T - 5)
 
     f32x4 acc[NPASS][NTW];
 #pragma unroll
@@ -727,10 +776,15 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     unsigned slot_c = 0;
     // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage
     // t with the fragment reads of stage t+1 in between
-    auto stage = [&](int t, f32x4 (&accp)[NTW], const bf16x8 (&a_cur)[3], bf16x8 (&a_nxt)[3], const bf16x8 (&b_cur)[NTW][3],
-                     bf16x8 (&b_nxt)[NTW][3], bool next_has_a) {
+    // FAST (tag fast_c): a stage of the steady state -- t + NST < T, so there is a next stage, a refill, and the standard
+    // counted wait: none of the run-time case distinctions of the generic form (which the first stages of a one-pass GEMM
+    // and the last NST stages use) and of its ~50 scalar instructions and ~15 branches per stage; the pass WP of the
+    // refilled stage and whether it carries A (AI) come from the call site.
+    auto stage = [&](auto fast_c, auto wp_c, auto ai_c, int t, f32x4 (&accp)[NTW], const bf16x8 (&a_cur)[3], bf16x8 (&a_nxt)[3],
+                     const bf16x8 (&b_cur)[NTW][3], bf16x8 (&b_nxt)[NTW][3], bool next_has_a) {
+        constexpr bool FAST = decltype(fast_c)::value;
         const unsigned slot_n = slot_after(slot_c);
-        const bool more = t + 1 < T;
+        const bool more = FAST || t + 1 < T;
         unsigned long long w0 = 0, w1 = 0;
         if (X3_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
         if (more) {
@@ -742,7 +796,8 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             // one-pass GEMM is complete once at most A(2), A(3) are outstanding.
             constexpr int MINP = NPASS == 1 ? (HAS_A ? 5 : 4) : (HAS_A ? 2 : 4);
             static_assert(NST == 4, "the counted waits assume three stages in flight");
-            if (NPASS == 1 && HAS_A && t == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // A(2) A(3)
+            if (FAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
+            else if (NPASS == 1 && HAS_A && t == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // A(2) A(3)
             else if (NPASS == 1 && HAS_A && t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A(3) W(4) A(4)
             else if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
             else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
@@ -762,11 +817,15 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
         };
         auto refill = [&]() {
-            if (more && iw_t < T && !((X3_ABL & 2) && t > 0)) {   // stage t+NST into the slot of stage t
-                issue_w();
-                issue_a();
+            if constexpr (FAST) {
+                if (!(X3_ABL & 2)) refill_fast(wp_c, ai_c, slot_c);
+            } else {
+                if (more && iw_t < T && !((X3_ABL & 2) && t > 0)) {   // stage t+NST into the slot of stage t
+                    issue_w();
+                    issue_a();
+                }
+                if (t == t_ops) epilogue_operands();
             }
-            if (t == t_ops) epilogue_operands();
         };
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NP == 3) {
@@ -819,42 +878,79 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         }
         slot_c = slot_n;
     };
+    using GEN = std::integral_constant<bool, false>;
+    using FST = std::integral_constant<bool, true>;
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using AY = std::integral_constant<bool, true>;
+    using AN = std::integral_constant<bool, false>;
+    // head (generic) -> steady state (fast) -> tail (generic): three loops one after the other, so that the fragment
+    // ping-pong registers never meet at a join of a fast and a generic path
     if constexpr (NPASS == 1) {
         int kt = 0;
-        for (; kt + 1 < KT; kt += 2) {
-            stage(kt, acc[0], A0, A1, B0, B1, true);
-            stage(kt + 1, acc[0], A1, A0, B1, B0, true);
+        if (KT > 1) {                            // the two stages with the special waits after the W-first prologue
+            stage(GEN{}, W0{}, AY{}, 0, acc[0], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, 1, acc[0], A1, A0, B1, B0, true);
+            kt = 2;
         }
-        if (kt < KT) stage(kt, acc[0], A0, A1, B0, B1, true);
+        for (; kt + 5 < T; kt += 2) {            // both stages refill: t + NST < T
+            stage(FST{}, W0{}, AY{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(FST{}, W0{}, AY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+        }
+        resync(kt, slot_c);
+        for (; kt + 1 < KT; kt += 2) {
+            stage(GEN{}, W0{}, AY{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) stage(GEN{}, W0{}, AY{}, kt, acc[0], A0, A1, B0, B1, true);
     } else if constexpr (NPASS == 2) {
         // two column groups share the A fragment of the k-tile; the second stage prefetches the next k-tile's.  The A
         // ping-pong alternates per k-tile; two stages per k-tile keep the B parity the same in every k-tile.
+        // Stage t refills stage t + 4: pass t % 2, with A when that is 0.
         int kt = 0;
+        for (; 2 * kt + 7 < T; kt += 2) {
+            stage(FST{}, W0{}, AY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+        }
+        resync(2 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(2 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(2 * kt + 1, acc[1], A0, A1, B1, B0, true);
-            stage(2 * kt + 2, acc[0], A1, A1, B0, B1, false);
-            stage(2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
         }
         if (kt < KT) {
-            stage(2 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
         }
     } else {
-        // k-tile by k-tile: q, k, v stages share the A fragment; three stages per k-tile flip the B parity every k-tile
+        // k-tile by k-tile: q, k, v stages share the A fragment; three stages per k-tile flip the B parity every k-tile.
+        // Stage t = 3 kt + j refills stage t + 4: pass (j + 1) % 3, with A when that is 0.
         int kt = 0;
+        for (; 3 * kt + 9 < T; kt += 2) {
+            stage(FST{}, W1{}, AN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W2{}, AN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(FST{}, W0{}, AY{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(FST{}, W1{}, AN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(FST{}, W2{}, AN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(FST{}, W0{}, AY{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+        }
+        resync(3 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(3 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(3 * kt + 1, acc[1], A0, A0, B1, B0, false);
-            stage(3 * kt + 2, acc[2], A0, A1, B0, B1, true);
-            stage(3 * kt + 3, acc[0], A1, A1, B1, B0, false);
-            stage(3 * kt + 4, acc[1], A1, A1, B0, B1, false);
-            stage(3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
         }
         if (kt < KT) {
-            stage(3 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(3 * kt + 1, acc[1], A0, A0, B1, B0, false);
-            stage(3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
         }
     }
 
