@@ -65,7 +65,7 @@ constexpr int X3_T0 = 5;
                    // MPL_HIPCC_FLAGS=-DX3_DBG=1); 0: the stamps, their branches and ~14 SGPRs are compiled out of the k loops
 #endif
 #ifndef X3_ABL
-#define X3_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads
+#define X3_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA
 #endif
 #ifndef X3_WT_AUX
 #define X3_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (system scope write-through), 16 = sc1 (agent scope)
@@ -664,11 +664,11 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
         dma16(src, lds0 + (unsigned)(X3_VEC + wave * 1024));
     }
-    // ---- prologue: the first NST stages.  W first (chain mode: before the wait for the other workgroups), then A.
-    // In-order queue of this wave after the prologue:  W(0) .. W(NST-1)  A(0) [A(k) of the later pass-0 stages].
-#pragma unroll
-    for (int t = 0; t < NST; ++t)
-        if (t < T) issue_w();
+    // ---- prologue: the first NST stages in stage order, W before A inside a stage.  Chain mode: W(0) does not depend on
+    // the other workgroups and is requested BEFORE the wait for them; everything else after it, A(0) first -- the LDS-DMA
+    // path of a CU moves ~1 KiB per 24 cycles, and with the whole W prologue in front of it (round 2a) A(0) landed
+    // ~2.5 k cycles later than it does now.  In-order queue of this wave:  W(0) A(0) | W(1) [A(1)] | W(2) [A(2)] | W(3) [A(3)].
+    issue_w();
     if (CHAIN) {
         if (tid == 0) {
             // one lane polls (relaxed, L2-bypassing); bounded so that a lost partner cannot hang the GPU: after ~2 s the
@@ -678,11 +678,16 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 __builtin_amdgcn_s_sleep(2);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();      // control dependency only: the A requests below are issued after the poll succeeded
+        asm volatile("" ::: "memory");
     }
+    issue_a();
 #pragma unroll
-    for (int t = 0; t < NST; ++t)
-        if (t < T) issue_a();
+    for (int t = 1; t < NST; ++t)
+        if (t < T) {
+            issue_w();
+            issue_a();
+        }
 
     const int row_l = rg * 16 + li;
     const bool row_ok = row_l < a.rpt && m0 + row_l < M;
@@ -724,7 +729,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
         }
     };
-    const int t_ops = T >= 8 ? T - 4 : 0;       // always a generic stage (the fast ones end at T - 5)
+    const int t_ops = T - 4;                    // always a generic stage (the fast ones end at T - 5; T >= 6)
 
     f32x4 acc[NPASS][NTW];
 #pragma unroll
@@ -759,12 +764,13 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     // the burst -- with its SIMD partner, which is in the same phase -- while the matrix pipe idles.
     auto mfma_row = [&](f32x4 (&accp)[NTW], const bf16x8& af, const bf16x8 (&bf)[NTW][3], int bp) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n][bp], af, accp[n], 0, 0, 0);
+        for (int n = 0; n < NTW; ++n)
+            if (!(X3_ABL & 8)) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[n][bp], af, accp[n], 0, 0, 0);
     };
-    {   // stage 0 landed for everyone: the wave's queue is W(0..3) A(0) A(later): everything up to A(0) must be in
-        constexpr int A_LATER = NPASS == 1 ? 3 : (NPASS == 2 ? 1 : 1);   // pass-0 stages among stages 1..3
-        if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * A_LATER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12) : "memory");            // W(1..3), four pieces each
+    {   // stage 0 landed for everyone: at most the pieces of stages 1..3 of this wave are outstanding (counted with the
+        // fewest pieces a wave of the role has: W pieces 2 (wave 3) / 4, A pieces 3 in the stages of pass 0)
+        constexpr int LATER = HAS_A ? (NPASS == 1 ? 15 : 9) : 12;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_a(0, A0);
@@ -792,13 +798,10 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             // returned: the barrier must not be passed before, the slot of stage t is refilled right after it.
             // The wait is an immediate, counted with the SMALLEST number of pieces any wave of the role has per stage
             // (conservative: a wave with more pieces then also waits for part of stage t+2, requested two stage times
-            // ago).  After the W-first prologue the queue of an A-carrying wave ends with A(0) A(later): stage 1 of a
-            // one-pass GEMM is complete once at most A(2), A(3) are outstanding.
+            // ago).  The queue is in stage order from the prologue on (every GEMM has >= 6 stages: K % 544 == 0).
             constexpr int MINP = NPASS == 1 ? (HAS_A ? 5 : 4) : (HAS_A ? 2 : 4);
             static_assert(NST == 4, "the counted waits assume three stages in flight");
             if (FAST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
-            else if (NPASS == 1 && HAS_A && t == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // A(2) A(3)
-            else if (NPASS == 1 && HAS_A && t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // A(3) W(4) A(4)
             else if (t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINP) : "memory");
             else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -889,11 +892,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     // ping-pong registers never meet at a join of a fast and a generic path
     if constexpr (NPASS == 1) {
         int kt = 0;
-        if (KT > 1) {                            // the two stages with the special waits after the W-first prologue
-            stage(GEN{}, W0{}, AY{}, 0, acc[0], A0, A1, B0, B1, true);
-            stage(GEN{}, W0{}, AY{}, 1, acc[0], A1, A0, B1, B0, true);
-            kt = 2;
-        }
         for (; kt + 5 < T; kt += 2) {            // both stages refill: t + NST < T
             stage(FST{}, W0{}, AY{}, kt, acc[0], A0, A1, B0, B1, true);
             stage(FST{}, W0{}, AY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
