@@ -73,12 +73,6 @@ constexpr int X3_T0 = 5;
 #ifndef X3_STAGGER
 #define X3_STAGGER 1   // 1: the waves 4..7 request their DMA pieces three product rows later than the waves 0..3
 #endif
-#ifndef X3_PRIO
-#define X3_PRIO 0      // 1: static s_setprio 1 for the younger half (waves 4..7)
-#endif
-#ifndef X3_CHAIN_WT
-#define X3_CHAIN_WT 1   // chain mode hand-offs: 1 = write-through stores + L1-bypassing loads, 0 = plain accesses + agent fences
-#endif                     // slots of waves 0..3; waves 4..7 take the other 4
 
 __host__ __device__ constexpr int x3_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
 
@@ -776,7 +770,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         read_a(0, A0);
         read_b(0, B0);
     }
-    if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(1);
     const unsigned long long t_loop = (X3_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_vm = 0, t_bar = 0;      // bench-only: cycles at the counted DMA wait / at lgkmcnt + barrier
     unsigned slot_c = 0;
@@ -952,7 +945,6 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         }
     }
 
-    if (X3_PRIO && !HAS_A) __builtin_amdgcn_s_setprio(0);
     // ------------------------------------------------------------------------------------------ epilogue
     const unsigned long long t_epi = (X3_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     float mu = 0.f, rs = 1.f;
