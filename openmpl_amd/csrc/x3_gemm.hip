@@ -662,11 +662,17 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     // the other workgroups and is requested BEFORE the wait for them; everything else after it, A(0) first -- the LDS-DMA
     // path of a CU moves ~1 KiB per 24 cycles, and with the whole W prologue in front of it (round 2a) A(0) landed
     // ~2.5 k cycles later than it does now.  In-order queue of this wave:  W(0) A(0) | W(1) [A(1)] | W(2) [A(2)] | W(3) [A(3)].
+    // The poll is the job of wave 7 (lane 0): its FIRST look at the counter goes out before any DMA piece of the wave --
+    // loads return in order, and behind W(0) the answer would take a DMA round trip (~2 k cycles) even for the workgroup
+    // that arrived last and has nothing to wait for (the one that sets the pace of its team).
+    bool arrived = !CHAIN;
+    if (CHAIN && !HAS_A && wave == 7)
+        arrived = __hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need;
     issue_w();
     if (CHAIN) {
-        if (tid == 0) {
-            // one lane polls (relaxed, L2-bypassing); bounded so that a lost partner cannot hang the GPU: after ~2 s the
-            // workgroup goes on with whatever is there and the result fails the parity tests instead
+        if (!HAS_A && wave == 7 && !arrived) {
+            // relaxed, L2-bypassing; bounded so that a lost partner cannot hang the GPU: after ~2 s the workgroup goes on
+            // with whatever is there and the result fails the parity tests instead
             for (unsigned spin = 0; spin < (1u << 21); ++spin) {
                 if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
                 __builtin_amdgcn_s_sleep(2);

@@ -7,7 +7,8 @@ from bench import build_model, make_batch, model_flags
 from openmpl_amd import cabi
 V, L, B, prec = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 kind = sys.argv[5] if len(sys.argv) > 5 else "chosen"
-m = build_model(model_flags(kind, V, L), torch.device("cuda"))
+more = dict(FPT_blocks_view_keypoint_tokens=True) if kind == "kptok" else {}
+m = build_model(model_flags("chosen" if kind == "kptok" else kind, V, L, **more), torch.device("cuda"))
 m.set_matmul_precision(prec)
 P, R, C = make_batch(B, V, "cuda", 1)
 with torch.no_grad():
