@@ -38,6 +38,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // exact-erf GELU == torch.nn.GELU() default (multiview_mpl.py:22 act_layer=nn.GELU)
+// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
+// M0 is saved/restored inside the statement (the compiler does not preserve it around asm).
+__device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_dst)
+        : "memory");
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU with erf from Abramowitz & Stegun 7.1.26 (|error| of erf <= 1.5e-7 in exact arithmetic, 6e-7 in fp32; the GELU
 // value is as close to the fp64 one as with an fp32 libm erf: 4.7e-7 vs 4.4e-7 max abs over [-6, 6]) on the hardware

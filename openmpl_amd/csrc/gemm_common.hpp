@@ -141,21 +141,6 @@ template <int NG> struct SubStage {
     static constexpr int PIECES = 8 + 17 * NG + 1;      // incl. the gamma/beta piece
 };
 
-// One 1-KiB DMA piece: lane l's 16 bytes at g land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
-// M0 is saved/restored inside the statement (the compiler does not preserve it around asm).
-__device__ __forceinline__ void dma16(const float* g, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_dst)
-        : "memory");
-}
-
 // Fast form for the A / W pieces: address = 64-bit SGPR base (advanced by the k offset once per stage) + 32-bit
 // per-lane VGPR offset that never changes, so a piece costs three instructions.  M0 is saved / restored once
 // per group by the caller (dma_m0_save / dma_m0_restore).

@@ -503,8 +503,22 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
 constexpr int ATS = 36;                       // ATT row stride (floats)
 constexpr int HS = 68;                        // HID row stride (floats)
 constexpr int KV_F = SJ * SH * SEQ * 4;       // 8704 floats each
-constexpr int SPT3_LDS_BYTES = (ROWS * XS + 2 * KV_F + ROWS * ATS) * 4;   // 147968
-static_assert(ROWS * HS <= 2 * KV_F + ROWS * ATS, "HID does not fit its alias");
+constexpr int SPT3_RING_BYTES = (ROWS * XS + 2 * KV_F + ROWS * ATS) * 4;   // 147968: X | K | V | ATT
+constexpr int SPT3_LDS_BYTES = 160 * 1024;          // + 15872 B: staged weights of the next phase | parameter vectors
+// Weights and parameter vectors of a phase are staged in LDS while the phase BEFORE it runs (LDS-DMA for the packed
+// weights, one float4 per thread for the 352 bias / LayerNorm values of a block): a phase that starts with ~16 global
+// loads per lane waits ~1.5 k cycles for L2 before its first MFMA, five times per block application (14 % of the kernel).
+//   S_W   spare + 0      12 KiB  proj weights (staged during qkv + attention), then fc2 weights (staged during fc1)
+//   S_PAR spare + 12 KiB 2 x 352 floats, double buffered by block application (staged during fc2 of the one before)
+//   F1    K + 0          12 KiB  fc1 weights (staged during proj: K is dead after the attention); HID starts behind it
+//   Q     ATT + 20 KiB   18 KiB  qkv weights of the NEXT application (staged during fc2; HID ends at ATT + 16.3 KiB)
+constexpr int SPT3_HID_OFF = 3072;                  // floats: HID = K + 12 KiB
+constexpr int SPT3_Q_OFF = 20480;                   // bytes into ATT
+constexpr int SPT3_NPAR = 352;                      // floats of parameter vectors per block
+static_assert(SPT3_HID_OFF + ROWS * HS <= 2 * KV_F + ROWS * ATS, "HID does not fit its alias");
+static_assert((SPT3_HID_OFF + ROWS * HS - 2 * KV_F) * 4 <= SPT3_Q_OFF, "HID reaches into the staged qkv weights");
+static_assert(SPT3_Q_OFF + 18 * 1024 <= ROWS * ATS * 4, "staged qkv weights do not fit behind HID in ATT");
+static_assert(SPT3_RING_BYTES + 12 * 1024 + 2 * SPT3_NPAR * 4 <= SPT3_LDS_BYTES, "spare LDS too small");
 constexpr int SPT_PACK_QKV = 0, SPT_PACK_PROJ = 18 * 1024, SPT_PACK_FC1 = 24 * 1024, SPT_PACK_FC2 = 36 * 1024;
 constexpr int SPT_PACK_BYTES = 48 * 1024;
 
@@ -575,11 +589,21 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     float* Kb = smem + ROWS * XS;
     float* Vb = Kb + KV_F;
     float* ATT = Vb + KV_F;
-    float* HID = Kb;                               // alias (K, V, ATT are dead between proj and the next qkv)
+    float* HID = Kb + SPT3_HID_OFF;                // alias (K, V, ATT are dead between proj and the next qkv)
+    char* S_W = reinterpret_cast<char*>(ATT + ROWS * ATS);
+    float* S_PAR = reinterpret_cast<float*>(S_W + 12 * 1024);
+    char* R_F1 = reinterpret_cast<char*>(Kb);
+    char* R_Q = reinterpret_cast<char*>(ATT) + SPT3_Q_OFF;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;      // li = sequence (row in tile), kq = k quarter / column quad
+    // every barrier of this kernel also publishes staged DMA pieces: the compiler does not see the LDS-DMA requests (inline
+    // asm), so the wait for them is explicit
+    auto phase_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
     const int hg = wave & 1, part = wave >> 1;     // head group, joint class
     const int view = blockIdx.x % p.V;
     const int b0 = (blockIdx.x / p.V) * SEQ;
@@ -588,12 +612,45 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     const float* ray = p.rays[view];
     const float* cen = p.centers[view];
 
+    // stage n_pieces KiB of a packed block (section at byte_off) into LDS at dst: wave w brings pieces w, w + 8, ...;
+    // the __syncthreads() that ends the current phase (it waits for vmcnt(0)) publishes them
+    auto stage_w = [&](char* dst, const unsigned short* pack, int byte_off, int n_pieces) {
+        const unsigned l0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+        for (int i = wave; i < n_pieces; i += NWAVE)
+            ::mpl::dma16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(pack) + byte_off + i * 1024) + lane * 4,
+                         l0 + (unsigned)(i * 1024));
+    };
+    // the 352 parameter values of a block, one float4 per thread (tid < 88):
+    // qkv_b 96 | ln1_w 32 | ln1_b 32 | proj_b 32 | fc1_b 64 | ln2_w 32 | ln2_b 32 | fc2_b 32
+    auto load_par = [&](const mpl_block_weights& b) -> float4 {
+        if (tid >= SPT3_NPAR / 4) return float4{0.f, 0.f, 0.f, 0.f};
+        const int i = tid;
+        gfp src = i < 24 ? G(b.qkv_b) + 4 * i
+                         : i < 32 ? G(b.ln1_w) + 4 * (i - 24)
+                         : i < 40 ? G(b.ln1_b) + 4 * (i - 32)
+                         : i < 48 ? G(b.proj_b) + 4 * (i - 40)
+                         : i < 64 ? G(b.fc1_b) + 4 * (i - 48)
+                         : i < 72 ? G(b.ln2_w) + 4 * (i - 64)
+                         : i < 80 ? G(b.ln2_b) + 4 * (i - 72)
+                                  : G(b.fc2_b) + 4 * (i - 80);
+        return ld4(src);
+    };
+    auto store_par = [&](int app_of, const float4& v) {
+        if (tid < SPT3_NPAR / 4) st4(S_PAR + (app_of & 1) * SPT3_NPAR + 4 * tid, v);
+    };
+    mpl_block_weights bw;
+    if (p.n_apps > 0) {                            // application 0: its qkv weights and parameters, under the embedding
+        bw = set.blocks[p.sched[0] & 0x7f];
+        stage_w(R_Q, bw.qkv_w3, SPT_PACK_QKV, 18);
+    }
+    const float4 par0 = p.n_apps > 0 ? load_par(bw) : float4{0.f, 0.f, 0.f, 0.f};
     spt_embed<true>(p, set, X, tid, b0, pose, ray, cen);
-    __syncthreads();
+    store_par(0, par0);
+    phase_sync();
 
     const int nj = part == 0 ? 5 : 4;              // joints part, part + 4, ... of this wave
-    auto load_w = [&](const unsigned short* pack, int byte_off, int unit, sbf16x8 (&w)[3]) {
-        gwp g = (gwp)(reinterpret_cast<const char*>(pack) + byte_off) + (size_t)unit * 3 * 64 + lane;
+    auto load_w = [&](const char* region, int unit, sbf16x8 (&w)[3]) {      // from the staged section in LDS
+        const sbf16x8* g = reinterpret_cast<const sbf16x8*>(region) + (size_t)unit * 3 * 64 + lane;
         w[0] = g[0];
         w[1] = g[64];
         w[2] = g[128];
@@ -624,22 +681,23 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         spt_split3(y, ah, am, al);
     };
 
-    mpl_block_weights bw;
     for (int app = 0; app < p.n_apps; ++app) {
         const bool weighted = (p.sched[app] & 0x80) != 0;
         bw = set.blocks[p.sched[app] & 0x7f];
         const unsigned short* pack = bw.qkv_w3;
+        const float* par = S_PAR + (app & 1) * SPT3_NPAR;
+        stage_w(S_W, pack, SPT_PACK_PROJ, 6);      // proj weights: land during qkv + attention
         // ---------------- qkv: this wave's q, k, v tiles (head group hg) of its joints
         {
             sbf16x8 wq[3][3];
             float4 bq[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                load_w(pack, SPT_PACK_QKV, 2 * c + hg, wq[c]);
-                bq[c] = ld4(G(bw.qkv_b) + 32 * c + 16 * hg + 4 * kq);
+                load_w(R_Q, 2 * c + hg, wq[c]);
+                bq[c] = ::mpl::ld4(par + 32 * c + 16 * hg + 4 * kq);
             }
-            const float4 g0 = ld4(G(bw.ln1_w) + 8 * kq), g1 = ld4(G(bw.ln1_w) + 8 * kq + 4);
-            const float4 e0 = ld4(G(bw.ln1_b) + 8 * kq), e1 = ld4(G(bw.ln1_b) + 8 * kq + 4);
+            const float4 g0 = ::mpl::ld4(par + 96 + 8 * kq), g1 = ::mpl::ld4(par + 96 + 8 * kq + 4);
+            const float4 e0 = ::mpl::ld4(par + 128 + 8 * kq), e1 = ::mpl::ld4(par + 128 + 8 * kq + 4);
             float4 q[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
@@ -656,7 +714,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{cv[0] + bq[2].x, cv[1] + bq[2].y, cv[2] + bq[2].z, cv[3] + bq[2].w});
                 }
             }
-            __syncthreads();
+            phase_sync();
             // ---------------- attention (:55-64): lane = (sequence li, head h), its <= 5 query joints against all 17 keys
             {
                 const int h = 4 * hg + kq;
@@ -706,15 +764,16 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     if (t < nj) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
             }
         }
-        __syncthreads();
+        phase_sync();
         // ---------------- X += attn_out . Wproj^T + b : 17 x 2 tiles, dealt as contiguous ranges of the (m, n) list
         {
+            stage_w(R_F1, pack, SPT_PACK_FC1, 12);      // fc1 weights into the dead K tile
             sbf16x8 wp[2][3];
             float4 bp[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                load_w(pack, SPT_PACK_PROJ, n, wp[n]);
-                bp[n] = ld4(G(bw.proj_b) + 16 * n + 4 * kq);
+                load_w(S_W, n, wp[n]);
+                bp[n] = ::mpl::ld4(par + 160 + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
@@ -731,18 +790,19 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 }
             }
         }
-        __syncthreads();
+        phase_sync();
         // ---------------- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles
         {
+            stage_w(S_W, pack, SPT_PACK_FC2, 12);       // fc2 weights (the proj weights in S_W were read a phase ago)
             sbf16x8 w1[4][3];
             float4 b1[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                load_w(pack, SPT_PACK_FC1, n, w1[n]);
-                b1[n] = ld4(G(bw.fc1_b) + 16 * n + 4 * kq);
+                load_w(R_F1, n, w1[n]);
+                b1[n] = ::mpl::ld4(par + 192 + 16 * n + 4 * kq);
             }
-            const float4 g0 = ld4(G(bw.ln2_w) + 8 * kq), g1 = ld4(G(bw.ln2_w) + 8 * kq + 4);
-            const float4 e0 = ld4(G(bw.ln2_b) + 8 * kq), e1 = ld4(G(bw.ln2_b) + 8 * kq + 4);
+            const float4 g0 = ::mpl::ld4(par + 256 + 8 * kq), g1 = ::mpl::ld4(par + 256 + 8 * kq + 4);
+            const float4 e0 = ::mpl::ld4(par + 288 + 8 * kq), e1 = ::mpl::ld4(par + 288 + 8 * kq + 4);
             const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
             for (int m = lo >> 2; m <= ((hi - 1) >> 2); ++m) {
                 sbf16x8 ah, am, al;
@@ -757,16 +817,23 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 }
             }
         }
-        __syncthreads();
+        phase_sync();
         // ---------------- X += Hid . W2^T + b : K = 64 (two k steps), 17 x 2 tiles
         {
+            // the next application's qkv weights (behind HID in ATT) and parameters travel under this phase
+            float4 parn = float4{0.f, 0.f, 0.f, 0.f};
+            if (app + 1 < p.n_apps) {
+                const mpl_block_weights bn = set.blocks[p.sched[app + 1] & 0x7f];
+                stage_w(R_Q, bn.qkv_w3, SPT_PACK_QKV, 18);
+                parn = load_par(bn);
+            }
             sbf16x8 w2[2][2][3];
             float4 b2[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                load_w(pack, SPT_PACK_FC2, 2 * n, w2[n][0]);
-                load_w(pack, SPT_PACK_FC2, 2 * n + 1, w2[n][1]);
-                b2[n] = ld4(G(bw.fc2_b) + 16 * n + 4 * kq);
+                load_w(S_W, 2 * n, w2[n][0]);
+                load_w(S_W, 2 * n + 1, w2[n][1]);
+                b2[n] = ::mpl::ld4(par + 320 + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
@@ -784,8 +851,9 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     st4(xd, float4{x.x + (c[0] + b2[n].x), x.y + (c[1] + b2[n].y), x.z + (c[2] + b2[n].z), x.w + (c[3] + b2[n].w)});
                 }
             }
+            if (app + 1 < p.n_apps) store_par(app + 1, parn);
         }
-        __syncthreads();
+        phase_sync();
     }
     spt_epilogue<true>(p, X, tid, view, b0, pose, ray, cen);
 }
