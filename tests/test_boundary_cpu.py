@@ -179,3 +179,12 @@ def test_shipped_yaml_configs_build_the_reference_module_layout():
         seen.add((ours.features.num_views, ours.features.depth, ours.features.input_rays_as_token))
     # h36m.yaml: CHOSEN depth 12, 2 views; hm_0_...: FULL depth 12, 4 views; cmu.yaml: CHOSEN depth 2; cmu_0_...: FULL depth 2
     assert seen == {(2, 12, False), (4, 12, True), (2, 2, False), (2, 2, True)}, seen
+
+
+def test_tools_and_bench_compile():
+    """The measurement scripts under tools/ and bench.py are part of the evidence chain: they must at least parse."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
