@@ -383,71 +383,43 @@ __device__ __forceinline__ void zero_pad_tiles(bool wt, char* strip, int Kout, i
     }
 }
 
-// NT, HD4 > 0: tokens per sequence and head width / 4 known at compile time (the headline shape, 4 views and 68-wide
-// heads: every loop unrolls, a thread's 34 LDS reads of the score are in flight together and the softmax of a score row
-// -- it sits in four adjacent lanes -- is two cross-lane exchanges; the generic form spent 18 k cycles per qkv phase in
-// LDS latency chains).  NT = HD4 = 0: run-time sizes.
-template <int NP, int NT, int HD4>
-__device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt_rt, int hd_rt, int S, char* C3, int tile_m,
+// Generic form (any n_tok <= 32, any head width that divides 136): run-time sizes.  The headline shape (4 tokens, 68-wide
+// heads) never comes here: x3_phase finishes its attention in registers.
+template <int NP>
+__device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C3, int tile_m,
                                              int g_out, int Dq) {
-    const int nt = NT ? NT : nt_rt, hd = HD4 ? 4 * HD4 : hd_rt;
     const int hd4 = hd >> 2;
     const int HP = BN / hd, nn = nt * nt;
     const float scale = 1.0f / sqrtf((float)hd);
-    if constexpr (NT == 4) {
-        for (int t = tid; t < S * HP * 16; t += 512) {
-            const int j = t & 3, i = (t >> 2) & 3, hh = (t >> 4) % HP, sq = t / (16 * HP);
-            const float* q = T + (sq * 4 + i) * X3_ATT_TS + hh * hd;
-            const float* k = T + (sq * 4 + j) * X3_ATT_TS + BN + hh * hd;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int e = 0; e < hd4; ++e) {
-                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
-                s0 = fmaf(a.x, b.x, s0);
-                s1 = fmaf(a.y, b.y, s1);
-                s2 = fmaf(a.z, b.z, s2);
-                s3 = fmaf(a.w, b.w, s3);
-            }
-            const float sc = ((s0 + s1) + (s2 + s3)) * scale;
-            float mx = fmaxf(sc, __shfl_xor(sc, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            const float e = __expf(sc - mx);
-            float l = e + __shfl_xor(e, 1, 64);
-            l += __shfl_xor(l, 2, 64);
-            SC[t] = e * (1.0f / l);
+    for (int t = tid; t < S * HP * nn; t += 512) {
+        const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
+        const float* q = T + (sq * nt + i) * X3_ATT_TS + hh * hd;
+        const float* k = T + (sq * nt + j) * X3_ATT_TS + BN + hh * hd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int e = 0; e < hd4; ++e) {
+            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+            s0 = fmaf(a.x, b.x, s0);
+            s1 = fmaf(a.y, b.y, s1);
+            s2 = fmaf(a.z, b.z, s2);
+            s3 = fmaf(a.w, b.w, s3);
         }
-        __syncthreads();
-    } else {
-        for (int t = tid; t < S * HP * nn; t += 512) {
-            const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
-            const float* q = T + (sq * nt + i) * X3_ATT_TS + hh * hd;
-            const float* k = T + (sq * nt + j) * X3_ATT_TS + BN + hh * hd;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (int e = 0; e < hd4; ++e) {
-                const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
-                s0 = fmaf(a.x, b.x, s0);
-                s1 = fmaf(a.y, b.y, s1);
-                s2 = fmaf(a.z, b.z, s2);
-                s3 = fmaf(a.w, b.w, s3);
-            }
-            SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
-        }
-        __syncthreads();
-        for (int t = tid; t < S * HP * nt; t += 512) {
-            float* pr = SC + t * nt;
-            float mx = pr[0];
-            for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
-            float l = 0.f;
-            for (int j = 0; j < nt; ++j) {
-                const float e = __expf(pr[j] - mx);
-                pr[j] = e;
-                l += e;
-            }
-            const float inv = 1.0f / l;
-            for (int j = 0; j < nt; ++j) pr[j] *= inv;
-        }
-        __syncthreads();
+        SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
     }
+    __syncthreads();
+    for (int t = tid; t < S * HP * nt; t += 512) {
+        float* pr = SC + t * nt;
+        float mx = pr[0];
+        for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
+        float l = 0.f;
+        for (int j = 0; j < nt; ++j) {
+            const float e = __expf(pr[j] - mx);
+            pr[j] = e;
+            l += e;
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < nt; ++j) pr[j] *= inv;
+    }
+    __syncthreads();
     // P.V and the A3 fragments of the output rows: task = (row, quarter p, lane quarter kq) -> 8 values = the two
     // 4-column chunks 32p + 4kq and 32p + 16 + 4kq; tail tasks (row, kq < 2) -> 4 values at 128 + 4kq
     const int Go = Dq / BN;
@@ -460,26 +432,13 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
             const int hh = c / hd;
             const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
             const float* v = T + (sq * nt) * X3_ATT_TS + 2 * BN + c;
-            if constexpr (NT == 4) {
-                const float4 p4 = ld4(pr);
-                const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 vv = ld4(v + j * X3_ATT_TS);
-                    o.x = fmaf(pj[j], vv.x, o.x);
-                    o.y = fmaf(pj[j], vv.y, o.y);
-                    o.z = fmaf(pj[j], vv.z, o.z);
-                    o.w = fmaf(pj[j], vv.w, o.w);
-                }
-            } else {
-                for (int j = 0; j < nt; ++j) {
-                    const float4 vv = ld4(v + j * X3_ATT_TS);
-                    const float pj = pr[j];
-                    o.x = fmaf(pj, vv.x, o.x);
-                    o.y = fmaf(pj, vv.y, o.y);
-                    o.z = fmaf(pj, vv.z, o.z);
-                    o.w = fmaf(pj, vv.w, o.w);
-                }
+            for (int j = 0; j < nt; ++j) {
+                const float4 vv = ld4(v + j * X3_ATT_TS);
+                const float pj = pr[j];
+                o.x = fmaf(pj, vv.x, o.x);
+                o.y = fmaf(pj, vv.y, o.y);
+                o.z = fmaf(pj, vv.z, o.z);
+                o.w = fmaf(pj, vv.w, o.w);
             }
         }
         return o;
@@ -1001,6 +960,104 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     unsigned long long t_st = 0;
 
     if constexpr (EPI == X3_EPI_ATT) {
+      if (a.att_ntok == 4 && a.att_hd == 68 && a.rpt == BM) {
+        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68-wide heads, in REGISTERS.  A sequence is 4
+        // consecutive rows = the 4 lanes of a quad (lane (li, kq), li = 4 s + i), and a lane holds 4 consecutive channels of
+        // its row per column tile: k_j / v_j of the sequence come from the quad by DPP (quad_perm broadcast), the q.k sum
+        // of a head (17 channel quads: tiles 0..3 + the first quad of tile 4 | the rest) is reduced over the tiles of the
+        // wave, the 4 kq lanes and the two waves of the row group (one 2-KiB exchange through LDS).  No q|k|v tile in LDS
+        // (round 2a wrote 104 KB per workgroup and read it back: 5 k + 7 k cycles of the qkv phase), and the output is
+        // emitted from registers exactly like the other epilogues.
+        float qv[NTW][4], kv[NTW][4], vv[NTW][4];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            value4(0, n, qv[n]);
+            value4(1, n, kv[n]);
+            value4(2, n, vv[n]);
+        }
+        auto quad = [](float x, int j) -> float {      // value of lane (quad base + j)
+            const int xi = __builtin_bit_cast(int, x);
+            int r;
+            switch (j) {
+                case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
+                case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
+                case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
+                default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
+            }
+            return __builtin_bit_cast(float, r);
+        };
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};       // partial q_i . k_j of head 0 / head 1
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const bool h1 = 4 * tile_of(n) + kq >= 17;       // channel quad 4 tile + kq: 0..16 head 0, 17..33 head 1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d = qv[n][0] * quad(kv[n][0], j);
+                d = fmaf(qv[n][1], quad(kv[n][1], j), d);
+                d = fmaf(qv[n][2], quad(kv[n][2], j), d);
+                d = fmaf(qv[n][3], quad(kv[n][3], j), d);
+                s0[j] += h1 ? 0.f : d;
+                s1[j] += h1 ? d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        float* xs = reinterpret_cast<float*>(smem);        // [2 halves][64 rows][8]
+        const int half = slot0 ? 1 : 0;
+        __syncthreads();                                    // every wave is done reading the last stage
+        if (kq == 0) {
+            st4(xs + (half * BM + row_l) * 8, float4{s0[0], s0[1], s0[2], s0[3]});
+            st4(xs + (half * BM + row_l) * 8 + 4, float4{s1[0], s1[1], s1[2], s1[3]});
+        }
+        __syncthreads();
+        float p0[4], p1[4];
+        {
+            const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
+            const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
+            const float scale = 1.0f / sqrtf(68.0f);
+            const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
+            const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
+            auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
+                const float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+                const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
+                const float inv = 1.0f / ((e0 + e1) + (e2 + e3));
+                pr[0] = e0 * inv; pr[1] = e1 * inv; pr[2] = e2 * inv; pr[3] = e3 * inv;
+            };
+            softmax4(t0, p0);
+            softmax4(t1, p1);
+        }
+        float ov[NTW][4];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const bool h1 = 4 * tile_of(n) + kq >= 17;
+            const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float o = pj[0] * quad(vv[n][c], 0);
+                o = fmaf(pj[1], quad(vv[n][c], 1), o);
+                o = fmaf(pj[2], quad(vv[n][c], 2), o);
+                o = fmaf(pj[3], quad(vv[n][c], 3), o);
+                ov[n][c] = o;
+            }
+        }
+        // the attention output as A3 of width Dq for proj: two adjacent tiles = one fragment of the consumer
+        const int Go = Dq / BN, g_out = n0 / BN;
+        char* cbase = a.C3 + ((size_t)tm * 4 + rg) * x3_stages(Dq, NP) * X3_RG;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x[8] = {ov[2 * q][0], ov[2 * q][1], ov[2 * q][2], ov[2 * q][3],
+                                ov[2 * q + 1][0], ov[2 * q + 1][1], ov[2 * q + 1][2], ov[2 * q + 1][3]};
+            emit_frag<NP>(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
+        }
+        if (NTW == X3_T0 && kq < 2) {     // the half tile: 4 values per lane into the shared tail k-tile
+            const float x[8] = {ov[NTW - 1][0], ov[NTW - 1][1], ov[NTW - 1][2], ov[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
+            emit_tail<NP>(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
+        }
+        if (NP == 1 && g_out == 0 && HAS_A) zero_pad_tiles<NP>(WT, cbase, Dq, lane);
+      } else {
         float* Tt = reinterpret_cast<float*>(smem);
         float* SC = Tt + BM * X3_ATT_TS;
         __syncthreads();                        // every wave is done reading the last stage
@@ -1016,8 +1073,8 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        if (a.att_ntok == 4 && a.att_hd == 68) x3_attention<NP, 4, 17>(WT, Tt, SC, tid, 4, 68, a.rpt / 4, a.C3, tm, n0 / BN, Dq);
-        else x3_attention<NP, 0, 0>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+        x3_attention<NP>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C3, tm, n0 / BN, Dq);
+      }
     } else {
         const int Go = N / BN;
         char* cbase = a.C3 + ((size_t)tm * 4 + rg) * x3_stages(N, NP) * X3_RG;   // this wave's row group of the output operand
