@@ -960,8 +960,8 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     unsigned long long t_st = 0;
 
     if constexpr (EPI == X3_EPI_ATT) {
-      if (a.att_ntok == 4 && a.att_hd == 68 && a.rpt == BM) {
-        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68-wide heads, in REGISTERS.  A sequence is 4
+      if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
+        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS.  A sequence is 4
         // consecutive rows = the 4 lanes of a quad (lane (li, kq), li = 4 s + i), and a lane holds 4 consecutive channels of
         // its row per column tile: k_j / v_j of the sequence come from the quad by DPP (quad_perm broadcast), the q.k sum
         // of a head (17 channel quads: tiles 0..3 + the first quad of tile 4 | the rest) is reduced over the tiles of the
@@ -986,10 +986,11 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             }
             return __builtin_bit_cast(float, r);
         };
+        const bool two_heads = a.att_hd == 68;          // 136 channels = two 68-wide heads, or one 136-wide head
         float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};       // partial q_i . k_j of head 0 / head 1
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            const bool h1 = 4 * tile_of(n) + kq >= 17;       // channel quad 4 tile + kq: 0..16 head 0, 17..33 head 1
+            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;       // channel quad 4 tile + kq: 0..16 head 0, 17..33 head 1
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float d = qv[n][0] * quad(kv[n][0], j);
@@ -1017,7 +1018,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         {
             const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
             const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
-            const float scale = 1.0f / sqrtf(68.0f);
+            const float scale = 1.0f / sqrtf((float)a.att_hd);
             const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
             const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
             auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
@@ -1032,7 +1033,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         float ov[NTW][4];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            const bool h1 = 4 * tile_of(n) + kq >= 17;
+            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
             const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
