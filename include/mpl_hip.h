@@ -9,7 +9,7 @@
  * reference's own parameter layouts (nn.Linear weight = [out][in] row-major, i.e. the
  * tensors of the reference state_dict are consumed as they are).  The one exception is
  * optional DERIVED data: the bf16 / split-operand copies of the FPT Linear weights that
- * mpl_convert_bf16 / mpl_split_bf16x3 build from those tensors; whoever hands them over
+ * mpl_pack_bf16 / mpl_split_bf16x3 build from those tensors; whoever hands them over
  * must rebuild them when the source parameters change (the Python binding keys them on
  * the parameters' storage addresses and versions).
  * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); every call only
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 6
+#define MPL_HIP_ABI_VERSION 7
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -46,6 +46,7 @@ extern "C" {
 #define MPL_E_UNSUPPORTED (-2) /* flag combination or size not implemented in HIP */
 #define MPL_E_WORKSPACE (-3)   /* workspace too small */
 #define MPL_E_LAUNCH (-4)      /* hip runtime reported an error at launch */
+#define MPL_E_DEVICE (-5)      /* a kernel of an EARLIER call on this device reported a failure (see mpl_device_error) */
 
 /* flag bits of mpl_config.flags == constructor kwargs of MultiView_MPL (multiview_mpl.py:98-117) */
 #define MPL_F_MULTI_SPT (1u << 0)       /* multiple_spatial_blocks */
@@ -260,6 +261,21 @@ int mpl_prepare_inputs(const float *joints_px, const float *conf, const double *
 int mpl_pose_metrics_size(int joints);
 int mpl_pose_metrics(const float *output, const float *target, const float *weight, int batch, int joints,
                      const float *scale3, const float *offset3, float *result, void *stream);
+
+/* ---- device-side failures.  The block stack runs as ONE persistent launch whose workgroups hand operands to each
+ * other (x3_gemm.hip); it needs all its workgroups resident, i.e. the device to itself for the duration of the launch
+ * (single tenant: launches of this library on different streams of one process are serialised by the library, other
+ * processes on the same GPU are not).  A workgroup whose wait for a partner runs out (~10 s) never goes on with stale
+ * operands: it sets a sticky per-device error word, the poses of that call are NaN, and EVERY later call on the device
+ * returns MPL_E_DEVICE until mpl_device_error_clear() -- the reference's convention for a failed forward is a Python
+ * exception (SURVEY.md 8b "Error convention"), which is what the binding turns this into.
+ * mpl_device_error(dev): 1 when the word is set (dev < 0: the current device); no synchronisation, reads pinned memory.
+ * mpl_x3_spin_limit(v): test hook.  v & 0xff = log2 of the polls before a wait counts as lost (default 23 ~ 10 s);
+ * v >> 8 = fault injection: when > 0, one workgroup of the next launches deserts its team before that GEMM phase, so
+ * that the failure path can be exercised deterministically (tests/test_failures_gpu.py). */
+int mpl_device_error(int device);
+int mpl_device_error_clear(int device);
+int mpl_x3_spin_limit(int log2_polls);
 
 /* Measurement aid (bench.py roofline leg): between start and stop every kernel launched by this
  * library on ANY stream is bracketed by a hipEvent pair recorded on that same stream.  stop()

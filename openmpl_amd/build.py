@@ -21,11 +21,15 @@ HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_common.hpp
 ARCH = "gfx950"
 
 
+class CompilerMissing(RuntimeError):
+    """No hipcc on this machine (the only build failure cabi.load() may tolerate, and only with an existing library)."""
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
             return c
-    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmpl_hip.so)")
+    raise CompilerMissing("hipcc not found (ROCm toolchain required to build libmpl_hip.so)")
 
 
 STAMP_PATH = LIB_PATH + ".srchash"
@@ -76,36 +80,43 @@ def _build_locked(verbose: bool) -> str:
     objs = []
     procs = []
     tag = ".%d" % os.getpid()
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", tag + ".o"))
-        cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MPL_HIPCC_FLAGS", "").split() + \
-              ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    failed = None
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0 and failed is None:
-            failed = "hipcc failed on %s:\n%s" % (src, out.decode(errors="replace"))
-    if failed:
-        raise RuntimeError(failed)
     tmp_so = LIB_PATH + tag
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp_so] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    for o in objs:
-        try:
-            os.remove(o)
-        except OSError:
-            pass
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
-    os.replace(tmp_so, LIB_PATH)
-    with open(STAMP_PATH + tag, "w") as f:
-        f.write(srchash + "\n")
-    os.replace(STAMP_PATH + tag, STAMP_PATH)
-    return LIB_PATH
+    try:
+        for src in SOURCES:
+            obj = os.path.join(LIB_DIR, src.replace(".hip", tag + ".o"))
+            cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MPL_HIPCC_FLAGS", "").split() + \
+                  ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            objs.append(obj)
+        failed = None
+        for src, p in procs:
+            out, _ = p.communicate()
+            if p.returncode != 0 and failed is None:
+                failed = "hipcc failed on %s:\n%s" % (src, out.decode(errors="replace"))
+        if failed:
+            raise RuntimeError(failed)
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp_so] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+        os.replace(tmp_so, LIB_PATH)
+        with open(STAMP_PATH + tag, "w") as f:
+            f.write(srchash + "\n")
+        os.replace(STAMP_PATH + tag, STAMP_PATH)
+        return LIB_PATH
+    finally:
+        # the PID-tagged temporaries never outlive the build, whether it succeeded, failed or was interrupted
+        for _, p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in objs + [tmp_so, STAMP_PATH + tag]:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

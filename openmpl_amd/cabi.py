@@ -14,7 +14,7 @@ from . import build as _build
 
 MPL_MAX_VIEWS = 32
 MPL_MAX_APPS = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # flag bits (mpl_hip.h MPL_F_*)
 F_MULTI_SPT = 1 << 0
@@ -73,7 +73,7 @@ class Inputs(C.Structure):
 
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
-           "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_ln_linear_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_ln_linear_x3_workspace_bytes", "mpl_ln_linear_x3", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
+           "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_ln_linear_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_ln_linear_x3_workspace_bytes", "mpl_ln_linear_x3", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_device_error", "mpl_device_error_clear", "mpl_x3_spin_limit", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
            "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
@@ -100,7 +100,9 @@ def load():
         if _build.needs_build():
             try:
                 _build.build()
-            except RuntimeError:
+            except _build.CompilerMissing:
+                # ONLY the missing-compiler case is tolerated (a box without hipcc that was handed a prebuilt library);
+                # a compile or link failure of edited sources propagates -- never run stale kernels silently
                 if not os.path.exists(path):
                     raise
                 import warnings
@@ -157,6 +159,9 @@ def load():
                                          _fp, C.c_size_t, _fp]
         lib.mpl_x3_stack_mode.restype = C.c_int
         lib.mpl_x3_stack_mode.argtypes = [C.c_int]
+        for fn in (lib.mpl_device_error, lib.mpl_device_error_clear, lib.mpl_x3_spin_limit):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_int]
         lib.mpl_x3_debug_buffer.restype = C.c_int
         lib.mpl_x3_debug_buffer.argtypes = [_fp]
         lib.mpl_token_attention.restype = C.c_int
@@ -203,3 +208,13 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().mpl_hip_error_string(rc).decode()
         raise RuntimeError("%s failed: %s (code %d)" % (what, msg, rc))
+
+
+def device_error(device: int = -1) -> bool:
+    """True when a kernel of an earlier call on `device` (default: the current one) reported a lost hand-off; every
+    call on that device fails with RuntimeError until clear_device_error().  Reads pinned memory, no synchronisation."""
+    return bool(load().mpl_device_error(device))
+
+
+def clear_device_error(device: int = -1):
+    check(load().mpl_device_error_clear(device), "mpl_device_error_clear")

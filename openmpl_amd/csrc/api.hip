@@ -39,9 +39,47 @@ mpl::ProfScope::~ProfScope() {
     if (slot < (int)g_prof.size()) hipEventRecord(g_prof[slot].e1, stream);
 }
 
+// ------------------------------------------------------------------ device-side failure word (common.hpp)
+namespace {
+std::mutex g_err_mu;
+unsigned* g_err_host[64];      // pinned host words, one per device, allocated on first use, never freed
+unsigned* g_err_dev[64];       // the same words as the device addresses them
+}  // namespace
+
+unsigned* mpl::device_error_word(int dev) {
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_err_mu);
+    if (!g_err_host[dev]) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
+        *reinterpret_cast<volatile unsigned*>(h) = 0u;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) d = h;
+        g_err_host[dev] = reinterpret_cast<unsigned*>(h);
+        g_err_dev[dev] = reinterpret_cast<unsigned*>(d);
+    }
+    return g_err_dev[dev];
+}
+int mpl::device_error_pending(int dev) {
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_err_host[dev] && *reinterpret_cast<volatile unsigned*>(g_err_host[dev]) != 0u;
+}
+void mpl::device_error_clear(int dev) {
+    if (dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> g(g_err_mu);
+    if (g_err_host[dev]) *reinterpret_cast<volatile unsigned*>(g_err_host[dev]) = 0u;
+}
+
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// a failure a kernel of an earlier call reported on the current device fails every later call until it is cleared
+inline int earlier_device_failure() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MPL_E_LAUNCH;
+    return device_error_pending(dev) ? MPL_E_DEVICE : MPL_OK;
+}
 
 struct StackWs {
     float *qkv, *att, *hid, *stats;
@@ -109,15 +147,17 @@ int stack_packed_parts(const mpl_block_weights* blocks, const uint8_t* schedule,
 // Block stack on split operands: per application LN1+qkv+attention | proj+residual | LN2+fc1+GELU | fc2+residual, the
 // activations handed from epilogue to k loop as A3 (x3 -> att3 -> x3 -> hid3 -> x3), x itself stays fp32 in place.
 int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
-                   int n_apps, void* ws, size_t ws_bytes, int np, hipStream_t s) {
+                   int n_apps, void* ws, size_t ws_bytes, int np, const unsigned** err_ws, hipStream_t s) {
     const int M = n_seq * n_tok, rpt = x3_rows_per_tile(n_tok);
     const X3Ws w = carve_x3_ws(ws, (size_t)M, (size_t)D, rpt);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
+    if (err_ws) *err_ws = w.counters + (M + rpt - 1) / rpt;
     const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     int rc;
     // entry of the stack, one launch: the rows as packed operand, their LayerNorm slice partials, zeroed arrival counters
     const int n_tiles = (M + rpt - 1) / rpt;
-    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, w.stats, w.counters, n_tiles, s))) return rc;
+    // (n_tiles arrival counters + the error word of this call, see launch_x3_stack)
+    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, w.stats, w.counters, n_tiles + 1, s))) return rc;
     auto op = [&](const mpl_block_weights& b, int i) -> const uint16_t* {
         return np == 3 ? (&b.qkv_w3)[i] : (&b.qkv_w16)[i];     // {qkv, proj, fc1, fc2} operands of the engine in use
     };
@@ -155,14 +195,15 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
 }
 
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
-                     const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, hipStream_t s) {
+                     const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
+    if (err_ws) *err_ws = nullptr;
     if (!x || n_seq <= 0 || n_tok <= 0 || D <= 0 || H <= 0 || n_apps < 0) return MPL_E_INVALID;
     // row counts are 32-bit in the kernels (byte offsets are 64-bit): refuse what would overflow instead of wrapping
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     if (const int np = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H))
-        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, s);
+        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, err_ws, s);
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
@@ -269,6 +310,10 @@ const char* mpl_hip_error_string(int code) {
         case MPL_E_UNSUPPORTED: return "configuration not supported by the HIP path";
         case MPL_E_WORKSPACE: return "workspace missing or too small";
         case MPL_E_LAUNCH: return "HIP runtime error at kernel launch";
+        case MPL_E_DEVICE:
+            return "an earlier forward on this device lost a hand-off between the workgroups of its persistent kernel (its "
+                   "poses are NaN): the GPU was shared with other work for longer than the wait bound; clear with "
+                   "mpl_device_error_clear()";
         default: return "unknown error";
     }
 }
@@ -301,7 +346,8 @@ int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs
 int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
                     const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, void* stream) {
     clear_stale_hip_error();
-    return block_stack_impl(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes,
+    if (int rc = earlier_device_failure()) return rc;
+    return block_stack_impl(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes, nullptr,
                             (hipStream_t)stream);
 }
 
@@ -353,6 +399,23 @@ int mpl_x3_stack_mode(int one_launch_per_gemm) {
     return MPL_OK;
 }
 
+int mpl_device_error(int device) {
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return 0;
+    return device_error_pending(device);
+}
+
+int mpl_device_error_clear(int device) {
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return MPL_E_LAUNCH;
+    device_error_clear(device);
+    return MPL_OK;
+}
+
+int mpl_x3_spin_limit(int log2_polls) {
+    if ((log2_polls & 0xff) < 1 || (log2_polls & 0xff) > 30 || log2_polls < 0) return MPL_E_INVALID;
+    x3_set_spin_log2(log2_polls);
+    return MPL_OK;
+}
+
 int mpl_x3_debug_buffer(void* device_buffer) {
     x3_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
     return MPL_OK;
@@ -399,7 +462,7 @@ int mpl_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, i
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !out) return MPL_E_INVALID;
-    return launch_fuse_head(cfg, w, x, batch, out, nullptr, (hipStream_t)stream);
+    return launch_fuse_head(cfg, w, x, batch, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mpl_view_fuse(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* y, void* stream) {
@@ -407,7 +470,7 @@ int mpl_view_fuse(const mpl_config* cfg, const mpl_weights* w, const float* x, i
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!w || !x || !y) return MPL_E_INVALID;
-    return launch_fuse_head(cfg, w, x, batch, nullptr, y, (hipStream_t)stream);
+    return launch_fuse_head(cfg, w, x, batch, nullptr, y, nullptr, (hipStream_t)stream);
 }
 
 int mpl_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* xn, void* stream) {
@@ -454,6 +517,7 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
     clear_stale_hip_error();
     int rc = check_cfg(cfg);
     if (rc) return rc;
+    if ((rc = earlier_device_failure())) return rc;
     if (!w || !in || !out || in->batch <= 0) return MPL_E_INVALID;
     if ((long long)in->batch * cfg->num_views * cfg->num_joints > (1ll << 30)) return MPL_E_UNSUPPORTED;
     const size_t need = mpl_forward_workspace_bytes(cfg, in->batch);
@@ -466,6 +530,7 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
 
     if ((rc = launch_spt(cfg, w, in, xs, w->spt_packed != 0, s))) return rc;
 
+    const unsigned* err_ws = nullptr;     // set by the block stack when it runs as the persistent launch
     if (!(cfg->flags & MPL_F_NO_FPT) && cfg->depth > 0) {
         // forward_features :420-423: the last block is applied twice
         uint8_t sched[MPL_MAX_APPS];
@@ -477,10 +542,10 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
         }
         const bool kp = (cfg->flags & MPL_F_KPTOK) != 0;
         if ((rc = block_stack_impl(xs, B, kp ? V * cfg->num_joints : V, kp ? cfg->dim : D, cfg->heads, w->fpt_blocks,
-                                   sched, n, rest, rest_bytes, s)))
+                                   sched, n, rest, rest_bytes, &err_ws, s)))
             return rc;
     }
-    return launch_fuse_head(cfg, w, xs, B, out, nullptr, s);
+    return launch_fuse_head(cfg, w, xs, B, out, nullptr, err_ws, s);
 }
 
 }  // extern "C"

@@ -116,9 +116,18 @@ int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned s
 int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
                    int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi, int np,
                    hipStream_t s);
+// counters: one arrival counter per row tile, then ONE error word (index n_tiles) that the kernel sets when a hand-off
+// was lost; all n_tiles + 1 words zero before the launch (counters_zeroed: the entry kernel of the stack did it)
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
                     int stop_after, int np, bool counters_zeroed, hipStream_t s);
+// ---- device-side failures (a persistent kernel whose wait for a partner workgroup ran out) -------------------------
+// One sticky word per device in pinned, device-visible host memory: kernels set it (system scope), the host reads it
+// without any synchronisation at the start of the next API call and fails that call (MPL_E_DEVICE) until it is cleared.
+unsigned* device_error_word(int dev);      // device-usable address; nullptr if the allocation failed
+int device_error_pending(int dev);         // 1 when a kernel reported a failure since the last clear
+void device_error_clear(int dev);
+void x3_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
                             int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
@@ -128,8 +137,9 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
 size_t spt_pack_bytes();
 int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s);
 // y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]
+// err_ws (optional): the error word of this call's block stack (see device_error_word); set -> the output is NaN
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,
-                     hipStream_t s);
+                     const unsigned* err_ws, hipStream_t s);
 int launch_layernorm_rows(const float* x, int M, int K, int ldx, const float* g, const float* b, float eps, float* y,
                           int ldy, hipStream_t s);
 int launch_view_norm(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* xn, hipStream_t s);

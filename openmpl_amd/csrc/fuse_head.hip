@@ -27,11 +27,16 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
                                                          const float* __restrict__ hl_w, const float* __restrict__ hl_b,
                                                          const float* __restrict__ hw, const float* __restrict__ hb,
                                                          int n_out, float* __restrict__ out,
-                                                         float* __restrict__ y_out) {
+                                                         float* __restrict__ y_out,
+                                                         const unsigned* __restrict__ err_ws) {
     extern __shared__ __attribute__((aligned(1024))) float fh_smem[];
     float* hws = fh_smem;                                    // the head weight [n_out][E], staged by LDS-DMA
     float (*y)[kMaxE] = reinterpret_cast<float (*)[kMaxE]>(fh_smem + FH_W_FLOATS);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the block stack of this call reported a lost hand-off (x3_stack_kernel): its rows are not to be trusted -- the
+    // result is NaN, never a plausible-looking pose (the host raises on the next call: MPL_E_DEVICE).  The word was
+    // written (if at all) by the previous kernel of this stream; requested now, used at the very end.
+    const unsigned poisoned = err_ws ? __hip_atomic_load(err_ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     if (!y_out) {
         // request the whole head weight (111 kB at E = 544, n_out = 51) now: it lands while the waves normalise and fuse
         // their poses; 1-KiB pieces, round-robin over the four waves (the last piece may read past the weight: the
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int f = lane + 64 * i;
-                if (f < E) y_out[(size_t)b * E + f] = acc[i];
+                if (f < E) y_out[(size_t)b * E + f] = poisoned ? __builtin_nanf("") : acc[i];
             }
         } else {
             // head LayerNorm (eps 1e-5), two-pass in registers
@@ -148,12 +153,12 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
             s1 = fmaf(yr[f], wr[f], s1);
             f = f + 1 == E ? 0 : f + 1;
         }
-        out[(size_t)(blockIdx.x * FH_POSES + p) * n_out + o] = (s0 + s1) + hb[o];
+        out[(size_t)(blockIdx.x * FH_POSES + p) * n_out + o] = poisoned ? __builtin_nanf("") : (s0 + s1) + hb[o];
     }
 }
 
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,
-                     hipStream_t s) {
+                     const unsigned* err_ws, hipStream_t s) {
     const int J = cfg->num_joints, d = cfg->dim, V = cfg->num_views;
     const int E = J * d;
     if (E > kMaxE || E > 64 * 9 || V > MPL_MAX_VIEWS || batch <= 0) return MPL_E_UNSUPPORTED;   // 9 features per lane (J*d = 544)
@@ -174,7 +179,7 @@ int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x
     ProfScope prof(MPL_K_FUSE_HEAD, s);
     hipLaunchKernelGGL(fuse_head_kernel, dim3((batch + FH_POSES - 1) / FH_POSES), dim3(256), LDS, s, x, batch, V, Df, E, d, strip, w->view_norm_w,
                        w->view_norm_b, w->wmean_w, w->wmean_b, w->head_ln_w, w->head_ln_b, w->head_w, w->head_b, 3 * J,
-                       out, y_out);
+                       out, y_out, err_ws);
     return hip_check_launch();
 }
 

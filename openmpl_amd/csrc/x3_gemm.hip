@@ -43,6 +43,7 @@
 // The k order of every output element is fixed, so results do not depend on batch size or launch geometry.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -308,15 +309,27 @@ struct X3Args {
     float eps;
     int att_ntok, att_hd;
     unsigned long long* dbg;   // bench-only (mpl_x3_debug_buffer): per-wave s_memtime stamps, else NULL
+    // chain mode only: where a workgroup reports that a partner of its team never arrived (x3_stack_kernel)
+    unsigned* err_ws;          // word in the call's workspace (read by fuse_head_kernel: the output is poisoned with NaN)
+    unsigned* err_host;        // sticky word in pinned host memory (read by the next API call on this device: it fails)
+    int spin_log2;             // polls of the arrival counter before a wait counts as lost
 };
 
 static std::atomic<unsigned long long*> g_x3_dbg{nullptr};
 void x3_set_debug_buffer(unsigned long long* p) { g_x3_dbg.store(p); }
+// polls (s_sleep 2 + one L2 round trip each, ~1 us) before a wait of x3_stack_kernel counts as lost: 2^23 ~ 10 s
+static std::atomic<int> g_x3_spin_log2{23};
+static std::atomic<int> g_x3_inject{0};
+void x3_set_spin_log2(int v) {         // bits 0..7 the bound, bits 8.. the phase of the injected desertion (0 = none)
+    g_x3_spin_log2.store(v & 0xff);
+    g_x3_inject.store(v >> 8);
+}
 
 enum { X3_EPI_BIAS = 0, X3_EPI_GELU = 1, X3_EPI_RES = 2, X3_EPI_ATT = 3 };
 
 constexpr int X3_VEC = X3_NST * X3_STAGE;   // the 4 KiB of LDS above the ring: the epilogue vectors [pass][c | s][136] of a phase
 constexpr int X3_LDS_BYTES = X3_VEC + 4096;  // = 160 KiB
+constexpr int X3_FAIL = X3_VEC + 4092;       // last word of the LDS (behind the <= 3264 B of epilogue vectors): "a wait of this workgroup was lost"
 constexpr int X3_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the attention epilogue
 
 // ---- stores / loads of data that crosses workgroups INSIDE a launch (chain mode, see x3_stack_kernel): write-through
@@ -466,8 +479,10 @@ __device__ __forceinline__ void x3_attention(bool WT, float* T, float* SC, int t
 // arrivals, the A operand of this phase may be read once it reaches `chain_need`, and this workgroup arrives when its
 // outputs are written.  The W operand does not depend on the other workgroups: its first stages are requested BEFORE
 // the wait.
+// Returns false (chain mode only, every wave of the workgroup alike) when the wait for the team timed out: nothing was
+// computed, the error words are set and the caller must leave the kernel -- a workgroup NEVER continues past a failed wait.
 template <int NP, int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
-__device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
+__device__ __forceinline__ bool x3_phase(const X3Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = X3_NST;
     constexpr bool HAS_A = NTW == X3_T0;         // waves 0..3 (slots 0..4) bring the A pieces
@@ -615,7 +630,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
         idx = on ? idx : 0;
         const int vp = idx / (2 * (BN / 4)), which = (idx / (BN / 4)) & 1, c4 = idx % (BN / 4);
         const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
-        dma16(src, lds0 + (unsigned)(X3_VEC + wave * 1024));
+        if (on) dma16(src, lds0 + (unsigned)(X3_VEC + wave * 1024));   // masked lanes write nothing: X3_FAIL stays intact
     }
     // ---- prologue: the first NST stages in stage order, W before A inside a stage.  Chain mode: W(0) does not depend on
     // the other workgroups and is requested BEFORE the wait for them; everything else after it, A(0) first -- the LDS-DMA
@@ -630,15 +645,29 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
     issue_w();
     if (CHAIN) {
         if (!HAS_A && wave == 7 && !arrived) {
-            // relaxed, L2-bypassing; bounded so that a lost partner cannot hang the GPU: after ~2 s the workgroup goes on
-            // with whatever is there and the result fails the parity tests instead
-            for (unsigned spin = 0; spin < (1u << 21); ++spin) {
+            // relaxed, L2-bypassing; bounded so that a lost partner cannot hang the GPU.  A wait that runs out is an
+            // ERROR, never a licence to go on: the workgroup raises the sticky error words and leaves the kernel (its
+            // team mates follow when their own waits run out), fuse_head_kernel poisons the poses of this call with NaN
+            // and the next API call on the device fails (MPL_E_DEVICE).
+            const unsigned lim = 1u << a.spin_log2;
+            unsigned spin = 0;
+            for (; spin < lim; ++spin) {
                 if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
                 __builtin_amdgcn_s_sleep(2);
+            }
+            if (spin == lim && lane == 0) {
+                *reinterpret_cast<volatile unsigned*>(smem + X3_FAIL) = 1u;
+                if (a.err_ws) __hip_atomic_store(a.err_ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.err_host) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
         }
         __builtin_amdgcn_s_barrier();      // control dependency only: the A requests below are issued after the poll succeeded
         asm volatile("" ::: "memory");
+        if (*reinterpret_cast<volatile unsigned*>(smem + X3_FAIL)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the W(0) pieces in flight land before the LDS is given up
+            return false;
+        }
     }
     issue_a();
 #pragma unroll
@@ -1163,6 +1192,7 @@ __device__ __forceinline__ void x3_phase(const X3Args& a, char* smem, int tid, i
             o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar;
         }
     }
+    return true;
 }
 
 template <int NP, int EPI, bool LNF, int NPASS>
@@ -1203,6 +1233,9 @@ struct X3StackArgs {
     int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
     float eps;
     unsigned long long* dbg;
+    unsigned *err_ws, *err_host;      // see X3Args
+    int spin_log2;
+    int inject;                       // test hook (mpl_x3_spin_limit): > 0 = workgroup (row tile 0, column group 0) leaves before phase `inject`
     const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
 };
 
@@ -1221,6 +1254,8 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
         tn = (b >> 3) % G;
         if (team >= s.n_teams) return;
     }
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + X3_FAIL) = 0u;
+    __syncthreads();
     auto vecs = [&](const char* w3, int N, int K) -> const float* {
         return reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(K, NP) * X3_W);
     };
@@ -1236,21 +1271,25 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
             const int wv = __builtin_amdgcn_readfirstlane(tidp >> 6);
             unsigned* ctr = s.counters + tile;
             const char* const* w = s.w[ph >> 2];
+            bool ok = true;
+            // fault injection for the failure-path test: one workgroup deserts its team, which must then REPORT the lost
+            // hand-off (error words, NaN poses, MPL_E_DEVICE) instead of computing on stale operands
+            if (s.inject > 0 && ph == s.inject && tile == 0 && tnp == 0) return;
             switch (ph & 3) {
                 case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
                     const float* v = vecs(w[0], 3 * D, D);
                     const X3Args a{s.x3, w[0], v, v + 3 * D, s.stats, nullptr, 0, nullptr, 0, s.att3, nullptr, s.M, 3 * D, D, s.rpt,
-                                   s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg};
-                    if (wv < 4) x3_phase<NP, X3_EPI_ATT, true, 3, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<NP, X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                                   s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                    if (wv < 4) ok = x3_phase<NP, X3_EPI_ATT, true, 3, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = x3_phase<NP, X3_EPI_ATT, true, 3, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const X3Args a{s.x3, w[2], v, v + 2 * D, s.stats, nullptr, 0, nullptr, 0, s.hid3, nullptr, s.M, 2 * D, D, s.rpt,
-                                   s.n_tiles, G, s.eps, 0, 0, s.dbg};
-                    if (wv < 4) x3_phase<NP, X3_EPI_GELU, true, 2, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<NP, X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                                   s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                    if (wv < 4) ok = x3_phase<NP, X3_EPI_GELU, true, 2, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = x3_phase<NP, X3_EPI_GELU, true, 2, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (ph & 3 == 1, A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -1259,12 +1298,13 @@ __global__ __launch_bounds__(512, 2) void x3_stack_kernel(const X3StackArgs s) {
                     const char* w3 = fc2 ? w[3] : w[1];
                     const float* v = vecs(w3, D, K);
                     const X3Args a{fc2 ? s.hid3 : s.att3, w3, v, v + D, nullptr, s.x, D, s.x, D, s.x3, s.stats, s.M, D, K, s.rpt, s.n_tiles,
-                                   G, s.eps, 0, 0, s.dbg};
-                    if (wv < 4) x3_phase<NP, X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else x3_phase<NP, X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
+                                   G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                    if (wv < 4) ok = x3_phase<NP, X3_EPI_RES, false, 1, X3_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = x3_phase<NP, X3_EPI_RES, false, 1, NT - X3_T0, true>(a, smem, tidp, wv, X3_T0, tile, tnp, ctr, need);
                     break;
                 }
             }
+            if (!ok) return;          // a partner of this team was lost (error words are set): never go on with stale operands
         }
     }
 }
@@ -1323,7 +1363,7 @@ int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, 
     const char* w3 = reinterpret_cast<const char*>(W3);
     const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(K, np) * X3_W);
     const X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, R, ldr, C, ldc, reinterpret_cast<char*>(C3), stats_out,
-                   M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load()};
+                   M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_x3_dbg.load(), nullptr, nullptr, 0};
     return np == 3 ? launch_x3_gemm_np<3>(a, ln, epi, s) : launch_x3_gemm_np<1>(a, ln, epi, s);
 }
 
@@ -1337,9 +1377,28 @@ static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
             return MPL_E_LAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    ProfScope prof(MPL_K_GEMM, s);
-    hipLaunchKernelGGL(x3_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
-    return hip_check_launch();
+    // Every workgroup of this kernel must be resident while it runs (teams spin on their partners), and a workgroup
+    // takes a whole CU (156 KiB of LDS): two of these launches on different streams of one device would each get part
+    // of the CUs and starve each other.  In-stream order does not cover other streams, so the library serialises ITS OWN
+    // stack launches per device: each one waits for the event recorded behind the previous one, whatever stream that was
+    // on (a no-op on the same stream).  Other processes on the same GPU are not covered: single tenant;
+    // a wait that runs out anyway is reported, never ignored (X3Args::err_*).
+    static std::mutex chain_mu[64];
+    static hipEvent_t chain_ev[64];
+    std::lock_guard<std::mutex> g(chain_mu[dev]);
+    if (!chain_ev[dev]) {
+        if (hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) return MPL_E_LAUNCH;
+    } else if (hipStreamWaitEvent(s, chain_ev[dev], 0) != hipSuccess) {
+        return MPL_E_LAUNCH;
+    }
+    int rc;
+    {
+        ProfScope prof(MPL_K_GEMM, s);
+        hipLaunchKernelGGL(x3_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
+        rc = hip_check_launch();
+    }
+    if (hipEventRecord(chain_ev[dev], s) != hipSuccess) return MPL_E_LAUNCH;
+    return rc;
 }
 
 int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
@@ -1352,9 +1411,13 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!resident[dev].load(std::memory_order_acquire)) {
-        int cus = 0;
+        int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
-        resident[dev].store(cus, std::memory_order_release);   // the 156 KiB ring admits exactly one workgroup per CU
+        // the 160 KiB of LDS admit exactly one workgroup per CU -- asked, not assumed: a device (or a runtime limit) that
+        // cannot hold even one makes the persistent form impossible
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)x3_stack_kernel<3>, 512, X3_LDS_BYTES) != hipSuccess || per_cu < 1)
+            return MPL_E_UNSUPPORTED;
+        resident[dev].store(cus, std::memory_order_release);
     }
     X3StackArgs a;
     a.x3 = reinterpret_cast<char*>(x3);
@@ -1375,6 +1438,10 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
     a.eps = eps;
     a.dbg = g_x3_dbg.load();
+    a.err_ws = counters + a.n_tiles;
+    a.err_host = device_error_word(dev);
+    a.spin_log2 = g_x3_spin_log2.load();
+    a.inject = g_x3_inject.load();
     for (int i = 0; i < n_apps; ++i)
         for (int j = 0; j < 4; ++j) {
             if (!ops[4 * i + j]) return MPL_E_INVALID;
@@ -1382,7 +1449,7 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
         }
     // per-call state: the arrival counter of every row tile (the entry kernel of the stack has already zeroed them when
     // it ran in front of this launch)
-    if (!counters_zeroed && hipMemsetAsync(counters, 0, (size_t)a.n_tiles * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
+    if (!counters_zeroed && hipMemsetAsync(counters, 0, (size_t)(a.n_tiles + 1) * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     return np == 3 ? launch_stack_np<3>(a, dev, s) : launch_stack_np<1>(a, dev, s);
 }
 
@@ -1406,7 +1473,7 @@ int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, 
     const char* w3 = reinterpret_cast<const char*>(W3);
     const float* vec = reinterpret_cast<const float*>(w3 + (size_t)(N / BN) * x3_stages(D, np) * X3_W);
     X3Args a{reinterpret_cast<const char*>(A3), w3, vec, vec + N, stats, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att3),
-             nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_x3_dbg.load()};
+             nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_x3_dbg.load(), nullptr, nullptr, 0};
     return np == 3 ? launch_x3<3, X3_EPI_ATT, true, 3>(a, s) : launch_x3<1, X3_EPI_ATT, true, 3>(a, s);
 }
 

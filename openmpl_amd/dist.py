@@ -42,8 +42,8 @@ def gather_outputs(local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
     lo, hi = shard_range(batch, world, rank)
     if local.shape[0] != hi - lo:
         raise RuntimeError("rank %d holds %d poses, its shard of %d is %d" % (rank, local.shape[0], batch, hi - lo))
-    if world == 1:
-        return local
+    # a process group of ONE rank still runs the collective (RCCL accepts a 1-rank communicator): the same code path,
+    # streams and events whatever the world size -- there is no separate single-GPU branch to go untested
     mx = -(-batch // world)
     if batch % world == 0:
         out = torch.empty((batch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -76,7 +76,7 @@ class GatherHandle:
             self._work = None
         self._keep = None
         buf, batch, world = self._buf, self._batch, self._world
-        if world == 1 or batch % world == 0:
+        if batch % world == 0:
             return buf
         mx = -(-batch // world)
         parts = []
@@ -93,9 +93,7 @@ def gather_outputs_async(local: torch.Tensor, batch: int, group=None) -> GatherH
     lo, hi = shard_range(batch, world, rank)
     if local.shape[0] != hi - lo:
         raise RuntimeError("rank %d holds %d poses, its shard of %d is %d" % (rank, local.shape[0], batch, hi - lo))
-    if world == 1:
-        return GatherHandle(None, local, batch, 1, None)
-    mx = -(-batch // world)
+    mx = -(-batch // world)             # world == 1 included: the collective always runs (see gather_outputs)
     src = local.contiguous()
     if batch % world:
         src = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -283,6 +283,12 @@ class MultiView_MPL(nn.Module):
         r = super()._replicate_for_data_parallel()
         r._hip_cache = {}
         r._dp_replica = True
+        if self.matmul_precision == "bf16":
+            # a replica cannot honour the request (no packed bf16 operands): say so instead of silently running fp32
+            import warnings
+            warnings.warn("MultiView_MPL (HIP): DataParallel replicas run the fp32 matrix instructions; the requested "
+                          "matmul precision 'bf16' applies to the one-process-per-GPU path (openmpl_amd.dist) only",
+                          RuntimeWarning, stacklevel=2)
         return r
 
     # ------------------------------------------------------------------ C-ABI argument marshalling

@@ -93,3 +93,75 @@ def test_sharded_lifter_world2_gloo(batch):
         lo, hi = shard_range(batch, world, r)
         want += [float(r + i) for i in range(lo, hi)]
     assert tags == want
+
+
+def _worker_w8(rank, world, port, batch, q):
+    """configs[3]'s partition at its real world size: 8 ranks, uneven batch; the 'model' is a cheap per-pose map (what
+    is under test is the partition and the ONE collective of openmpl_amd/dist.py, not the forward)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(1)
+    P = [torch.randn(batch, 17, 3, generator=g) for _ in range(4)]
+    calls = []
+
+    def model(poses, rays=None, centers=None):
+        calls.append(poses[0].shape[0])
+        return torch.stack([p * (v + 1) for v, p in enumerate(poses)], 0).sum(0) + 0.25
+
+    lifter = ShardedLifter(model)
+    out = lifter(P)                                              # DataParallel call shape: full batch on every rank
+    lo, hi = shard_range(batch, world, rank)
+    ps, _, _, (a, b) = shard_inputs(P, None, None, world, rank)
+    assert (a, b) == (lo, hi) and calls == [hi - lo]
+    h = lifter.lift_shard(ps, batch=batch)                       # pre-sharded call shape
+    out2 = h.wait()
+    want = model(P)
+    ok = torch.equal(out, want) and torch.equal(out2, want) and out.shape == (batch, 17, 3)
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok))
+    if rank == 0:
+        q.put((all(oks), [shard_range(batch, world, r) for r in range(world)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [8190, 8192])
+def test_sharded_lifter_world8_gloo_uneven_batch(batch):
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w8, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, ranges = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, "8-rank sharded result differs from the single-process result on some rank"
+    sizes = [b - a for a, b in ranges]
+    assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1 and ranges[0][0] == 0 and ranges[-1][1] == batch
+    if batch == 8192:
+        assert sizes == [1024] * 8                               # BASELINE.json configs[3]: 1024 poses per GPU
+
+
+def test_single_rank_group_still_runs_the_collective():
+    """World size 1: the all-gather is issued all the same (no single-GPU shortcut to go untested)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        import unittest.mock as mock
+        x = torch.arange(5 * 17 * 3, dtype=torch.float32).reshape(5, 17, 3)
+        with mock.patch.object(dist, "all_gather_into_tensor", wraps=dist.all_gather_into_tensor) as spy:
+            lifter = ShardedLifter(lambda poses, rays=None, centers=None: poses[0] * 2)
+            out = lifter([x])
+            h = lifter.lift_shard([x], batch=5)
+            out2 = h.wait()
+            assert spy.call_count == 2
+        assert torch.equal(out, x * 2) and torch.equal(out2, x * 2) and out.data_ptr() != x.data_ptr()
+        assert torch.equal(gather_outputs(x, 5), x)
+    finally:
+        dist.destroy_process_group()

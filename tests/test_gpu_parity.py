@@ -250,6 +250,33 @@ def test_poses_are_independent_bitwise(name):
     assert torch.isfinite(full).all()
 
 
+def test_configs3_batch_8192_equals_its_eight_shards_bitwise():
+    """BASELINE.json configs[3] (V=4, J=17, batch 8192 sharded over 8 GPUs, 1024 each) on ONE GPU: the whole batch in
+    one call against the eight dist.shard_range shards run one after the other -- what rank r of the 8-GPU job computes
+    (valid_mpl.py:177-178,207: DataParallel scatters dim 0) -- must agree bit for bit, and the first and the last shard
+    must match the fp64 oracle."""
+    from openmpl_amd.dist import shard_range
+    m, g = _model("chosen_v4_b8_l12")
+    B, V, W = 8192, 4, 8
+    P, R, Cn = _big_inputs(B, V, 8192)
+    with torch.no_grad():
+        whole = m(P, rays=R, centers=Cn)
+        parts = []
+        for r in range(W):
+            lo, hi = shard_range(B, W, r)
+            assert hi - lo == 1024
+            cut = lambda lst: [x[lo:hi].contiguous() for x in lst]
+            parts.append(m(cut(P), rays=cut(R), centers=cut(Cn)))
+    assert whole.shape == (B, 17, 3) and torch.isfinite(whole).all()
+    assert torch.equal(whole, torch.cat(parts, 0)), "batch 8192 differs from its eight 1024-pose shards"
+    sd = golden_state_dict("chosen_v4_b8_l12", g)
+    for r in (0, W - 1):
+        lo, hi = shard_range(B, W, r)
+        cpu = lambda lst: [x[lo:hi].cpu() for x in lst]
+        ref = mpl_oracle.forward(sd, g["flags"], cpu(P), cpu(R), cpu(Cn), dtype=torch.float64)
+        _assert_close(parts[r], ref, "configs[3] shard %d vs fp64 oracle" % r)
+
+
 def test_view_order_matters_only_through_weights():
     """With shared SPT weights (CHOSEN) swapping two views == swapping the Conv1d view weights."""
     m, g = _model("chosen_v4_b8_l2")

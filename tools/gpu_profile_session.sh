@@ -1,18 +1,28 @@
 #!/bin/bash
-# One GPU session for the tracked profiles/ of a round:  bash tools/gpu_profile_session.sh r02
-#   1. headline bench line (N=1)                                   -> gpurun_out/prof_$TAG/bench.json
-#   2. rocprofv3 kernel trace + stats of the SAME command          -> gpurun_out/prof_$TAG/trace/
+# One GPU session for the tracked profiles/ of a round:
+#     bash tools/gpu_profile_session.sh r03                         headline workload (python bench.py)
+#     bash tools/gpu_profile_session.sh r03 cmu_v8_bf16 "--precision bf16 --views 8 --depth 2"    another workload
+#   1. bench line (N=1)                                             -> gpurun_out/prof_$TAG[_$SUF]/bench.json
+#   2. rocprofv3 kernel trace + stats of the SAME command           -> .../trace/
 #   3. rocprofv3 PMC passes (each its own run, --kernel-trace only) over the same command: the kernels profiled are
-#      the ones the forward runs (x3_stack_kernel, spt_kernel, fuse_head_kernel, ...)
-# tools/make_profiles.py turns the outputs into profiles/$TAG_*.
-TAG=${1:-r02}
+#      the ones the forward runs (x3_stack_kernel, spt3_kernel, fuse_head_kernel, ...)
+# tools/make_profiles.py $TAG [$SUF] turns the outputs into profiles/$TAG_*.
+TAG=${1:-r03}
+SUF=$2
+ARGS=$3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/prof_$TAG
+O=$R/gpurun_out/prof_$TAG${SUF:+_$SUF}
 mkdir -p $O; export TMPDIR=/tmp
 cd $R
-python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json
+if [ -z "$SUF" ]; then
+  python bench.py > $O/bench.log 2>&1
+else
+  python bench.py $ARGS --no-extra --no-cpu-baseline > $O/bench.log 2>&1
+fi
+tail -1 $O/bench.log > $O/bench.json
 cd /tmp
-CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
+CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra $ARGS"
+echo "$CMD" | sed "s#$R/##" > $O/cmd.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $CMD > $O/trace.log 2>&1
 P="rocprofv3 --kernel-trace --output-format csv"
 $P --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_a -o p -- $CMD > $O/pmc_a.log 2>&1
