@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs / engines)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the rank code path (process group + all-gather) even at one GPU")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_mfma", "bf16"],
-                    help="fp32: split-operand GEMMs on the bf16 matrix cores (default); fp32_mfma: native fp32 MFMA; "
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32x3", "fp32_mfma", "bf16"],
+                    help="fp32: fp16x2 split-operand GEMMs on the fp16 matrix cores (default); fp32x3: the round-2 engine "
+                         "(three bf16 parts, six products); fp32_mfma: native fp32 MFMA; "
                          "bf16: bf16 operands (BASELINE.json configs[2]: use with --views 8 --depth 2 / 12)")
     return ap.parse_args()
 
@@ -260,7 +261,7 @@ def run_rank(a):
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # backend "nccl" IS RCCL on ROCm
         lifter = ShardedLifter(model)
-    split = a.precision in ("fp32", "bf16") and model._x3_supported()
+    split = a.precision in ("fp32", "fp32x3", "bf16") and model._x3_supported()
     # a few distinct resident batches (per rank: pre-sharded inputs) so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
 
@@ -307,7 +308,8 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
     io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
     weight_bytes = sum(p.numel() for p in model.parameters()) * 4
-    gemm_kernel = ("x3_stack_kernel" if launches == 1 else "x3_gemm_kernel") if split else "ln_gemm_ng_kernel"
+    eng = "h2" if a.precision == "fp32" else "x3"
+    gemm_kernel = ((eng + "_stack_kernel") if launches == 1 else (eng + "_gemm_kernel")) if split else "ln_gemm_ng_kernel"
     # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
     # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
     traffic, traffic_src = None, None
@@ -322,25 +324,33 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     D = fpt_width(flags)
     # algorithmic bytes of the mean GEMM launch: A + W operand + C (+ residual) once each
     M = a.batch * a.views
-    np_ = 1 if a.precision == "bf16" else 3   # bf16 parts per operand element of the packed-operand engine
+    np_ = {"bf16": 1, "fp32": 2}.get(a.precision, 3)   # 16-bit parts per operand element of the packed-operand engine
     kpad = 1.0
     if split and np_ == 1:                    # bf16 engine: K padded with zero k-tiles to whole stages of 96
         kpad = (-(-(D // 32) // 3) * 3) / (D // 32)
     w_bytes = 2.0 * np_ * 144.0 / 136.0 * kpad if split else 4.0   # packed operand: np bf16 parts in 144/136-padded fragment order
     a_bytes = 2.0 * np_ * kpad if split else 4.0                   # activations travel between the GEMMs as np bf16 parts
+    # h2: the residual stream x (fp32) IS the operand of the LayerNorm GEMMs; x3 / bf16 hand a packed copy of x on as well
+    x_copy = M * D * a_bytes if (split and np_ != 2) else 0
     alg_bytes = ((M * D * a_bytes + 3 * D * D * w_bytes + M * D * a_bytes)                 # LN1 + qkv + attention: x in, att out
-                 + (M * D * a_bytes + D * D * w_bytes + 2 * M * D * 4 + (M * D * a_bytes if split else 0))    # proj: att in, x in/out (+ packed x out)
+                 + (M * D * a_bytes + D * D * w_bytes + 2 * M * D * 4 + x_copy)            # proj: att in, x in/out (+ packed x out)
                  + (M * D * a_bytes + 2 * D * D * w_bytes + M * 2 * D * a_bytes)           # fc1: x in, hid out
-                 + (M * 2 * D * a_bytes + 2 * D * D * w_bytes + 2 * M * D * 4 + (M * D * a_bytes if split else 0))) / 4.0   # fc2: hid in, x in/out
+                 + (M * 2 * D * a_bytes + 2 * D * D * w_bytes + 2 * M * D * 4 + x_copy)) / 4.0   # fc2: hid in, x in/out
     if split:
         # executed matrix-pipe work: 6 (fp32: three bf16 parts per operand) or 1 (bf16) partial products per product on
         # 144-column (9 x 16) tiles of 136; the bf16 engine also multiplies the zero k-tiles that pad K to stages of 96
-        products = 6.0 if np_ == 3 else 1.0
+        products = {3: 6.0, 2: 3.0, 1: 1.0}[np_]
         ex = alg * products * 144.0 / 136.0 * kpad
-        roof = dict(bound="mfma", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x32_bf16",
+        roof = dict(bound="mfma", kernel=gemm_kernel,
+                    instruction="v_mfma_f32_16x16x32_f16" if np_ == 2 else "v_mfma_f32_16x16x32_bf16",
                     achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
-                    arithmetic=("fp32 GEMM: operands split exactly into 3 bf16 terms, 6 significant partial products per "
+                    arithmetic=("fp32 GEMM: operands split into 2 fp16 terms under exact power-of-two scales, 3 partial products "
+                                "per fp32 product on the fp16 matrix cores (same rate as bf16; 9 MFMA column tiles per 136 output "
+                                "columns), fp32 accumulation -- as accurate as an fp32 GEMM (extra.max_scaled_err_vs_fp64); "
+                                "`achieved` = algorithmic fp32 FLOPs x 3 x 144/136 = executed fp16 MFMA FLOP/s; "
+                                if np_ == 2 else
+                                "fp32 GEMM: operands split exactly into 3 bf16 terms, 6 significant partial products per "
                                 "fp32 product on the bf16 matrix cores (9 MFMA column tiles per 136 output columns), fp32 "
                                 "accumulation; `achieved` = algorithmic fp32 FLOPs x 6 x 144/136 = executed bf16 MFMA FLOP/s; "
                                 if np_ == 3 else
@@ -468,17 +478,21 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     P, R, C = batches[0]
     sub = lambda lst, n: [x[:n].contiguous() for x in lst]
     cpu = lambda lst, n: [x[:n].cpu() for x in lst]
-    other = "fp32_mfma" if a.precision == "fp32" else "fp32"
-    model.set_matmul_precision(other)
-    n_o = max(10, a.steps // 2)
-    v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3)
-    with torch.no_grad():
-        got_o = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
-    model.set_matmul_precision(a.precision)
     ref64 = mpl_oracle.forward(sd, flags, cpu(P, nb), cpu(R, nb), cpu(C, nb), dtype=torch.float64)
     e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
-    extra[other + "_poses_per_s"] = round(v_o, 1)
-    extra["max_scaled_err_vs_fp64"] = {"hip_" + a.precision: e(got), "hip_" + other: e(got_o), "reference_fp32_cpu": e(ref)}
+    errs = {"hip_" + a.precision: e(got), "reference_fp32_cpu": e(ref)}
+    n_o = max(10, a.steps // 2)
+    for other in ("fp32", "fp32x3", "fp32_mfma"):          # the other fp32 engines: rate and distance from fp64
+        if other == a.precision:
+            continue
+        model.set_matmul_precision(other)
+        v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3)
+        with torch.no_grad():
+            got_o = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
+        extra[other + "_poses_per_s"] = round(v_o, 1)
+        errs["hip_" + other] = e(got_o)
+    model.set_matmul_precision(a.precision)
+    extra["max_scaled_err_vs_fp64"] = errs
     # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
     f2 = model_flags("full", a.views, a.depth)
     m2 = build_model(f2, dev)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 7
+#define MPL_HIP_ABI_VERSION 8
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -90,6 +90,13 @@ typedef struct mpl_block_weights {
      * significant partial products -- at least as accurate as an fp32 multiply (csrc/x3_gemm.hip) at 2.7x less matrix-
      * pipe time than the native fp32 MFMA.  Shapes must satisfy mpl_split_bf16x3_bytes() != 0, else leave them NULL. */
     const uint16_t *qkv_w3, *proj_w3, *fc1_w3, *fc2_w3;
+    /* Optional fp16x2 operands (mpl_pack_h2) of the four Linear layers, same folding as above: the DEFAULT fp32 engine of the
+     * FPT block stack (csrc/h2_gemm.hip).  Every fp32 operand is split in two fp16 parts under an exact power-of-two scale
+     * (per weight column; static per layer for the activations, from a data-free bound), each product is accumulated in fp32
+     * from three partial products ("3xTF32" on the fp16 matrix cores): as accurate as an fp32 GEMM, half the matrix
+     * instructions and two thirds of the operand bytes of the *_w3 engine.  Used when all four are non-NULL (and *_w16,
+     * *_w3 are NULL) in every block; shapes must satisfy mpl_pack_h2_bytes() != 0. */
+    const uint16_t *qkv_h2, *proj_h2, *fc1_h2, *fc2_h2;
 } mpl_block_weights;
 
 /* Per-view (or shared) spatial parameter set, multiview_mpl.py:159-195, :236-249. */
@@ -261,6 +268,20 @@ int mpl_prepare_inputs(const float *joints_px, const float *conf, const double *
 int mpl_pose_metrics_size(int joints);
 int mpl_pose_metrics(const float *output, const float *target, const float *weight, int batch, int joints,
                      const float *scale3, const float *offset3, float *result, void *stream);
+
+/* ---- fp16x2 split-operand engine (csrc/h2_gemm.hip): "fp32" precision of MultiView_MPL (the default).
+ * mpl_pack_h2: derived operand of one nn.Linear (W (N,K) row-major, bias (N)), optionally with the LayerNorm in front of it
+ * folded in (ln_w, ln_b of length K, or both NULL).  dst: mpl_pack_h2_bytes(N, K) bytes (0 = the shape has no layout:
+ * N % 136 == 0, K % 544 == 0 required; with a LayerNorm folded in also K <= 2048).
+ * mpl_ln_linear_h2: y[M,N] = epi(LN?(x) W^T + b) from that operand -- the unit-test entry of one GEMM (the forward runs all
+ * GEMMs of a stack in ONE launch, mpl_block_stack); has_ln: x is normalised with eps (stats: 2 * M * K/136 floats of
+ * scratch); else x is packed with its measured amax.  workspace: mpl_ln_linear_h2_workspace_bytes(M, K). */
+size_t mpl_pack_h2_bytes(int N, int K);
+int mpl_pack_h2(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
+                void *stream);
+size_t mpl_ln_linear_h2_workspace_bytes(int M, int K);
+int mpl_ln_linear_h2(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W2, int N, int epilogue,
+                     const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- device-side failures.  The block stack runs as ONE persistent launch whose workgroups hand operands to each
  * other (x3_gemm.hip); it needs all its workgroups resident, i.e. the device to itself for the duration of the launch

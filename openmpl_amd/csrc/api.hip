@@ -71,6 +71,19 @@ void mpl::device_error_clear(int dev) {
 }
 
 namespace {
+std::mutex g_chain_mu[64];
+hipEvent_t g_chain_ev[64];
+std::mutex g_chain_create_mu;
+}  // namespace
+std::mutex& mpl::stack_chain_mutex(int dev) { return g_chain_mu[(dev >= 0 && dev < 64) ? dev : 0]; }
+hipEvent_t mpl::stack_chain_event(int dev) {
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_chain_create_mu);
+    if (!g_chain_ev[dev] && hipEventCreateWithFlags(&g_chain_ev[dev], hipEventDisableTiming) != hipSuccess) g_chain_ev[dev] = nullptr;
+    return g_chain_ev[dev];
+}
+
+namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -130,19 +143,51 @@ X3Ws carve_x3_ws(void* base, size_t M, size_t D, int rpt) {
     return w;
 }
 
-// 3 = every block carries split-fp32 operands, 1 = every block carries packed bf16 operands, 0 = neither (or the shape has
-// no packed layout): the stack then runs on the fp32 matrix instructions
+// 2 = every block carries fp16x2 operands (h2_gemm.hip, the default fp32 engine), 3 = split-bf16x3 operands, 1 = packed bf16
+// operands, 0 = none of them (or the shape has no packed layout): the stack then runs on the fp32 matrix instructions
 int stack_packed_parts(const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps, int n_tok, int D, int H) {
     if (n_apps <= 0 || !x3_attention_fusable(n_tok, D, H) || !x3_shape_ok(D, 2 * D)) return 0;
     int np = 0;
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        const int bp = (b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16) ? 1 : ((b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3) ? 3 : 0);
+        const int bp = (b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16) ? 1
+                     : ((b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3) ? 3
+                     : ((b.qkv_h2 && b.proj_h2 && b.fc1_h2 && b.fc2_h2) ? 2 : 0));
         if (bp == 0 || (np && bp != np)) return 0;
         np = bp;
     }
+    if (np == 2 && (!h2_attention_fusable(n_tok, D, H) || !h2_shape_ok(D, 2 * D))) return 0;
     return np;
 }
+
+// fp16x2 path (h2_gemm.hip): x stays fp32 in place and is the A operand of the LayerNorm GEMMs; the attention output and
+// the GELU output travel as packed operands
+struct H2Ws {
+    unsigned short *att2, *hid2;
+    float* stats;
+    unsigned* counters;
+    size_t bytes;
+};
+H2Ws carve_h2_ws(void* base, size_t M, size_t D, int rpt) {
+    H2Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
+    };
+    w.att2 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)D, rpt)));
+    w.hid2 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)(2 * D), rpt)));
+    w.stats = reinterpret_cast<float*>(take((M + 64) * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
+    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt + 64) * sizeof(unsigned)));
+    w.bytes = off;
+    return w;
+}
+inline const float* h2_meta(const uint16_t* op, int N, int K) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(op) + h2_operand_bytes(N, K)) - 8;
+}
+int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
+                   int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s);
 
 // Block stack on split operands: per application LN1+qkv+attention | proj+residual | LN2+fc1+GELU | fc2+residual, the
 // activations handed from epilogue to k loop as A3 (x3 -> att3 -> x3 -> hid3 -> x3), x itself stays fp32 in place.
@@ -194,6 +239,49 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     return MPL_OK;
 }
 
+int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
+                   int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
+    const int M = n_seq * n_tok, rpt = h2_rows_per_tile(n_tok);
+    const H2Ws w = carve_h2_ws(ws, (size_t)M, (size_t)D, rpt);
+    if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
+    const int n_tiles = (M + rpt - 1) / rpt;
+    if (err_ws) *err_ws = w.counters + n_tiles;
+    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
+    int rc;
+    // entry of the stack, one launch: LayerNorm slice partials of the incoming rows, zeroed arrival counters + error word
+    if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, n_tiles + 1, s))) return rc;
+    if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
+    if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
+        const unsigned short* ops[MPL_MAX_APPS * 4];
+        for (int a = 0; a < n_apps; ++a) {
+            const mpl_block_weights& b = blocks[schedule[a]];
+            for (int i = 0; i < 4; ++i) ops[4 * a + i] = (&b.qkv_h2)[i];
+        }
+        return launch_h2_stack(x, M, D, n_tok, H, ops, n_apps, w.att2, w.hid2, w.stats, w.counters, eps, g_x3_stop.load(), s);
+    }
+    // A/B switch (mpl_x3_stack_mode): the same phases as one launch per GEMM
+    const int stop = g_x3_stop.load();
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        const float* m_qkv = h2_meta(b.qkv_h2, 3 * D, D);
+        const float* m_fc1 = h2_meta(b.fc1_h2, 2 * D, D);
+        if ((rc = launch_h2_qkv_attention(x, b.qkv_h2, w.stats, eps, M, D, n_tok, H, w.att2, s))) return rc;
+        if (stop && 4 * a + 1 >= stop) return MPL_OK;
+        if ((rc = launch_h2_gemm(nullptr, w.att2, m_qkv + 3, b.proj_h2, false, nullptr, 0.f, x, D, x, D, nullptr, nullptr, w.stats, M, D, D,
+                                 rpt, MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+        if (stop && 4 * a + 2 >= stop) return MPL_OK;
+        if ((rc = launch_h2_gemm(x, nullptr, nullptr, b.fc1_h2, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid2, m_fc1, nullptr, M, 2 * D,
+                                 D, rpt, MPL_EPI_BIAS_GELU, s)))
+            return rc;
+        if (stop && 4 * a + 3 >= stop) return MPL_OK;
+        if ((rc = launch_h2_gemm(nullptr, w.hid2, m_fc1 + 2, b.fc2_h2, false, nullptr, 0.f, x, D, x, D, nullptr, nullptr, w.stats, M, D,
+                                 2 * D, rpt, MPL_EPI_BIAS_RESIDUAL, s)))
+            return rc;
+    }
+    return MPL_OK;
+}
+
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
                      const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
     if (err_ws) *err_ws = nullptr;
@@ -202,8 +290,10 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
-    if (const int np = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H))
+    if (const int np = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H)) {
+        if (np == 2) return block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
         return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, err_ws, s);
+    }
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
@@ -219,7 +309,9 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
             // packed operands (split fp32 / bf16) take the block_stack_x3 route above; here they cannot be used
-        if (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3 || b.qkv_w16 || b.proj_w16 || b.fc1_w16 || b.fc2_w16) return MPL_E_UNSUPPORTED;
+        if (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3 || b.qkv_w16 || b.proj_w16 || b.fc1_w16 || b.fc2_w16 || b.qkv_h2 ||
+            b.proj_h2 || b.fc1_h2 || b.fc2_h2)
+            return MPL_E_UNSUPPORTED;
         const bool fused_att = fusable;
         // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
         if (!have_stats && (rc = launch_row_stats(x, M, D, D, w.stats, s))) return rc;
@@ -259,6 +351,8 @@ size_t stack_ws_bytes(size_t M, size_t D, int n_tok) {
     if (rpt > 0 && n_tok <= 32 && x3_shape_ok((int)D, (int)(2 * D))) {
         const size_t b3 = carve_x3_ws(nullptr, M, D, rpt).bytes;
         b = b3 > b ? b3 : b;
+        const size_t b2 = carve_h2_ws(nullptr, M, D, rpt).bytes;
+        b = b2 > b ? b2 : b;
     }
     return b;
 }
@@ -393,6 +487,38 @@ int mpl_pack_bf16(const float* W, const float* bias, const float* ln_w, const fl
     return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 1, (hipStream_t)stream);
 }
 
+size_t mpl_pack_h2_bytes(int N, int K) { return h2_operand_bytes(N, K); }
+
+int mpl_pack_h2(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst, void* stream) {
+    clear_stale_hip_error();
+    if (mpl_pack_h2_bytes(N, K) == 0) return MPL_E_INVALID;
+    return launch_pack_h2(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
+}
+
+size_t mpl_ln_linear_h2_workspace_bytes(int M, int K) {
+    const size_t a = h2_act_bytes(M, K, 64);
+    return a ? a + 256 : 0;
+}
+
+int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W2, int N, int epilogue,
+                     const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    clear_stale_hip_error();
+    if (!x || !W2 || !y || h2_operand_bytes(N, K) == 0 || M <= 0) return MPL_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (has_ln) {
+        if (!stats) return MPL_E_INVALID;
+        if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
+        return launch_h2_gemm(x, nullptr, nullptr, W2, true, stats, eps, residual, N, y, N, nullptr, nullptr, nullptr, M, N, K, 64, epilogue, s);
+    }
+    const size_t need = mpl_ln_linear_h2_workspace_bytes(M, K);
+    if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
+    float* sc = reinterpret_cast<float*>(workspace);
+    unsigned short* a2 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + 256);
+    if ((rc = launch_h2_pack_rows(x, M, K, K, 64, a2, sc, s))) return rc;
+    return launch_h2_gemm(nullptr, a2, sc + 2, W2, false, nullptr, 0.f, residual, N, y, N, nullptr, nullptr, nullptr, M, N, K, 64, epilogue, s);
+}
+
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);
@@ -413,11 +539,13 @@ int mpl_device_error_clear(int device) {
 int mpl_x3_spin_limit(int log2_polls) {
     if ((log2_polls & 0xff) < 1 || (log2_polls & 0xff) > 30 || log2_polls < 0) return MPL_E_INVALID;
     x3_set_spin_log2(log2_polls);
+    h2_set_spin_log2(log2_polls);
     return MPL_OK;
 }
 
 int mpl_x3_debug_buffer(void* device_buffer) {
     x3_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
+    h2_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
     return MPL_OK;
 }
 

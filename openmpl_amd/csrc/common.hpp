@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/mpl_hip.h"
 
@@ -128,8 +129,34 @@ unsigned* device_error_word(int dev);      // device-usable address; nullptr if 
 int device_error_pending(int dev);         // 1 when a kernel reported a failure since the last clear
 void device_error_clear(int dev);
 void x3_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
+void h2_set_spin_log2(int log2_polls);
+// The persistent block-stack kernels (x3_stack_kernel, h2_stack_kernel) need every workgroup resident: the library
+// serialises its own launches of them per device, whatever stream they are on -- each launch waits for the event recorded
+// behind the previous one (api.hip).  The event exists from the first call (waiting on a never-recorded event is a no-op).
+hipEvent_t stack_chain_event(int dev);
+std::mutex& stack_chain_mutex(int dev);
 int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
                             int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
+// fp32 GEMMs on the fp16 matrix cores from operands split in TWO fp16 parts (three partial products), h2_gemm.hip: the
+// default engine of the FPT block stack
+bool h2_shape_ok(int N, int K);
+size_t h2_operand_bytes(int N, int K);                    // packed weights + {c, sc, sw, bound}[N] + meta[8]; 0 = no layout
+size_t h2_act_bytes(int M, int K, int rpt);
+int h2_rows_per_tile(int n_tok);
+bool h2_attention_fusable(int n_tok, int dim, int heads);
+void h2_set_debug_buffer(unsigned long long* p);
+int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
+                   hipStream_t s);
+int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters, hipStream_t s);
+int launch_h2_pack_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, float* sc, hipStream_t s);
+int launch_h2_gemm(const float* X, const unsigned short* A2, const float* a_inv, const unsigned short* W2, bool ln, const float* stats,
+                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, const float* o_scale, float* stats_out,
+                   int M, int N, int K, int rpt, int epi, hipStream_t s);
+int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const float* stats, float eps, int M, int D, int n_tok,
+                            int heads, unsigned short* att2, hipStream_t s);
+int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
+                    unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
+                    hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 // use_packed: every SPT block carries the split operand of mpl_spt_pack in qkv_w3 (spt3_kernel: Linear layers on the bf16
 // matrix cores); else the fp32-MFMA kernel reads the nn.Linear weights in place

@@ -1,0 +1,1375 @@
+// fp32 GEMM on the fp16 matrix cores by two-way operand splitting ("h2"), the default engine of the FPT block stack:
+//     C = epi( LN(A) . W^T + bias )
+//
+// Reference ops (MPL/lib/models/multiview_mpl.py): Block.norm1 + Attention.qkv :55 + Attention.forward :55-64,
+// Attention.proj :65 + residual :90, Block.norm2 + Mlp.fc1 + GELU :32-33, Mlp.fc2 :35 + residual :91.
+//
+// Arithmetic.  The packed 16-bit matrix pipe of gfx950 is 16x faster than the fp32 one, so an fp32 product is formed from
+// 16-bit pieces.  Round 2 (x3_gemm.hip, still selectable as "fp32x3") used three bf16 pieces per operand and six partial
+// products.  This engine uses TWO fp16 pieces and THREE partial products -- the "3xTF32" scheme of the CUDA world on the
+// fp16 pipe (fp16 has the 11-bit significand of TF32):
+//     x = hi + lo (+ eps),  hi = fp16(x),  lo = fp16(x - hi)      |eps| <= 2^-22 |x|   (x - hi is exact in fp32)
+//     x . w  ~=  lo.hi + hi.lo + hi.hi        (A part . W part, fp32 accumulation in v_mfma_f32_16x16x32_f16)
+// the dropped lo.lo term is <= 2^-22 relative.  Measured against fp64 on the bench model the result is as far from the
+// truth as an fp32 GEMM is (the fp32 ACCUMULATION error dominates both): single GEMM 5.5e-7 (h2) / 5.2e-7 (fp32) /
+// 2.8e-7 (x3) max-scaled; whole forward 7.9e-7 / 7.9e-7 / 7.9e-7 (tools/h2_emulate.py, tests/test_h2_gpu.py).
+// Half the matrix instructions and two thirds of the operand bytes of x3 -- and the operand bytes through the LDS-DMA path
+// are what bounds the k loop (tools/h2_probe.hip: 19-42 cycles per KiB and CU, by source).
+//
+// fp16 has a 5-bit exponent, so every operand is brought into its window by an EXACT power-of-two scale that the epilogue
+// takes out again (no rounding anywhere):
+//   * weights: one scale per output column n, max_k |W_nk| sw_n in [2^13, 2^14)   (computed when the binding packs them);
+//   * the input of a LayerNorm GEMM (qkv, fc1) is normalised BEFORE it is split: z = (x - mean) rstd 2^10, |z| <= sqrt(K)
+//     2^10 < 65504 for every K <= 2048 -- the gain gamma is folded into W, beta and the bias into c:
+//         LN(x) . W^T + b  =  2^-10 sw_n^-1 ( z . (sw_n gamma o W_n) ) + c_n,     c_n = b_n + sum_k beta_k W_nk ;
+//   * the inputs of proj and fc2 (attention output, GELU output) use one STATIC scale per layer from a bound that needs no
+//     data: |LN(x) . W_n + b_n| <= sqrt(K) |gamma o W_n|_2 + |c_n| (Cauchy-Schwarz, |LN(x)|_2 <= sqrt(K)); the attention
+//     output is a convex combination of v rows and |gelu(t)| <= |t|, so the bound of the producing Linear holds for both.
+//     Typical values sit sqrt(K) below the bound, i.e. at >= 2^10 of a 2^15 window; fp16 subnormals are honoured by the
+//     MFMA and by v_cvt (tools/h2_probe.hip), so the absolute resolution is 2^-24 2^-11 of the window.
+// Nothing overflows for ANY input; the unit-test entry (mpl_ln_linear_h2) scales a plain A operand by its measured amax.
+//
+// Data flow of a block application (x = fp32 residual stream, the ONLY activation kept in fp32):
+//   qkv : A = x (fp32 rows, LDS-DMA'd raw into the stage, normalised + split IN PLACE by the wave that brought them -- 32 B
+//         of fp32 become 16 B hi + 16 B lo in the same LDS bytes), epilogue = attention in registers -> att2 (packed)
+//   proj: A = att2 (packed, LDS-DMA), epilogue: x += ..., LayerNorm slice partials
+//   fc1 : A = x as above, epilogue GELU -> hid2 (packed);   fc2: A = hid2, epilogue: x += ..., partials
+// x3 handed x from GEMM to GEMM as a split copy; here the residual epilogues write only fp32 x (write-through) and the
+// consumers split it themselves: 4 B per element on the wire instead of 4 + 6, and no two-step scale exchange.
+//
+// Layouts (K = 136 G columns, G a multiple of 4; KT = K / 32 k-tiles; the k permutation is x3's):
+//   k-tile t < 4G:  lane (i, kq) element j <-> column 136 (t/4) + 32 (t%4) + 16 (j/4) + 4 kq + (j%4);  t = 4G + u: 136 (4u + kq) + 128 + j
+//   A2[row tile][4 row groups][KT][2 parts][64 lanes][8 fp16]     lane = 16 kq + i, i = row in the 16-row group
+//   W2[N/136][KT][9 slots][2 parts][64 lanes][8 fp16]             slot s = column tile {0,1,2,3,8,4,5,6,7}[s]
+//       followed by fp32 vectors c[N], sc[N] (epilogue multiplier), sw[N], bound[N] and meta[8] = {scale of the packed
+//       output (all columns), the same for the last third of the columns (v), their reciprocals, ...}
+// Workgroup = one row tile x 136 columns (x NPASS column groups), 8 waves: wave w owns row group w & 3 and slots 0..4
+// (w < 4) or 5..8.  Stage = A 8 KiB + W 18 KiB = 26 KiB, ring of 6 (156 KiB, one workgroup per CU).
+// The k order of every output element is fixed: results do not depend on batch size or launch geometry.
+#include <stdlib.h>
+
+#include <mutex>
+#include <type_traits>
+
+#include "gemm_common.hpp"
+
+namespace mpl {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int H2_RG = 2 * 1024;              // A bytes per (row group, k-tile): hi | lo fragment
+constexpr int H2_A = 4 * H2_RG;              // A bytes per stage (64 rows)
+constexpr int H2_W = 18 * 1024;              // W bytes per k-tile of a 136-column group: 9 slots x {hi, lo}
+constexpr int H2_STAGE = H2_A + H2_W;        // 26624
+constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
+constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
+constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
+constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
+constexpr int H2_T0 = 5;
+constexpr int H2_MAX_WGS = 1024;
+constexpr int H2_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the generic attention epilogue
+constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (K <= 2048)
+#ifndef H2_DBG
+#define H2_DBG 0
+#endif
+#ifndef H2_ABL
+#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no in-place conversion
+#endif
+#ifndef H2_WT_AUX
+#define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
+#endif
+#ifndef H2_STAGGER
+#define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
+#endif
+
+__host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
+__host__ __device__ inline int h2_col(int t, int kq, int j, int G) {
+    if (t < 4 * G) return 136 * (t >> 2) + 32 * (t & 3) + 16 * (j >> 2) + 4 * kq + (j & 3);
+    return 136 * (4 * (t - 4 * G) + kq) + 128 + j;
+}
+
+// K <= 2048 is needed only where a LayerNorm is folded in (the static 2^10 scale of a normalised row, |z| <= sqrt(K) 2^10);
+// launch_pack_h2 checks that; the packed layout itself exists for every multiple of 544
+bool h2_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 * BN) == 0 && K <= 8704; }
+
+size_t h2_operand_bytes(int N, int K) {
+    if (!h2_shape_ok(N, K)) return 0;
+    return (size_t)(N / BN) * (K / BK) * H2_W + ((size_t)4 * N + 8) * sizeof(float);
+}
+size_t h2_act_bytes(int M, int K, int rpt) {
+    if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
+    const size_t tiles = ((size_t)M + rpt - 1) / rpt;
+    return tiles * 4 * (K / BK) * H2_RG;
+}
+int h2_rows_per_tile(int n_tok) { return (n_tok >= 1 && n_tok <= BM) ? (BM / n_tok) * n_tok : 0; }
+bool h2_attention_fusable(int n_tok, int dim, int heads) {
+    if (n_tok < 1 || n_tok > 32 || heads <= 0 || dim % heads || !h2_shape_ok(3 * dim, dim)) return false;
+    const int hd = dim / heads;
+    if (BN % hd || (hd & 3)) return false;
+    const int S = BM / n_tok, HP = BN / hd;
+    return (size_t)(BM * H2_ATT_TS + S * HP * n_tok * n_tok) * sizeof(float) <= (size_t)H2_NST * H2_STAGE;
+}
+
+// 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept)
+__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
+}
+// largest power of two p with p * v <= 2^15 (v > 0, finite); 1 for v == 0
+__host__ __device__ inline float h2_window_scale(float v) {
+    if (!(v > 0.f)) return 1.0f;
+    int e;
+    (void)frexpf(32768.0f / v, &e);            // 32768 / v = m 2^e, m in [0.5, 1)  ->  2^(e-1) <= 32768 / v
+    e = e - 1 < -120 ? -120 : (e - 1 > 120 ? 120 : e - 1);   // both the scale and its reciprocal stay normal fp32 numbers
+    return ldexpf(1.0f, e);
+}
+
+// ---------------------------------------------------------------------------------------------- weight operand
+// trailer floats behind the fragments: c[N] | sc[N] | sw[N] | bound[N] | meta[8]
+// One wave per output column n: the column scale sw_n (max |gamma o W_n| sw_n in [2^13, 2^14)), c_n = b_n + sum_k beta_k W_nk
+// (fp64 sum), the epilogue multiplier sc_n = 1 / (sa sw_n) (sa = the static scale of a normalised LayerNorm input, or 1) and
+// the data-free bound of |out_n| (LayerNorm GEMMs only; see the head of the file).
+__global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
+                                                       float* __restrict__ tr) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double ss = 0.0, c = 0.0;
+    float amax = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const float wg = gamma ? w * gamma[k] : w;
+        amax = fmaxf(amax, fabsf(wg));
+        ss += (double)wg * (double)wg;
+        if (gamma) c += (double)w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        c += __shfl_xor(c, o, 64);
+        amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    }
+    if (lane == 0) {
+        float sw = 1.0f;
+        if (amax > 0.f && amax < 3.0e38f) {
+            int e;
+            (void)frexpf(amax, &e);            // amax = m 2^e, m in [0.5, 1): amax 2^(14 - e) in [2^13, 2^14)
+            e = 14 - e;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            sw = ldexpf(1.0f, e);
+        }
+        const float cn = (float)(c + (double)bias[n]);
+        const float sa = gamma ? H2_SA : 1.0f;
+        tr[n] = cn;
+        tr[N + n] = 1.0f / (sa * sw);
+        tr[2 * N + n] = sw;
+        tr[3 * N + n] = gamma ? (float)(sqrt((double)K) * sqrt(ss)) + fabsf(cn) : 0.f;
+    }
+}
+// meta: the static scales of what a LayerNorm GEMM hands on (all columns: GELU output of fc1; last third: v of qkv)
+__global__ __launch_bounds__(256) void h2_meta_kernel(int N, float* __restrict__ tr) {
+    __shared__ float red[2][256];
+    float ball = 0.f, bv = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float b = tr[3 * N + n];
+        ball = fmaxf(ball, b);
+        if (3 * n >= 2 * N) bv = fmaxf(bv, b);
+    }
+    red[0][threadIdx.x] = ball;
+    red[1][threadIdx.x] = bv;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = fmaxf(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* m = tr + 4 * N;
+        const float sa = h2_window_scale(red[0][0]), sv = h2_window_scale(red[1][0]);
+        m[0] = sa; m[1] = sv; m[2] = 1.0f / sa; m[3] = 1.0f / sv;
+        m[4] = red[0][0]; m[5] = red[1][0]; m[6] = 0.f; m[7] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict__ W, const float* __restrict__ gamma, int N, int K,
+                                                         const float* __restrict__ tr, f16x8* __restrict__ dst, size_t total) {
+    const int G = K / BN, KT = K / BK;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        const int slot = (int)((idx >> 6) % NT);
+        const int kt = (int)((idx / (64 * NT)) % KT);
+        const int g = (int)(idx / ((size_t)64 * NT * KT));
+        const int li = lane & 15, kq = lane >> 4;
+        const int c = h2_slot_tile(slot) * 16 + li;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = 0.f;
+            if (c < BN) {
+                const int k = h2_col(kt, kq, j, G);
+                const float w = W[(size_t)(g * BN + c) * K + k];
+                x[j] = (gamma ? w * gamma[k] : w) * tr[2 * N + g * BN + c];    // gain folded (one fp32 rounding), then the exact column scale
+            }
+        }
+        f16x8 hi, lo;
+        split2(x, hi, lo);
+        f16x8* o = dst + ((size_t)(g * KT + kt) * 18 + slot * 2) * 64 + lane;
+        o[0] = hi;
+        o[64] = lo;
+    }
+}
+
+int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
+                   hipStream_t s) {
+    if (!W || !dst || !bias || !h2_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr))) return MPL_E_INVALID;
+    if (ln_w && K > 2048) return MPL_E_UNSUPPORTED;
+    float* tr = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * (K / BK) * H2_W);
+    hipLaunchKernelGGL(h2_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, tr);
+    hipLaunchKernelGGL(h2_meta_kernel, dim3(1), dim3(256), 0, s, N, tr);
+    const size_t total = (size_t)(N / BN) * (K / BK) * NT * 64;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(h2_pack_w_kernel, dim3(grid), dim3(256), 0, s, W, ln_w, N, K, tr, reinterpret_cast<f16x8*>(dst), total);
+    return hip_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- entry of a stack
+// One launch in front of the persistent kernel: the LayerNorm slice partials {mean, M2} of the incoming rows (one wave per
+// row, two-pass per 136-column slice) and -- block 0 -- the zeroed arrival counters + error word of the call.
+__global__ __launch_bounds__(256) void h2_entry_kernel(const float* __restrict__ X, int M, int K, int ldx, float* __restrict__ stats,
+                                                        unsigned* __restrict__ counters, int n_counters) {
+    if (blockIdx.x == 0 && counters)
+        for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0u;
+    const int lane = threadIdx.x & 63;
+    const int row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int ns = K / BN;
+    for (int sidx = 0; sidx < ns; ++sidx) {
+        const float* xr = X + (size_t)row * ldx + sidx * BN;
+        const bool on = lane < BN / 4;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (on) v = ld4(xr + 4 * lane);
+        const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)BN;
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        const float ss = wave_sum(on ? (a * a + b * b) + (c * c + d * d) : 0.f);
+        if (lane == 0) {
+            stats[((size_t)row * ns + sidx) * 2] = mean;
+            stats[((size_t)row * ns + sidx) * 2 + 1] = ss;
+        }
+    }
+}
+int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters, hipStream_t s) {
+    if (!X || !stats || M <= 0 || K % BN || (ldx & 3)) return MPL_E_INVALID;
+    ProfScope prof(MPL_K_ROW_STATS, s);
+    hipLaunchKernelGGL(h2_entry_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, M, K, ldx, stats, counters, n_counters);
+    return hip_check_launch();
+}
+
+// plain (not normalised) fp32 rows -> packed A2 with ONE measured scale (unit-test entry of a GEMM without LayerNorm):
+// sc[0] <- amax bits (atomicMax over |x|), then sc[1] = scale, sc[2] = 1 / scale, operand = split2(x scale)
+__global__ __launch_bounds__(256) void h2_amax_kernel(const float* __restrict__ X, size_t n, unsigned* __restrict__ sc) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(X[i]));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(sc, __builtin_bit_cast(unsigned, m));      // non-negative floats order like their bits
+}
+__global__ __launch_bounds__(256) void h2_pack_rows_kernel(const float* __restrict__ X, int M, int K, int ldx, int rpt,
+                                                            char* __restrict__ dst, size_t total, float* __restrict__ sc) {
+    const float amax = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(sc)[0]);
+    const float scale = h2_window_scale(amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[1] = scale;
+        sc[2] = 1.0f / scale;
+    }
+    const int G = K / BN, KT = K / BK;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        const int kt = (int)((idx >> 6) % KT);
+        const size_t rgi = idx / ((size_t)64 * KT);          // tile * 4 + row group
+        const int li = lane & 15, kq = lane >> 4;
+        const int rl = (int)(rgi & 3) * 16 + li;
+        const size_t row = (rgi >> 2) * rpt + rl;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = 0.f;
+        if (rl < rpt && row < (size_t)M) {
+            const float* src = X + row * ldx;
+            const float4 p = ld4(src + h2_col(kt, kq, 0, G)), q = ld4(src + h2_col(kt, kq, 4, G));
+            x[0] = p.x * scale; x[1] = p.y * scale; x[2] = p.z * scale; x[3] = p.w * scale;
+            x[4] = q.x * scale; x[5] = q.y * scale; x[6] = q.z * scale; x[7] = q.w * scale;
+        }
+        f16x8 hi, lo;
+        split2(x, hi, lo);
+        char* o = dst + (rgi * KT + kt) * H2_RG + lane * 16;
+        *reinterpret_cast<f16x8*>(o) = hi;
+        *reinterpret_cast<f16x8*>(o + 1024) = lo;
+    }
+}
+// sc: 4 floats of device scratch ({amax bits, scale, 1 / scale, -}); the GEMM reads sc + 2 as its a_inv
+int launch_h2_pack_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, float* sc, hipStream_t s) {
+    if (!X || !dst || !sc || h2_act_bytes(M, K, rpt) == 0 || (ldx & 3) || ldx != K) return MPL_E_INVALID;
+    if (hipMemsetAsync(sc, 0, 16, s) != hipSuccess) return MPL_E_LAUNCH;
+    const size_t n = (size_t)M * K;
+    hipLaunchKernelGGL(h2_amax_kernel, dim3((int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, X, n,
+                       reinterpret_cast<unsigned*>(sc));
+    const size_t tiles = ((size_t)M + rpt - 1) / rpt;
+    const size_t total = tiles * 4 * (K / BK) * 64;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(h2_pack_rows_kernel, dim3(grid), dim3(256), 0, s, X, M, K, ldx, rpt, reinterpret_cast<char*>(dst), total, sc);
+    return hip_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM
+struct H2Args {
+    const char* A2;          // packed activations (GEMMs without LayerNorm); unused when LNF
+    const float* X;          // LNF: the fp32 rows, normalised and split in the k loop
+    int ldx;
+    const char* W2;          // packed weights (gamma folded for LNF)
+    const float* cvec;       // c per output column
+    const float* svec;       // sc per output column: 1 / (sa sw)
+    const float* stats;      // LNF: per-row slice partials of the K-wide input rows
+    const float* a_inv;      // !LNF: device scalar, reciprocal of the scale of A2 (NULL = 1)
+    const float* o_scale;    // C2 != NULL: device scalar, scale of the packed output
+    const float* R;          // residual (fp32), EPI_RES
+    int ldr;
+    float* C;                // fp32 output (optional)
+    int ldc;
+    char* C2;                // packed output (optional): the next GEMM's operand
+    float* stats_out;        // residual epilogue: slice partials of the rows produced
+    int M, N, K, rpt;
+    int grid_m, grid_n;
+    float eps;
+    int att_ntok, att_hd;
+    unsigned long long* dbg;
+    unsigned* err_ws;        // chain mode: see x3_gemm.hip X3Args
+    unsigned* err_host;
+    int spin_log2;
+};
+
+static std::atomic<unsigned long long*> g_h2_dbg{nullptr};
+void h2_set_debug_buffer(unsigned long long* p) { g_h2_dbg.store(p); }
+static std::atomic<int> g_h2_spin_log2{23};
+static std::atomic<int> g_h2_inject{0};
+void h2_set_spin_log2(int v) {
+    g_h2_spin_log2.store(v & 0xff);
+    g_h2_inject.store(v >> 8);
+}
+
+enum { H2_EPI_BIAS = 0, H2_EPI_GELU = 1, H2_EPI_RES = 2, H2_EPI_ATT = 3 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void h2_st16(bool wt, void* base, unsigned off, const u32x4& w) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(w, h2_rsrc(base), off, 0, H2_WT_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, h2_rsrc(base), off, 0, 0);
+}
+__device__ __forceinline__ void h2_st8(bool wt, void* base, unsigned off, const u32x2& h) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, h2_rsrc(base), off, 0, H2_WT_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(h, h2_rsrc(base), off, 0, 0);
+}
+__device__ __forceinline__ u32x4 h2_ld16_l2(const void* base, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(h2_rsrc(base), off, 0, 16);
+}
+// pack 8 fp32 values (already multiplied by the output scale) of one fragment lane: k-tile t of the strip at `base`
+__device__ __forceinline__ void h2_emit_frag(bool wt, char* base, int t, unsigned lo_off, const float (&x)[8]) {
+    f16x8 hi, lo;
+    split2(x, hi, lo);
+    h2_st16(wt, base, (unsigned)(t * H2_RG) + lo_off, __builtin_bit_cast(u32x4, hi));
+    h2_st16(wt, base, (unsigned)(t * H2_RG + 1024) + lo_off, __builtin_bit_cast(u32x4, lo));
+}
+// the 4 values (8 bytes per part) a lane contributes to the shared tail k-tile
+__device__ __forceinline__ void h2_emit_tail(bool wt, char* base, int t, unsigned lo_off, const float (&x)[8]) {
+    f16x8 hi, lo;
+    split2(x, hi, lo);
+    const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
+    h2_st8(wt, base, (unsigned)(t * H2_RG) + lo_off, u32x2{h[0], h[1]});
+    h2_st8(wt, base, (unsigned)(t * H2_RG + 1024) + lo_off, u32x2{l[0], l[1]});
+}
+
+// Attention.forward :55-64 on the q | k | v tile T[64][H2_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
+// channels, generic form (any n_tok <= 32, any head width that divides 136): S whole sequences of nt tokens; the output
+// is written as packed A2 of width Dq (scaled by osc) for proj.  The 4-token shapes never come here (registers).
+__device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C2, int tile_m,
+                                             int g_out, int Dq, float osc) {
+    const int hd4 = hd >> 2;
+    const int HP = BN / hd, nn = nt * nt;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int t = tid; t < S * HP * nn; t += 512) {
+        const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
+        const float* q = T + (sq * nt + i) * H2_ATT_TS + hh * hd;
+        const float* k = T + (sq * nt + j) * H2_ATT_TS + BN + hh * hd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int e = 0; e < hd4; ++e) {
+            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
+            s0 = fmaf(a.x, b.x, s0);
+            s1 = fmaf(a.y, b.y, s1);
+            s2 = fmaf(a.z, b.z, s2);
+            s3 = fmaf(a.w, b.w, s3);
+        }
+        SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
+    }
+    __syncthreads();
+    for (int t = tid; t < S * HP * nt; t += 512) {
+        float* pr = SC + t * nt;
+        float mx = pr[0];
+        for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
+        float l = 0.f;
+        for (int j = 0; j < nt; ++j) {
+            const float e = __expf(pr[j] - mx);
+            pr[j] = e;
+            l += e;
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < nt; ++j) pr[j] *= inv;
+    }
+    __syncthreads();
+    const int Go = Dq / BN;
+    const int strip = (Dq / BK) * H2_RG;                         // bytes of one row group of the output operand
+    char* cbase = C2 + (size_t)tile_m * 4 * strip;
+    auto pv4 = [&](int row, int c) -> float4 {
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+        if (row < S * nt) {
+            const int sq = row / nt, i = row - sq * nt;
+            const int hh = c / hd;
+            const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
+            const float* v = T + (sq * nt) * H2_ATT_TS + 2 * BN + c;
+            for (int j = 0; j < nt; ++j) {
+                const float4 vv = ld4(v + j * H2_ATT_TS);
+                const float pj = pr[j];
+                o.x = fmaf(pj, vv.x, o.x);
+                o.y = fmaf(pj, vv.y, o.y);
+                o.z = fmaf(pj, vv.z, o.z);
+                o.w = fmaf(pj, vv.w, o.w);
+            }
+        }
+        return o;
+    };
+    for (int t = tid; t < BM * 16; t += 512) {
+        const int li = t & 15, kq = (t >> 4) & 3, rg = (t >> 6) & 3, p = t >> 8;
+        const int row = rg * 16 + li;
+        const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
+        const float x[8] = {a.x * osc, a.y * osc, a.z * osc, a.w * osc, b.x * osc, b.y * osc, b.z * osc, b.w * osc};
+        h2_emit_frag(WT, cbase, 4 * g_out + p, (unsigned)(rg * strip + (kq * 16 + li) * 16), x);
+    }
+    for (int t = tid; t < BM * 2; t += 512) {
+        const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
+        const int row = rg * 16 + li;
+        const float4 a = pv4(row, 128 + 4 * kq);
+        const float x[8] = {a.x * osc, a.y * osc, a.z * osc, a.w * osc, 0.f, 0.f, 0.f, 0.f};
+        h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(rg * strip + ((g_out & 3) * 16 + li) * 16 + kq * 8), x);
+    }
+}
+
+// One GEMM of one workgroup tile (tm, tn): everything a wave does for its NTW slots starting at slot `slot0`.
+// CHAIN = false: the GEMM is a launch of its own.  CHAIN = true: one phase of h2_stack_kernel (see there): `chain` counts
+// the arrivals of the team, the A operand (and the LayerNorm partials) may be read once it reaches `chain_need`, and this
+// workgroup arrives when its outputs are written.  Returns false when the wait timed out (error words set, nothing computed).
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
+__device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
+                                         unsigned* chain, unsigned chain_need) {
+    constexpr int NST = H2_NST;
+    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF, convert) the A pieces
+    constexpr bool WT = CHAIN;
+    const int lane = tid & 63;
+    const int rg = wave & 3;
+    const int li = lane & 15, kq = lane >> 4;
+    const int M = a.M, N = a.N, K = a.K;
+    const int m0 = tm * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
+    const int Dq = N / 3;
+    const int KT = K / BK, G = K / BN;
+    const int T = NPASS * KT;                    // stages: stage u carries W of pass u % NPASS, and A when that pass is 0
+    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
+    const unsigned long long t_entry = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
+
+    const int row_l = rg * 16 + li;
+    const bool row_ok = row_l < a.rpt && m0 + row_l < M;
+    const int row = row_ok ? m0 + row_l : (M - 1);
+
+    // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
+    // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.
+    const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
+    const int w_cnt = HAS_A ? 1 : (wave < 6 ? 4 : 3);
+    unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
+    // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
+    // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
+    unsigned voA = (unsigned)(lane * 16);
+    unsigned voT = 0;
+    if (LNF) {
+        voA = (unsigned)(((size_t)(row - m0) * a.ldx + 4 * kq) * 4);
+        voT = (unsigned)(((size_t)(row - m0) * a.ldx + 136 * kq + 128) * 4);
+    }
+    asm volatile("" : "+v"(voA), "+v"(voW), "+v"(voT));
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    int iw_t = 0, iw_g = 0, ia_t = 0, ia_kt = 0;
+    unsigned iw_slot = 0, ia_slot = 0;
+    const char* is_w[NPASS];
+#pragma unroll
+    for (int g = 0; g < NPASS; ++g) is_w[g] = a.W2 + (size_t)(colbase(g) / BN) * KT * H2_W;
+    const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
+                           : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
+    auto w_pieces = [&](const char* src, unsigned dst) {
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1"
+            :
+            : "v"(voW), "s"(src), "s"(dst)
+            : "memory");
+        if (w_cnt > 1) {
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voW), "s"(src) : "memory");
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
+        }
+        if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
+    };
+    // the two A pieces of this wave's row group for A k-tile ia_kt into stage slot `slot` (waves 0..3; M0 is the caller's)
+    auto a_pieces = [&](unsigned slot) {
+        const unsigned dst = lds0 + slot + (unsigned)(wave * H2_RG);
+        if (!LNF) {
+            if (CHAIN)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 sc1"
+                             : : "v"(voA), "s"(is_a), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                             : : "v"(voA), "s"(is_a), "s"(dst) : "memory");
+            is_a += H2_RG;
+        } else {
+            // raw fp32: the lane's columns j = 0..3 land in the first KiB (where the hi fragment will be), j = 4..7 in the second;
+            // the instruction offset would move BOTH addresses, so the second piece gets its own source base and M0
+            const bool full = ia_kt < 4 * G;
+            const char* src = full ? is_a + (size_t)(136 * (ia_kt >> 2) + 32 * (ia_kt & 3)) * 4 : is_a + (size_t)(136 * 4 * (ia_kt - 4 * G)) * 4;
+            const char* src2 = src + (full ? 64 : 16);
+            const unsigned vo = full ? voA : voT;
+            if (CHAIN)
+                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1"
+                             : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                             : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
+        }
+        ++ia_kt;
+    };
+    auto issue_w = [&]() {
+        const unsigned keep = dma_m0_save();
+#pragma unroll
+        for (int g = 0; g < NPASS; ++g)
+            if (g == iw_g) {
+                w_pieces(is_w[g], lds0 + iw_slot + (unsigned)(H2_A + w_first * 1024));
+                is_w[g] += H2_W;
+            }
+        if (++iw_g == NPASS) iw_g = 0;
+        dma_m0_restore(keep);
+        ++iw_t;
+        iw_slot += H2_STAGE;
+        if (iw_slot == NST * H2_STAGE) iw_slot = 0;
+    };
+    auto issue_a = [&]() {
+        if ((ia_t % NPASS) == 0 && HAS_A) {
+            const unsigned keep = dma_m0_save();
+            a_pieces(ia_slot);
+            dma_m0_restore(keep);
+        }
+        ++ia_t;
+        ia_slot += H2_STAGE;
+        if (ia_slot == NST * H2_STAGE) ia_slot = 0;
+    };
+    // steady state: stage t + NST lives where stage t lived; NST is a multiple of NPASS, so the refilled stage has the pass of
+    // the current one (compile-time at the call site) and carries A exactly when the current one did
+    auto refill_fast = [&](auto wp_c, auto ai_c, unsigned slot) {
+        constexpr int g = decltype(wp_c)::value;
+        constexpr bool with_a = decltype(ai_c)::value;
+        const unsigned keep = dma_m0_save();
+        w_pieces(is_w[g], lds0 + slot + (unsigned)(H2_A + w_first * 1024));
+        is_w[g] += H2_W;
+        if (with_a && HAS_A) a_pieces(slot);
+        dma_m0_restore(keep);
+    };
+    auto resync = [&](int t_next, unsigned slot) {
+        iw_t = ia_t = t_next + NST;
+        iw_g = iw_t % NPASS;
+        iw_slot = ia_slot = slot;
+    };
+    static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
+
+    // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue)
+    if (HAS_A) {
+        constexpr int NV = NPASS * 2 * (BN / 4);                   // float4s: [pass][c | sc][34]
+        int idx = wave * 64 + lane;
+        const bool on = idx < NV;
+        idx = on ? idx : 0;
+        const int vp = idx / (2 * (BN / 4)), which = (idx / (BN / 4)) & 1, c4 = idx % (BN / 4);
+        const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
+        if (on) dma16(src, lds0 + (unsigned)(H2_VEC + wave * 1024));
+    }
+    // ---- prologue.  Chain mode: W(0) does not depend on the other workgroups and is requested BEFORE the wait for them;
+    // the poll is the job of wave 7 (lane 0), its first look goes out before any DMA piece of the wave.
+    bool arrived = !CHAIN;
+    if (CHAIN && !HAS_A && wave == 7)
+        arrived = __hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need;
+    issue_w();
+    if (CHAIN) {
+        if (!HAS_A && wave == 7 && !arrived) {
+            const unsigned lim = 1u << a.spin_log2;
+            unsigned spin = 0;
+            for (; spin < lim; ++spin) {
+                if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (spin == lim && lane == 0) {     // a lost partner is an ERROR, never a licence to go on (x3_gemm.hip)
+                *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 1u;
+                if (a.err_ws) __hip_atomic_store(a.err_ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.err_host) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (*reinterpret_cast<volatile unsigned*>(smem + H2_FAIL)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return false;
+        }
+    }
+    issue_a();
+    // LNF: the row statistics (slice partials {mean, M2} written by the producers of x) of this wave's 16 rows, requested
+    // right behind A(0).  NPASS >= 2: by LDS-DMA (L1-bypassing in chain mode) into the A region of stage slot 1, which a
+    // pass-1 stage never uses -- an ordinary load here would make the compiler drain the WHOLE queue (it cannot see the
+    // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
+    constexpr unsigned ST_LDS = H2_STAGE;
+    float4 st_raw[4];
+    if (LNF && HAS_A) {
+        const int ns = K / BN;
+        if constexpr (NPASS >= 2) {
+            // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
+            const int hpr = ns >> 1;
+            if (lane < 16 * hpr) {
+                int r = m0 + 16 * wave + lane / hpr;
+                r = r < M ? r : M - 1;
+                const float* g = a.stats + ((size_t)r * ns + 2 * (lane % hpr)) * 2;
+                unsigned keep;
+                if (CHAIN)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024)) : "memory");
+                else
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024)) : "memory");
+            }
+        } else {
+            const float* sp = a.stats + (size_t)row * ns * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sp + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int t = 1; t < NST; ++t) {
+        issue_w();
+        issue_a();
+    }
+    const float ainv = (!LNF && a.a_inv) ? a.a_inv[0] : 1.0f;
+    const float osc = a.o_scale ? a.o_scale[0] : 1.0f;
+
+    // residual of this lane's outputs (fp32 rows this workgroup wrote itself two phases ago, or a previous launch wrote)
+    float4 rv[NTW];
+    auto epilogue_operands = [&]() {
+        if (EPI == H2_EPI_RES) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                int c = 16 * h2_slot_tile(slot0 + n) + 4 * kq;
+                c = c + 3 < BN ? c : 0;
+                const float* rp = a.R + (size_t)row * a.ldr + n0 + c;
+                if (CHAIN) rv[n] = __builtin_bit_cast(float4, h2_ld16_l2(a.R + (size_t)m0 * a.ldr, (unsigned)((size_t)(rp - (a.R + (size_t)m0 * a.ldr)) * 4)));
+                else rv[n] = ld4(rp);
+            }
+        }
+    };
+    const int t_ops = T - 4;                    // always a generic stage (the fast ones end before T - NST)
+
+    f32x4 acc[NPASS][NTW];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- LNF: normalise + split the raw fp32 A pieces of a stage IN PLACE (waves 0..3, each its own row group: the wave
+    // that requested the bytes waits for them with its own vmcnt, no other wave touches them before the next barrier)
+    float cv_a = 0.f, cv_b = 0.f;               // z = x cv_a + cv_b = (x - mean) rstd 2^10
+    auto convert = [&](unsigned slot) {
+        if (H2_ABL & 16) return;
+        char* p = smem + slot + wave * H2_RG + lane * 16;
+        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 1024);
+        float z[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            z[j] = fmaf(z[j], cv_a, cv_b);
+            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
+            if (!row_ok) z[j] = 0.f;
+        }
+        f16x8 hi, lo;
+        split2(z, hi, lo);
+        *reinterpret_cast<f16x8*>(p) = hi;
+        *reinterpret_cast<f16x8*>(p + 1024) = lo;
+    };
+
+    f16x8 A0[2], A1[2];
+    f16x8 B0[NTW][2], B1[NTW][2];
+    auto read_a = [&](unsigned slot, f16x8 (&f)[2]) {
+        const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + rg * H2_RG) + lane;
+        f[0] = as[0];
+        f[1] = as[64];
+    };
+    auto read_b = [&](unsigned slot, f16x8 (&f)[NTW][2]) {
+        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot + H2_A) + slot0 * 2 * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            f[n][0] = bs[(n * 2 + 0) * 64];
+            f[n][1] = bs[(n * 2 + 1) * 64];
+        }
+    };
+    auto slot_after = [](unsigned sl) -> unsigned { return sl + H2_STAGE == NST * H2_STAGE ? 0u : sl + H2_STAGE; };
+    // Three products, fixed order (A part . W part): lo.hi, hi.lo, hi.hi, each over the wave's NTW tiles.  The W fragment is
+    // the FIRST MFMA operand: lane (i, kq) then holds C[row i][4 consecutive columns 16 tile + 4 kq ..].
+    auto mfma_row = [&](f32x4 (&accp)[NTW], const f16x8& af, const f16x8 (&bf)[NTW][2], int bp) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+            if (!(H2_ABL & 8)) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[n][bp], af, accp[n], 0, 0, 0);
+    };
+    // counted waits.  Per stage a wave of the waves 4..7 requests w_cnt (4 or 3) pieces, a wave 0..3 one W piece plus two A
+    // pieces in the A stages (every NPASS-th).  Stages t+1 (.. t+5) are in flight when stage t starts; the waves 4..7 need
+    // their pieces of stage t+1, the waves 0..3 of stage t+2 when they convert it during stage t (LNF) else of stage t+1.
+    // Smallest number of pieces of this wave in the stages that may stay in flight:
+    constexpr int A_ALLOW = LNF ? (NPASS == 1 ? 9 : 5) : (NPASS == 1 ? 12 : (NPASS == 2 ? 8 : 6));
+    {   // stage 0 (LNF: and what the prologue converts) landed
+        if (HAS_A) {
+            constexpr int LATER = LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
+            if (LNF) {
+                // Chan's combination of the per-slice {mean, M2} partials (fixed order)
+                const int ns = K / BN;
+                if constexpr (NPASS >= 2) {
+                    const float* sl = reinterpret_cast<const float*>(smem + ST_LDS + wave * 1024) + li * ns * 2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sl + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+                }
+                float st[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st[4 * i] = st_raw[i].x; st[4 * i + 1] = st_raw[i].y; st[4 * i + 2] = st_raw[i].z; st[4 * i + 3] = st_raw[i].w;
+                }
+                float msum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) msum += (i < ns) ? st[2 * i] : 0.f;
+                const float mean = msum / (float)ns;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = st[2 * i] - mean;
+                    m2 += (i < ns) ? fmaf((float)BN * d, d, st[2 * i + 1]) : 0.f;
+                }
+                const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
+                cv_a = rs * H2_SA;
+                cv_b = -mean * cv_a;
+                convert(0);
+                if (NPASS == 1) convert(H2_STAGE);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            if (w_cnt == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_a(0, A0);
+        read_b(0, B0);
+    }
+    const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_vm = 0, t_bar = 0;
+    unsigned slot_c = 0;
+    // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage t
+    // with the fragment reads of stage t+1 -- and, waves 0..3 of a LayerNorm GEMM, the in-place conversion of the A pieces
+    // of stage t+2 (CV) -- in between.  FAST: a stage of the steady state (t + NST < T).
+    auto stage = [&](auto fast_c, auto wp_c, auto ai_c, auto cv_c, int t, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
+                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        const unsigned slot_n = slot_after(slot_c);
+        const bool more = FAST || t + 1 < T;
+        const bool cv = LNF && HAS_A && (FAST ? decltype(cv_c)::value : (t + 2 < T && (t + 2) % NPASS == 0));
+        unsigned long long w0 = 0, w1 = 0;
+        if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
+        if (more) {
+            if (FAST) {
+                if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
+                else if (w_cnt == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                // tail: every stage < T has been requested; conservative counts from the pieces per stage of this wave
+                const int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
+                const int per = HAS_A ? (NPASS == 1 ? 3 : 1) : w_cnt;
+                wait_vm(later > 0 ? later * per : 0);
+            }
+            if (H2_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (H2_DBG && a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
+        }
+        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot_n + H2_A) + slot0 * 2 * 64 + lane;
+        auto rd_b = [&](int n) {
+            if (more && n < NTW && !(H2_ABL & 1)) {
+                b_nxt[n][0] = bs[(n * 2 + 0) * 64];
+                b_nxt[n][1] = bs[(n * 2 + 1) * 64];
+            }
+        };
+        auto refill = [&]() {
+            if constexpr (FAST) {
+                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, slot_c);
+            } else {
+                if (more && iw_t < T && !((H2_ABL & 2) && t > 0)) {
+                    issue_w();
+                    issue_a();
+                }
+                if (t == t_ops) epilogue_operands();
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[1], b_cur, 0);             // lo . hi
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(H2_STAGGER && !HAS_A)) refill();
+        if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+        rd_b(0);
+        if (!next_has_a) rd_b(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[0], b_cur, 1);             // hi . lo
+        __builtin_amdgcn_sched_barrier(0);
+        if (next_has_a) rd_b(1);
+        rd_b(2);
+        if (H2_STAGGER && !HAS_A) refill();
+        if (cv) convert(slot_after(slot_n));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(accp, a_cur[0], b_cur, 0);             // hi . hi
+        __builtin_amdgcn_sched_barrier(0);
+        rd_b(3);
+        rd_b(4);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_c = slot_n;
+    };
+    using GEN = std::integral_constant<bool, false>;
+    using FST = std::integral_constant<bool, true>;
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using AY = std::integral_constant<bool, true>;
+    using AN = std::integral_constant<bool, false>;
+    using CY = std::integral_constant<bool, true>;
+    using CN = std::integral_constant<bool, false>;
+    // head -> steady state (fast) -> tail (generic).  Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of
+    // stage t + 2 when (j + 2) % NPASS == 0.
+    if constexpr (NPASS == 1) {
+        int kt = 0;
+        for (; kt + 1 + NST < T; kt += 2) {
+            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+        }
+        resync(kt, slot_c);
+        for (; kt + 1 < KT; kt += 2) {
+            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
+    } else if constexpr (NPASS == 2) {
+        int kt = 0;
+        for (; 2 * kt + 3 + NST < T; kt += 2) {
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+        }
+        resync(2 * kt, slot_c);
+        for (; kt + 1 < KT; kt += 2) {
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) {
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+        }
+    } else {
+        // three stages per k-tile flip the B parity every k-tile
+        int kt = 0;
+        for (; 3 * kt + 5 + NST < T; kt += 2) {
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+        }
+        resync(3 * kt, slot_c);
+        for (; kt + 1 < KT; kt += 2) {
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+        }
+        if (kt < KT) {
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ epilogue
+    const unsigned long long t_epi = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
+    // acc[p][n][r] = scaled C[row_l][colbase(p) + 16 tile(n) + 4 kq + r];   value = acc * sc_n (* 1 / a_scale) + c_n
+    auto tile_of = [&](int n) -> int { return h2_slot_tile(slot0 + n); };
+    auto value4 = [&](int p, int n, float (&v)[4]) {
+        const int cl = 16 * tile_of(n) + 4 * kq;
+        const bool ok = cl + 3 < BN;
+        const float* vecs = reinterpret_cast<const float*>(smem + H2_VEC) + p * 2 * BN + (ok ? cl : 0);
+        const float4 cv = ld4(vecs), sv = ld4(vecs + BN);
+        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+        const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // explicit fused operations: the same roundings in every instantiation (chain phases and one-GEMM launches agree
+            // bitwise); sc_n, 1 / a_scale are powers of two: their product is exact
+            float t = fmaf(acc[p][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
+            if (EPI == H2_EPI_GELU) t = gelu_as(t);
+            v[r] = ok ? t : 0.f;
+        }
+    };
+    unsigned long long t_st = 0;
+
+    if constexpr (EPI == H2_EPI_ATT) {
+      if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
+        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS (x3_gemm.hip): a
+        // sequence is the 4 lanes of a quad, k_j / v_j come by DPP quad broadcast, the q.k sums are reduced over the tiles of
+        // the wave, the 4 kq lanes and -- through 2 KiB of LDS -- the two waves of the row group.
+        float qv[NTW][4], kv[NTW][4], vv[NTW][4];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            value4(0, n, qv[n]);
+            value4(1, n, kv[n]);
+            value4(2, n, vv[n]);
+        }
+        auto quad = [](float x, int j) -> float {
+            const int xi = __builtin_bit_cast(int, x);
+            int r;
+            switch (j) {
+                case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
+                case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
+                case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
+                default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
+            }
+            return __builtin_bit_cast(float, r);
+        };
+        const bool two_heads = a.att_hd == 68;
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d = qv[n][0] * quad(kv[n][0], j);
+                d = fmaf(qv[n][1], quad(kv[n][1], j), d);
+                d = fmaf(qv[n][2], quad(kv[n][2], j), d);
+                d = fmaf(qv[n][3], quad(kv[n][3], j), d);
+                s0[j] += h1 ? 0.f : d;
+                s1[j] += h1 ? d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
+            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+        }
+        float* xs = reinterpret_cast<float*>(smem);        // [2 halves][64 rows][8]
+        const int half = slot0 ? 1 : 0;
+        __syncthreads();                                    // every wave is done reading the last stage
+        if (kq == 0) {
+            st4(xs + (half * BM + row_l) * 8, float4{s0[0], s0[1], s0[2], s0[3]});
+            st4(xs + (half * BM + row_l) * 8 + 4, float4{s1[0], s1[1], s1[2], s1[3]});
+        }
+        __syncthreads();
+        float p0[4], p1[4];
+        {
+            const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
+            const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
+            const float scale = 1.0f / sqrtf((float)a.att_hd);
+            const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
+            const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
+            auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
+                const float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+                const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
+                const float inv = 1.0f / ((e0 + e1) + (e2 + e3));
+                pr[0] = e0 * inv; pr[1] = e1 * inv; pr[2] = e2 * inv; pr[3] = e3 * inv;
+            };
+            softmax4(t0, p0);
+            softmax4(t1, p1);
+        }
+        float ov[NTW][4];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+            const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float o = pj[0] * quad(vv[n][c], 0);
+                o = fmaf(pj[1], quad(vv[n][c], 1), o);
+                o = fmaf(pj[2], quad(vv[n][c], 2), o);
+                o = fmaf(pj[3], quad(vv[n][c], 3), o);
+                ov[n][c] = o * osc;
+            }
+        }
+        const int Go = Dq / BN, g_out = n0 / BN;
+        char* cbase = a.C2 + ((size_t)tm * 4 + rg) * (Dq / BK) * H2_RG;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x[8] = {ov[2 * q][0], ov[2 * q][1], ov[2 * q][2], ov[2 * q][3],
+                                ov[2 * q + 1][0], ov[2 * q + 1][1], ov[2 * q + 1][2], ov[2 * q + 1][3]};
+            h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
+        }
+        if (NTW == H2_T0 && kq < 2) {
+            const float x[8] = {ov[NTW - 1][0], ov[NTW - 1][1], ov[NTW - 1][2], ov[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
+            h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
+        }
+      } else {
+        float* Tt = reinterpret_cast<float*>(smem);
+        float* SC = Tt + BM * H2_ATT_TS;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int cl = 16 * tile_of(n) + 4 * kq;
+                if (cl + 3 < BN) {
+                    float v[4];
+                    value4(p, n, v);
+                    st4(Tt + row_l * H2_ATT_TS + p * BN + cl, float4{v[0], v[1], v[2], v[3]});
+                }
+            }
+        __syncthreads();
+        h2_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm, n0 / BN, Dq, osc);
+      }
+    } else {
+        const int Go = N / BN;
+        char* cbase = a.C2 + ((size_t)tm * 4 + rg) * (N / BK) * H2_RG;
+        float vals[NTW][4];
+#pragma unroll
+        for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
+            const int g_out = colbase(p) / BN;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                value4(p, n, vals[n]);
+                const int cl = 16 * tile_of(n) + 4 * kq;
+                const bool ok = cl + 3 < BN;
+                if (EPI == H2_EPI_RES) {
+                    vals[n][0] += rv[n].x; vals[n][1] += rv[n].y; vals[n][2] += rv[n].z; vals[n][3] += rv[n].w;
+                    if (!ok) vals[n][0] = vals[n][1] = vals[n][2] = vals[n][3] = 0.f;
+                }
+                if (a.C && ok && row_ok) {
+                    // fp32 rows: in chain mode the WHOLE team reads them (LayerNorm GEMM of the next phase): write-through
+                    const float4 o4 = {vals[n][0], vals[n][1], vals[n][2], vals[n][3]};
+                    h2_st16(WT, a.C + (size_t)m0 * a.ldc, (unsigned)(((size_t)(row - m0) * a.ldc + colbase(p) + cl) * 4),
+                            __builtin_bit_cast(u32x4, o4));
+                }
+            }
+            if (a.C2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float x[8] = {vals[2 * q][0] * osc, vals[2 * q][1] * osc, vals[2 * q][2] * osc, vals[2 * q][3] * osc,
+                                        vals[2 * q + 1][0] * osc, vals[2 * q + 1][1] * osc, vals[2 * q + 1][2] * osc, vals[2 * q + 1][3] * osc};
+                    h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
+                }
+                if (NTW == H2_T0 && kq < 2) {
+                    const float x[8] = {vals[NTW - 1][0] * osc, vals[NTW - 1][1] * osc, vals[NTW - 1][2] * osc, vals[NTW - 1][3] * osc, 0.f, 0.f, 0.f, 0.f};
+                    h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
+                }
+            }
+        }
+        if (H2_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
+        if constexpr (EPI == H2_EPI_RES) {
+            if (a.stats_out) {
+                // LayerNorm partials {mean, M2} of the 136-column slice of each row (x3_gemm.hip): two exchanges through LDS
+                float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][64 rows]
+                const int half = slot0 ? 1 : 0;
+                float sum = 0.f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) sum += (vals[n][0] + vals[n][1]) + (vals[n][2] + vals[n][3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                __syncthreads();
+                if (kq == 0) xch[half * 64 + row_l] = sum;
+                __syncthreads();
+                const float mean = (xch[row_l] + xch[64 + row_l]) * (1.0f / (float)BN);
+                float q = 0.f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    const bool ok = 16 * tile_of(n) + 4 * kq + 3 < BN;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = vals[n][r] - mean;
+                        q = ok ? fmaf(d, d, q) : q;
+                    }
+                }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (kq == 0) xch[128 + half * 64 + row_l] = q;
+                __syncthreads();
+                if (half == 0 && kq == 0 && row_ok) {
+                    const u32x2 h = {__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, xch[128 + row_l] + xch[192 + row_l])};
+                    h2_st8(WT, a.stats_out + (size_t)m0 * Go * 2, (unsigned)(((row - m0) * Go + n0 / BN) * 8), h);
+                }
+            }
+        }
+    }
+    if (CHAIN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (H2_DBG && a.dbg) {
+        if (!t_st) t_st = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
+            o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar;
+        }
+    }
+    return true;
+}
+
+template <int EPI, bool LNF, int NPASS>
+__global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    {
+        const int b = blockIdx.x;
+        if ((a.grid_m & 7) == 0) {
+            const int per = a.grid_m >> 3;
+            const int xcd = b & 7, i = b >> 3;
+            tm = xcd * per + (i % per);
+            tn = i / per;
+        } else {
+            tm = b % a.grid_m;
+            tn = b / a.grid_m;
+        }
+    }
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------- whole block stack
+// ONE launch for all Block applications of a stack (the team protocol of x3_stack_kernel): G = D / 136 workgroups form a
+// team that walks one row tile through every GEMM of every application, synchronising only among themselves through a
+// monotonic arrival counter per row tile.
+struct H2StackArgs {
+    char *att2, *hid2;
+    float *x, *stats;
+    unsigned* counters;          // one per row tile (+ the error word), zeroed before the launch
+    int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
+    float eps;
+    unsigned long long* dbg;
+    unsigned *err_ws, *err_host;
+    int spin_log2;
+    int inject;
+    const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
+};
+
+__global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int G = s.G, D = s.D;
+    int team, tn;
+    {
+        const int b = blockIdx.x;
+        team = (b & 7) + 8 * ((b >> 3) / G);
+        tn = (b >> 3) % G;
+        if (team >= s.n_teams) return;
+    }
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    __syncthreads();
+    auto vecs = [&](const char* w2, int N, int K) -> const float* {
+        return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
+    };
+    for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
+        unsigned need = 0;
+        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            int tidp = tid, tile = tile0, tnp = tn;
+            asm volatile("" : "+v"(tidp));
+            asm volatile("" : "+s"(tile), "+s"(tnp));
+            const int wv = __builtin_amdgcn_readfirstlane(tidp >> 6);
+            unsigned* ctr = s.counters + tile;
+            const char* const* w = s.w[ph >> 2];
+            bool ok = true;
+            if (s.inject > 0 && ph == s.inject && tile == 0 && tnp == 0) return;     // fault injection (test hook)
+            switch (ph & 3) {
+                case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
+                    const float* v = vecs(w[0], 3 * D, D);
+                    const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
+                                   nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
+                                   s.spin_log2};
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    break;
+                }
+                case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
+                    const float* v = vecs(w[2], 2 * D, D);
+                    const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
+                                   nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    break;
+                }
+                default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
+                    const bool fc2 = (ph & 3) == 3;
+                    const int K = fc2 ? 2 * D : D;
+                    const char* w2 = fc2 ? w[3] : w[1];
+                    const float* v = vecs(w2, D, K);
+                    // reciprocal of the scale the producer packed the operand with: meta[3] (v columns) of qkv / meta[2] of fc1
+                    const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
+                    const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
+                                   s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    break;
+                }
+            }
+            if (!ok) return;
+        }
+    }
+}
+
+template <int EPI, bool LNF, int NPASS>
+static int launch_h2(const H2Args& a, hipStream_t s) {
+    constexpr int LDS = H2_LDS_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)h2_gemm_kernel<EPI, LNF, NPASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return MPL_E_LAUNCH;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL((h2_gemm_kernel<EPI, LNF, NPASS>), dim3(a.grid_m * a.grid_n), dim3(512), LDS, s, a);
+    return hip_check_launch();
+}
+
+// One GEMM as a launch of its own.  ln: A = fp32 rows X (ld = K) normalised with `stats`; else A = packed A2 whose scale
+// reciprocal sits at a_inv (device).  Outputs: C fp32 (optional) and / or C2 packed with the device scalar o_scale.
+int launch_h2_gemm(const float* X, const unsigned short* A2, const float* a_inv, const unsigned short* W2, bool ln, const float* stats,
+                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, const float* o_scale, float* stats_out,
+                   int M, int N, int K, int rpt, int epi, hipStream_t s) {
+    if (M <= 0 || !W2 || (!C && !C2) || !h2_shape_ok(N, K) || rpt <= 0 || rpt > BM) return MPL_E_INVALID;
+    if (ln ? (!X || !stats || K > 2048) : !A2) return MPL_E_INVALID;
+    if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
+    if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
+    if (C2 && (N % (4 * BN) || !o_scale)) return MPL_E_INVALID;
+    const char* w2 = reinterpret_cast<const char*>(W2);
+    const float* vec = reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
+    H2Args a{reinterpret_cast<const char*>(A2), X, K, w2, vec, vec + N, stats, a_inv, o_scale, R, ldr, C, ldc, reinterpret_cast<char*>(C2),
+             stats_out, M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_h2_dbg.load(), nullptr, nullptr, 0};
+    const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0;     // by the SHAPE only (batch invariance)
+    if (pair) a.grid_n /= 2;
+    switch (epi) {
+        case MPL_EPI_BIAS:
+            if (pair) return ln ? launch_h2<H2_EPI_BIAS, true, 2>(a, s) : launch_h2<H2_EPI_BIAS, false, 2>(a, s);
+            return ln ? launch_h2<H2_EPI_BIAS, true, 1>(a, s) : launch_h2<H2_EPI_BIAS, false, 1>(a, s);
+        case MPL_EPI_BIAS_GELU:
+            if (pair) return ln ? launch_h2<H2_EPI_GELU, true, 2>(a, s) : launch_h2<H2_EPI_GELU, false, 2>(a, s);
+            return ln ? launch_h2<H2_EPI_GELU, true, 1>(a, s) : launch_h2<H2_EPI_GELU, false, 1>(a, s);
+        case MPL_EPI_BIAS_RESIDUAL:
+            return ln ? launch_h2<H2_EPI_RES, true, 1>(a, s) : launch_h2<H2_EPI_RES, false, 1>(a, s);
+        default:
+            return MPL_E_INVALID;
+    }
+}
+
+// LN1 + qkv projection + softmax attention in one launch: att2 (packed, width D, scaled by meta[1] of W2) from fp32 rows
+int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const float* stats, float eps, int M, int D, int n_tok,
+                            int heads, unsigned short* att2, hipStream_t s) {
+    if (!h2_attention_fusable(n_tok, D, heads) || !X || !W2 || !stats || !att2 || M <= 0 || M % n_tok) return MPL_E_INVALID;
+    const int N = 3 * D, rpt = h2_rows_per_tile(n_tok);
+    const char* w2 = reinterpret_cast<const char*>(W2);
+    const float* vec = reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (D / BK) * H2_W);
+    H2Args a{nullptr, X, D, w2, vec, vec + N, stats, nullptr, vec + 4 * N + 1, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att2),
+             nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_h2_dbg.load(), nullptr, nullptr, 0};
+    return launch_h2<H2_EPI_ATT, true, 3>(a, s);
+}
+
+// The whole block stack in one launch.  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands; counters: n_tiles arrival
+// counters + 1 error word, zeroed by the caller (launch_h2_entry).
+int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
+                    unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
+                    hipStream_t s) {
+    if (!x || !ops || !att2 || !hid2 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
+        !h2_attention_fusable(n_tok, D, heads) || !h2_shape_ok(D, 2 * D) || M % n_tok)
+        return MPL_E_INVALID;
+    static std::atomic<int> resident[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
+    if (!resident[dev].load(std::memory_order_acquire)) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+        if (hipFuncSetAttribute((const void*)h2_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
+            return MPL_E_LAUNCH;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h2_stack_kernel, 512, H2_LDS_BYTES) != hipSuccess || per_cu < 1)
+            return MPL_E_UNSUPPORTED;
+        resident[dev].store(cus, std::memory_order_release);
+    }
+    H2StackArgs a;
+    a.att2 = reinterpret_cast<char*>(att2);
+    a.hid2 = reinterpret_cast<char*>(hid2);
+    a.x = x;
+    a.stats = stats;
+    a.counters = counters;
+    a.M = M; a.D = D; a.n_tok = n_tok; a.heads = heads;
+    a.rpt = h2_rows_per_tile(n_tok);
+    a.n_tiles = (M + a.rpt - 1) / a.rpt;
+    a.G = D / BN;
+    const int cap = resident[dev].load() / a.G;
+    if (cap < 1) return MPL_E_UNSUPPORTED;
+    a.n_teams = a.n_tiles < cap ? a.n_tiles : cap;
+    if (a.n_teams * a.G > H2_MAX_WGS) a.n_teams = H2_MAX_WGS / a.G;
+    a.n_apps = n_apps;
+    a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
+    a.eps = eps;
+    a.dbg = g_h2_dbg.load();
+    a.err_ws = counters + a.n_tiles;
+    a.err_host = device_error_word(dev);
+    a.spin_log2 = g_h2_spin_log2.load();
+    a.inject = g_h2_inject.load();
+    for (int i = 0; i < n_apps; ++i)
+        for (int j = 0; j < 4; ++j) {
+            if (!ops[4 * i + j]) return MPL_E_INVALID;
+            a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
+        }
+    // the library serialises ITS OWN persistent launches per device (see x3_gemm.hip launch_stack_np)
+    hipEvent_t ev = stack_chain_event(dev);
+    if (!ev) return MPL_E_LAUNCH;
+    std::lock_guard<std::mutex> g(stack_chain_mutex(dev));
+    if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) return MPL_E_LAUNCH;
+    int rc;
+    {
+        ProfScope prof(MPL_K_GEMM, s);
+        hipLaunchKernelGGL(h2_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
+        rc = hip_check_launch();
+    }
+    if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;
+    return rc;
+}
+
+}  // namespace mpl

@@ -1383,21 +1383,17 @@ static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
     // stack launches per device: each one waits for the event recorded behind the previous one, whatever stream that was
     // on (a no-op on the same stream).  Other processes on the same GPU are not covered: single tenant;
     // a wait that runs out anyway is reported, never ignored (X3Args::err_*).
-    static std::mutex chain_mu[64];
-    static hipEvent_t chain_ev[64];
-    std::lock_guard<std::mutex> g(chain_mu[dev]);
-    if (!chain_ev[dev]) {
-        if (hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) return MPL_E_LAUNCH;
-    } else if (hipStreamWaitEvent(s, chain_ev[dev], 0) != hipSuccess) {
-        return MPL_E_LAUNCH;
-    }
+    hipEvent_t ev = stack_chain_event(dev);
+    if (!ev) return MPL_E_LAUNCH;
+    std::lock_guard<std::mutex> g(stack_chain_mutex(dev));
+    if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) return MPL_E_LAUNCH;
     int rc;
     {
         ProfScope prof(MPL_K_GEMM, s);
         hipLaunchKernelGGL(x3_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), LDS, s, a);
         rc = hip_check_launch();
     }
-    if (hipEventRecord(chain_ev[dev], s) != hipSuccess) return MPL_E_LAUNCH;
+    if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;
     return rc;
 }
 

@@ -243,31 +243,34 @@ class MultiView_MPL(nn.Module):
     def set_matmul_precision(self, precision: str):
         """Arithmetic of the FPT block GEMMs (everything else is fp32 always):
         "fp32" (default) -- fp32 in, fp32 out, fp32 accumulation; where the FPT width is a multiple of 136 (every
-            view-token model) the products are formed on the bf16 matrix cores from operands split exactly into three
-            bf16 terms (csrc/x3_gemm.hip: at least as accurate as an fp32 multiply, 2.7x less matrix-pipe time on
-            gfx950); other widths (KPTOK, D = 32) use the native fp32 MFMA kernels;
+            view-token model) the products are formed on the fp16 matrix cores from operands split into two fp16 terms under
+            exact power-of-two scales, three partial products per product (csrc/h2_gemm.hip: as accurate as an fp32 GEMM,
+            1/5 of its matrix-pipe time on gfx950); other widths (KPTOK, D = 32) use the native fp32 MFMA kernels;
+        "fp32x3" -- the round-2 engine: operands split exactly into three bf16 terms, six partial products
+            (csrc/x3_gemm.hip); slower than "fp32", kept as the reference point of the split-operand arithmetic;
         "fp32_mfma" -- native fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere;
-        "bf16" -- the same engine with ONE bf16 per operand element: operands rounded to bf16 (activations when a GEMM
+        "bf16" -- the x3 engine with ONE bf16 per operand element: operands rounded to bf16 (activations when a GEMM
             epilogue hands them to the next GEMM, weights with the LayerNorm gain folded in), exact products, fp32
             accumulation; statistics, softmax, GELU and the residual stream stay fp32: BASELINE.json configs[2].
-        The split / bf16 weight copies are derived data, rebuilt whenever a parameter's storage or version changes."""
-        if precision not in ("fp32", "fp32_mfma", "bf16"):
-            raise ValueError("matmul precision must be 'fp32', 'fp32_mfma' or 'bf16'")
-        if precision == "bf16" and not self._x3_supported():
-            raise NotImplementedError("the bf16 engine covers the view-token FPT blocks (widths 544 / 1088, up to 32 views)")
+        The packed weight copies are derived data, rebuilt whenever a parameter's storage or version changes."""
+        if precision not in ("fp32", "fp32x3", "fp32_mfma", "bf16"):
+            raise ValueError("matmul precision must be 'fp32', 'fp32x3', 'fp32_mfma' or 'bf16'")
+        if precision in ("bf16", "fp32x3") and not self._x3_supported():
+            raise NotImplementedError("the %s engine covers the view-token FPT blocks (widths 544 / 1088, up to 32 views)" % precision)
         self.matmul_precision = precision
         self._hip_cache = {}
         return self
 
     def _x3_supported(self) -> bool:
-        """The split-operand engine needs every FPT Linear shape to have a split layout (out features a multiple of 136,
-        in features of 544: widths 544 and 1088, i.e. every view-token model at DIM 32; mpl_split_bf16x3_bytes decides)
-        and fuses the attention for up to 32 tokens per sequence."""
+        """The packed-operand engines (h2 / x3 / bf16) need every FPT Linear shape to have a packed layout (out features a
+        multiple of 136, in features of 544: widths 544 and 1088, i.e. every view-token model at DIM 32;
+        mpl_split_bf16x3_bytes / mpl_pack_h2_bytes decide) and fuse the attention for up to 32 tokens per sequence."""
         if self.no_transformer_fpt or len(self.blocks) == 0 or self.FPT_blocks_view_keypoint_tokens or self.num_views > 32:
             return False
         lib = cabi.load()
         b = self.blocks[0]
-        return all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0
+        return all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0 and
+                   lib.mpl_pack_h2_bytes(int(t.shape[0]), int(t.shape[1])) > 0
                    for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight))
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -350,11 +353,12 @@ class MultiView_MPL(nn.Module):
         plist = self._param_list()
         key = tuple(map(torch.Tensor.data_ptr, plist))
         bf16 = self.matmul_precision == "bf16" and not self._dp_replica and self._x3_supported()
-        x3 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
+        x3 = self.matmul_precision == "fp32x3" and not self._dp_replica and self._x3_supported()
+        h2 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
         # the SPT Linear layers also run from split operands (fp32 arithmetic on the bf16 matrix cores) unless the native
         # fp32 matrix instructions were asked for or this is a DataParallel replica
         spt3 = self.matmul_precision != "fp32_mfma" and not self._dp_replica and not self.no_transformer_spt
-        if bf16 or x3:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
+        if bf16 or x3 or h2:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
         if spt3:
             stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
@@ -402,11 +406,14 @@ class MultiView_MPL(nn.Module):
         w16_keep = []
         for l, b in enumerate(self.blocks):
             ptrs = [_ptr(t) for t in self._block_ptrs(b)]
-            if bf16 or x3:
+            if bf16 or x3 or h2:
                 lib = cabi.load()
-                nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else (lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3)
+                nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else \
+                    ((lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3) if x3 else (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2))
                 if x3:
                     ptrs += [0, 0, 0, 0]
+                if h2:
+                    ptrs += [0] * 8
                 for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
                     n, k = lin.weight.shape
                     c3 = torch.empty(nbytes(n, k), dtype=torch.uint8, device=device)

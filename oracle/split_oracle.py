@@ -110,3 +110,96 @@ def six_product_matmul(A: np.ndarray, W: np.ndarray) -> np.ndarray:
     ah, am, al = (t.astype(np.float64) for t in split3(A))
     wh, wm, wl = (t.astype(np.float64) for t in split3(W))
     return al @ wh.T + ah @ wl.T + am @ wm.T + am @ wh.T + ah @ wm.T + ah @ wh.T
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16x2 engine (openmpl_amd/csrc/h2_gemm.hip): two fp16 parts per operand under exact power-of-two scales, three
+# partial products.  Same k permutation, 2 parts instead of 3:
+#     W2[N/136][KT][9 slots][2 parts][64 lanes][8 fp16], then fp32 c[N], sc[N], sw[N], bound[N], meta[8]
+#     sw_n = 2^(14 - e), max_k |gamma_k W_nk| = m 2^e with m in [0.5, 1)      (the scaled column maximum is in [2^13, 2^14))
+#     sc_n = 1 / (sa sw_n), sa = 1024 for an operand with LayerNorm folded in, else 1
+#     bound_n = sqrt(K) |gamma o W_n|_2 + |c_n|  (LayerNorm operands; 0 otherwise);
+#     meta = {scale(max bound), scale(max bound of the last third of the columns), their reciprocals, the two maxima, 0, 0},
+#     scale(v) = largest power of two p with p v <= 2^15.
+H2_SA = 1024.0
+
+
+def split2(x: np.ndarray):
+    """fp32 -> (hi, lo) fp16 parts as fp32 arrays: hi = fp16(x), lo = fp16(x - hi) (RNE, subnormals kept)."""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16).astype(np.float32)
+    lo = (x - hi).astype(np.float32).astype(np.float16).astype(np.float32)
+    return hi, lo
+
+
+def f16_bits(x: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def h2_window_scale(v: float) -> float:
+    if not v > 0:
+        return 1.0
+    m, e = np.frexp(np.float32(32768.0) / np.float32(v))
+    return float(np.ldexp(np.float32(1.0), int(min(120, max(-120, e - 1)))))
+
+
+def h2_trailer(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None):
+    """(c, sc, sw, bound, meta) fp32 arrays stored behind the fragments of an fp16x2 weight operand."""
+    W = np.asarray(W, dtype=np.float32)
+    N, K = W.shape
+    Wg = W if gamma is None else (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    amax = np.abs(Wg).max(1)
+    m, e = np.frexp(amax)
+    sw = np.where(amax > 0, np.ldexp(np.float32(1.0), 14 - e), np.float32(1.0)).astype(np.float32)
+    c = np.asarray(bias, dtype=np.float64).copy()
+    if gamma is not None:
+        c += W.astype(np.float64) @ np.asarray(beta, dtype=np.float64)
+    c = c.astype(np.float32)
+    sa = np.float32(H2_SA if gamma is not None else 1.0)
+    sc = (np.float32(1.0) / (sa * sw)).astype(np.float32)
+    if gamma is not None:
+        nrm = np.sqrt((Wg.astype(np.float64) ** 2).sum(1))
+        bound = ((np.sqrt(np.float64(K)) * nrm).astype(np.float32) + np.abs(c)).astype(np.float32)
+    else:
+        bound = np.zeros(N, dtype=np.float32)
+    ball = float(bound.max())
+    bv = float(bound[(3 * np.arange(N) >= 2 * N)].max())
+    s_all, s_v = h2_window_scale(ball), h2_window_scale(bv)
+    meta = np.array([s_all, s_v, 1.0 / s_all, 1.0 / s_v, ball, bv, 0.0, 0.0], dtype=np.float32)
+    return c, sc, sw, bound, meta
+
+
+def h2_operand(W: np.ndarray, gamma: np.ndarray = None) -> np.ndarray:
+    """uint16 array [N/136][KT][9][2][64][8] of the fragment bytes mpl_pack_h2 must produce for W[N][K] (gamma folded)."""
+    W = np.asarray(W, dtype=np.float32)
+    N, K = W.shape
+    assert N % 136 == 0 and K % 544 == 0
+    Gn, KT = N // 136, K // 32
+    Wg = W if gamma is None else (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    amax = np.abs(Wg).max(1)
+    m, e = np.frexp(amax)
+    sw = np.where(amax > 0, np.ldexp(np.float32(1.0), 14 - e), np.float32(1.0)).astype(np.float32)
+    Ws = (Wg * sw[:, None]).astype(np.float32)
+    Wp = np.zeros((Gn, 144, K), dtype=np.float32)
+    Wp[:, :136] = Ws.reshape(Gn, 136, K)
+    cols = k_permutation(K)
+    out = np.zeros((Gn, KT, 9, 2, 64, 8), dtype=np.uint16)
+    for p, part in enumerate(split2(Wp)):
+        b = f16_bits(part)[:, :, cols]                   # [g][c][kt][kq][j]
+        b = b.reshape(Gn, 9, 16, KT, 4, 8).transpose(0, 3, 1, 4, 2, 5).reshape(Gn, KT, 9, 64, 8)
+        out[:, :, :, p] = b[:, :, list(SLOT_TILE)]
+    return out
+
+
+def three_product_matmul(A: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """A . W^T from the three partial products of the fp16x2 engine (fp64 accumulation: isolates the split error); A and W
+    are scaled into the fp16 window like the kernels do (one scale for A, one per row of W), the scales taken out again."""
+    A = np.asarray(A, dtype=np.float32)
+    W = np.asarray(W, dtype=np.float32)
+    sa = np.float32(h2_window_scale(float(np.abs(A).max())))
+    amax = np.abs(W).max(1)
+    m, e = np.frexp(amax)
+    sw = np.where(amax > 0, np.ldexp(np.float32(1.0), 14 - e), np.float32(1.0)).astype(np.float32)
+    ah, al = (t.astype(np.float64) for t in split2(A * sa))
+    wh, wl = (t.astype(np.float64) for t in split2(W * sw[:, None]))
+    return (al @ wh.T + ah @ wl.T + ah @ wh.T) / (np.float64(sa) * sw.astype(np.float64))[None, :]

@@ -131,7 +131,7 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == max(want32, want3)
     cfg.flags |= cabi.F_RAYS_TOKEN
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
-    assert ctypes.sizeof(cabi.BlockWeights) == 160 and ctypes.sizeof(cabi.SptSet) == 48
+    assert ctypes.sizeof(cabi.BlockWeights) == 192 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
     # split operands of the fp32-on-bf16-cores GEMMs: 27 KiB per (136-column group, 32-deep k-tile) + the two fold
     # vectors (c, s: N floats each); 0 = unsupported

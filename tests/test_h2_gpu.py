@@ -1,0 +1,203 @@
+"""GPU tests of the fp16x2 split-operand engine (openmpl_amd/csrc/h2_gemm.hip), the default "fp32" arithmetic of the FPT
+block stack (reference ops: multiview_mpl.py:84-92 Block, :53-67 Attention, :31-37 Mlp): unit GEMMs through the C ABI
+against fp64 torch, the packed operand byte for byte against oracle/split_oracle.py, range robustness, and the engine
+inside the whole forward (goldens, launch modes, the older engines)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from openmpl_amd import cabi
+from oracle import mpl_oracle, split_oracle
+from tests.test_gpu_parity import DEV, _assert_close, _big_inputs, _fp64_linear, _model, _stream, _x3_linear
+
+pytestmark = pytest.mark.gpu
+
+
+def _h2_pack(lib, Wd, bd, gd, bed, N, K, ln):
+    nbytes = lib.mpl_pack_h2_bytes(N, K)
+    assert nbytes == (N // 136) * (K // 32) * 18 * 1024 + (4 * N + 8) * 4
+    W2 = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    cabi.check(lib.mpl_pack_h2(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None, bed.data_ptr() if ln else None,
+                               N, K, W2.data_ptr(), _stream()), "mpl_pack_h2")
+    return W2
+
+
+def _h2_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln):
+    W2 = _h2_pack(lib, Wd, bd, gd, bed, N, K, ln)
+    so = torch.zeros(M + 64, max(1, K // 136), 2, device=DEV)
+    wsb = lib.mpl_ln_linear_h2_workspace_bytes(M, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    cabi.check(lib.mpl_ln_linear_h2(Ad.data_ptr(), M, K, 1 if ln else 0, 1e-6, W2.data_ptr(), N, epi,
+                                    Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None, Y.data_ptr(),
+                                    so.data_ptr() if ln else None, ws.data_ptr(), wsb, _stream()), "mpl_ln_linear_h2")
+    return Y
+
+
+@pytest.mark.parametrize("M,K,N,epi,ln", [
+    (4096, 544, 1632, cabi.EPI_BIAS, True),
+    (4096, 544, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (1000, 544, 1088, cabi.EPI_BIAS_GELU, True),
+    (77, 1088, 544, cabi.EPI_BIAS_RESIDUAL, False),
+    (3, 544, 544, cabi.EPI_BIAS, False),
+    (130, 1088, 3264, cabi.EPI_BIAS, True),
+    (640, 2176 // 2, 1088, cabi.EPI_BIAS_RESIDUAL, True),       # LayerNorm in front of a one-pass (residual) GEMM
+    (640, 1632, 1088, cabi.EPI_BIAS_RESIDUAL, False),
+    (300, 2176, 1088, cabi.EPI_BIAS_RESIDUAL, False),            # fc2 of the FULL flag set
+    (8192, 544, 1088, cabi.EPI_BIAS_GELU, True),
+    (200, 544, 136, cabi.EPI_BIAS, True),                        # a single column group (one pass)
+])
+def test_h2_linear_is_fp32_accurate(M, K, N, epi, ln):
+    """mpl_pack_h2 + mpl_ln_linear_h2 against an fp64 evaluation: the fp16x2 GEMM must be as accurate as fp32 arithmetic --
+    its error may not exceed the native fp32 MFMA kernel's by more than rounding noise."""
+    lib = cabi.load()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    ref = _fp64_linear(A, W, b, R, gam, bet, epi, ln)
+    Ad, Wd, bd, Rd, gd, bed = (t.to(DEV) for t in (A, W, b, R, gam, bet))
+    Y = _h2_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    e_h2 = mpl_oracle.rel_errors(Y.cpu(), ref)
+    Y2 = torch.full((M, N), float("nan"), device=DEV)
+    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
+    cabi.check(lib.mpl_ln_linear(Ad.data_ptr(), M, K, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-6,
+                                 Wd.data_ptr(), bd.data_ptr(), N, epi, Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None,
+                                 Y2.data_ptr(), so.data_ptr() if ln else None, _stream()), "mpl_ln_linear")
+    torch.cuda.synchronize()
+    e_mfma = mpl_oracle.rel_errors(Y2.cpu(), ref)
+    print("M=%d K=%d N=%d: h2 %.2e/%.2e  fp32 MFMA %.2e/%.2e" % ((M, K, N) + e_h2 + e_mfma))
+    assert e_h2[0] <= 3e-6 and e_h2[1] <= 1e-6
+    assert e_h2[1] <= 1.5 * e_mfma[1] + 1e-8, "the fp16x2 GEMM is less accurate than the fp32 MFMA GEMM"
+    # a second call is bitwise the first (fixed k order, fixed product order)
+    assert torch.equal(Y, _h2_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln))
+
+
+@pytest.mark.parametrize("shift,scale", [(0.0, 1.0), (5.0, 1.0), (-40.0, 2.0), (0.0, 1e-20), (0.0, 1e15), (100.0, 1e-2)])
+def test_h2_layernorm_input_is_robust_to_offset_and_scale(shift, scale):
+    """The LayerNorm GEMMs normalise their input BEFORE it is split ((x - mean) rstd 2^10, always inside the fp16 window), so
+    neither the offset nor the magnitude of the rows costs anything beyond what fp32 statistics cost any implementation."""
+    lib = cabi.load()
+    M, K, N = 256, 544, 1632
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K, generator=g) + shift) * scale
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    a = A.double()
+    a = (a - a.mean(-1, keepdim=True)) / torch.sqrt(a.var(-1, unbiased=False, keepdim=True) + 1e-6) * gam.double() + bet.double()
+    ref = a @ W.double().T + b.double()
+    Ad, Wd, bd, gd, bed = (t.to(DEV) for t in (A, W, b, gam, bet))
+    Y = _h2_linear(lib, Ad, Wd, bd, gd, bed, None, M, K, N, cabi.EPI_BIAS, True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    mx, nw = mpl_oracle.rel_errors(Y.cpu(), ref)
+    # the fp32 row statistics lose |mean| / sigma of relative precision (as in any fp32 LayerNorm, the reference's included)
+    amp = (1.0 + abs(shift) ** 2) ** 0.5
+    print("shift %g scale %g: %.2e / %.2e" % (shift, scale, mx, nw))
+    assert mx <= 3e-6 * amp and nw <= 1e-6 * amp and mx < 1e-4
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-8, 1.0, 3e4, 1e20])
+def test_h2_plain_operand_is_robust_to_scale(scale):
+    """A GEMM without LayerNorm (unit entry): the A operand is packed under its measured amax, the weights under their column
+    maxima -- any magnitude that fp32 itself can carry works, including all-zero weight columns and all-zero rows."""
+    lib = cabi.load()
+    M, K, N = 192, 544, 544
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g) * scale
+    A[7] = 0.0
+    W = torch.randn(N, K, generator=g) * K ** -0.5 / max(scale, 1e-20) ** 0.5
+    W[11] = 0.0
+    W[12] *= 1e-6
+    b = torch.randn(N, generator=g) * float((A.double() @ W.double().T).abs().max())
+    ref = A.double() @ W.double().T + b.double()
+    Ad, Wd, bd = (t.to(DEV) for t in (A, W, b))
+    Y = _h2_linear(lib, Ad, Wd, bd, None, None, None, M, K, N, cabi.EPI_BIAS, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    mx, nw = mpl_oracle.rel_errors(Y.cpu(), ref)
+    print("scale %g: %.2e / %.2e" % (scale, mx, nw))
+    assert mx <= 3e-6 and nw <= 1e-6
+    assert torch.equal(Y[:, 11].cpu(), b[11].expand(M)) and torch.equal(Y[7].cpu(), b)
+
+
+def test_h2_operand_bytes_match_the_definition():
+    """mpl_pack_h2 against oracle/split_oracle.py: both fp16 parts in MFMA fragment order byte for byte, then the trailer."""
+    lib = cabi.load()
+    g = torch.Generator().manual_seed(3)
+    for N, K, ln in ((272, 544, False), (544, 544, True), (1632, 544, True), (544, 1088, False)):
+        W = torch.randn(N, K, generator=g) * K ** -0.5
+        W[0, 0], W[1, 1], W[2, 2] = 0.0, 1.0 + 2 ** -23, -255.99998
+        W[3] = 0.0
+        bias = torch.randn(N, generator=g)
+        gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+        Wd, bd, gd, bed = (t.to(DEV) for t in (W, bias, gam, bet))
+        dst = _h2_pack(lib, Wd, bd, gd, bed, N, K, ln)
+        torch.cuda.synchronize()
+        raw = dst.cpu().numpy()
+        nfr = (N // 136) * (K // 32) * 18 * 1024
+        got = raw[:nfr].view(np.uint16)
+        want = split_oracle.h2_operand(W.numpy(), gam.numpy() if ln else None).reshape(-1)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "N=%d K=%d: %d of %d fp16 words differ" % (N, K, int((got != want).sum()), want.size)
+        c, sc, sw, bound, meta = split_oracle.h2_trailer(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
+        vec = raw[nfr:].view(np.float32)
+        assert np.array_equal(vec[:N], c) and np.array_equal(vec[N:2 * N], sc) and np.array_equal(vec[2 * N:3 * N], sw)
+        assert np.allclose(vec[3 * N:4 * N], bound, rtol=2e-6, atol=0)
+        if ln:
+            assert np.array_equal(vec[4 * N:4 * N + 4], meta[:4]), (vec[4 * N:4 * N + 8], meta)
+
+
+def test_h2_shapes_are_validated():
+    lib = cabi.load()
+    for n, k in ((100, 544), (544, 40), (136, 32), (0, 544), (544, -544), (544, 272), (544, 136), (544, 9248)):
+        assert lib.mpl_pack_h2_bytes(n, k) == 0
+    x = torch.zeros(64, 544, device=DEV)
+    assert lib.mpl_pack_h2(x.data_ptr(), x.data_ptr(), None, None, 100, 544, x.data_ptr(), _stream()) != 0
+    big = torch.zeros(lib.mpl_pack_h2_bytes(544, 544), dtype=torch.uint8, device=DEV)
+    W = torch.zeros(544, 544, device=DEV)
+    assert lib.mpl_pack_h2(W.data_ptr(), x.data_ptr(), x.data_ptr(), None, 544, 544, big.data_ptr(), _stream()) != 0    # half a LayerNorm
+    assert lib.mpl_pack_h2_bytes(136, 2176) > 0              # fc2 of the FULL flag set (plain operand: any multiple of 544)
+    assert lib.mpl_ln_linear_h2(x.data_ptr(), 64, 544, 0, 1e-6, big.data_ptr(), 544, 0, None, W.data_ptr(), None,
+                                W.data_ptr(), 16, _stream()) == -3
+
+
+def test_h2_is_the_default_engine_and_the_older_engines_still_agree():
+    """"fp32" packs fp16x2 operands; "fp32x3" (three bf16 parts) and "fp32_mfma" give the same poses to rounding; every engine is
+    bitwise independent of the batch size."""
+    m, g = _model("chosen_v4_b8_l12")
+    P, R, Cn = _big_inputs(512, 4, 5)
+    outs = {}
+    for prec in ("fp32", "fp32x3", "fp32_mfma"):
+        m.set_matmul_precision(prec)
+        with torch.no_grad():
+            full = m(P, rays=R, centers=Cn)
+            part = m([x[100:400].contiguous() for x in P], rays=[x[100:400].contiguous() for x in R],
+                     centers=[x[100:400].contiguous() for x in Cn])
+        assert torch.equal(full[100:400], part), prec + ": batch slice changed results"
+        outs[prec] = full
+        blk = m._hip_cache[0]["fpt_blocks"][0]
+        assert bool(blk.qkv_h2) == (prec == "fp32") and bool(blk.qkv_w3) == (prec == "fp32x3")
+    for other in ("fp32x3", "fp32_mfma"):
+        mx, nw = mpl_oracle.rel_errors(outs["fp32"].cpu(), outs[other].cpu())
+        assert 0 < mx < 5e-6 and nw < 5e-6, (other, mx, nw)
+    m.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2", "chosen_v8_b4_l2", "chosen_v5_b19_l2", "chosen_v31_b2_l12", "chosen_v2_b1_l12"])
+def test_x3_engine_still_matches_goldens(name):
+    """The round-2 engine stays selectable ("fp32x3") and stays green against the reference goldens."""
+    m, g = _model(name)
+    m.set_matmul_precision("fp32x3")
+    from tests.util import golden_inputs
+    P, R, Cn = golden_inputs(g, DEV)
+    with torch.no_grad():
+        out = m(P, rays=R, centers=Cn)
+    _assert_close(out, torch.from_numpy(g["out"]), name + " fp32x3")

@@ -1,0 +1,30 @@
+"""Shared fixture of the block-stack tools: one FPT block with packed operands of the chosen engine.
+ENGINE=h2 (default: fp16x2, h2_gemm.hip) | x3 (bf16x3, x3_gemm.hip) in the environment."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from openmpl_amd import cabi
+
+ENGINE = os.environ.get("ENGINE", "h2")
+lib = cabi.load()
+dev = "cuda"
+st = lambda: torch.cuda.current_stream().cuda_stream
+
+
+def make_block(D, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    nbytes, pack = (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2) if ENGINE == "h2" else (lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3)
+
+    def operand(N, K, ln):
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
+        gam = (torch.rand(K, generator=g) + 0.5).to(dev); bet = (torch.randn(K, generator=g) * 0.1).to(dev)
+        o = torch.empty(nbytes(N, K), dtype=torch.uint8, device=dev)
+        cabi.check(pack(W.data_ptr(), b.data_ptr(), gam.data_ptr() if ln else None, bet.data_ptr() if ln else None, N, K, o.data_ptr(), st()), "pack")
+        return o
+    blk = cabi.BlockWeights()
+    keep = [operand(3 * D, D, True), operand(D, D, False), operand(2 * D, D, True), operand(D, 2 * D, False)]
+    if ENGINE == "h2":
+        blk.qkv_h2, blk.proj_h2, blk.fc1_h2, blk.fc2_h2 = (k.data_ptr() for k in keep)
+    else:
+        blk.qkv_w3, blk.proj_w3, blk.fc1_w3, blk.fc2_w3 = (k.data_ptr() for k in keep)
+    return (cabi.BlockWeights * 1)(blk), keep, g

@@ -1,27 +1,16 @@
 """Per-phase time line of the persistent stack kernel (chain mode) at the headline shape: the stack is stopped after
 phase p (mpl_x3_stack_mode) so that the per-wave stamps of mpl_x3_debug_buffer are those of phase p.
-python tools/chain_phase.py [D] [n_blocks] [M]"""
+[ENGINE=h2|x3] python tools/chain_phase.py [D] [n_blocks] [M]   (library built with -DH2_DBG=1 / -DX3_DBG=1)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from openmpl_amd import cabi
 
-lib = cabi.load()
+from tools._stack_fixture import lib, dev, st, make_block, ENGINE
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 544
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-M, dev = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), "cuda"
-st = lambda: torch.cuda.current_stream().cuda_stream
-g = torch.Generator().manual_seed(0)
-def operand(N, K, ln):
-    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
-    gam = (torch.rand(K, generator=g) + 0.5).to(dev); bet = (torch.randn(K, generator=g) * 0.1).to(dev)
-    o = torch.empty(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=dev)
-    cabi.check(lib.mpl_split_bf16x3(W.data_ptr(), b.data_ptr(), gam.data_ptr() if ln else None, bet.data_ptr() if ln else None, N, K, o.data_ptr(), st()), "split")
-    return o
-blk = cabi.BlockWeights()
-keep = [operand(3 * D, D, True), operand(D, D, False), operand(2 * D, D, True), operand(D, 2 * D, False)]
-blk.qkv_w3, blk.proj_w3, blk.fc1_w3, blk.fc2_w3 = (k.data_ptr() for k in keep)
-blks = (cabi.BlockWeights * 1)(blk)
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+blks, keep, g = make_block(D)
 x = torch.randn(M, D, generator=g).to(dev)
 wsb = lib.mpl_block_stack_workspace_bytes(M // 4, 4, D)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
