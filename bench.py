@@ -539,6 +539,23 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
             h2d_step(i)
         torch.cuda.synchronize()
     extra["h2d_inclusive_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
+    # the same through ONE pinned staging buffer and one copy per batch (openmpl_amd.inputs.HostStager)
+    from openmpl_amd.inputs import HostStager
+    stagers = [HostStager(a.batch, a.views, 17, dev) for _ in range(2)]       # double-buffered: batch i+1 is packed while i runs
+    plain = [tuple([t.cpu() for t in lst] for lst in b) for b in batches[:2]]
+
+    def staged_step(i):
+        Pv, Rv, Cv = stagers[i % 2].stage(*plain[i % 2])
+        return model(Pv, rays=Rv, centers=Cv)
+    with torch.no_grad():
+        for i in range(3):
+            staged_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_o):
+            staged_step(i)
+        torch.cuda.synchronize()
+    extra["h2d_inclusive_staged_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
     # BASELINE.json configs[0] shape on the GPU: single-frame latency (V=2, B=1, depth 12), synchronised per call
     f0 = model_flags("chosen", 2, a.depth)
     m0 = build_model(f0, dev)

@@ -268,6 +268,10 @@ int mpl_prepare_inputs(const float *joints_px, const float *conf, const double *
 int mpl_pose_metrics_size(int joints);
 int mpl_pose_metrics(const float *output, const float *target, const float *weight, int batch, int joints,
                      const float *scale3, const float *offset3, float *result, void *stream);
+/* The same with config.NOT_CONSIDER_SOME_KP_IN_EVAL (evaluate.py:101-104, :110-113): bit j of not_consider_mask set = joint j is
+ * deleted from the two MEANS over joints (mpjpe_abs, mpjpe_rel); the per-joint errors are reported unchanged. */
+int mpl_pose_metrics_ex(const float *output, const float *target, const float *weight, int batch, int joints,
+                        const float *scale3, const float *offset3, uint32_t not_consider_mask, float *result, void *stream);
 
 /* ---- fp16x2 split-operand engine (csrc/h2_gemm.hip): "fp32" precision of MultiView_MPL (the default).
  * mpl_pack_h2: derived operand of one nn.Linear (W (N,K) row-major, bias (N)), optionally with the LayerNorm in front of it

@@ -75,7 +75,7 @@ class Inputs(C.Structure):
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
            "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_ln_linear_bf16", "mpl_split_bf16x3_bytes", "mpl_split_bf16x3", "mpl_pack_h2_bytes", "mpl_pack_h2", "mpl_ln_linear_h2_workspace_bytes", "mpl_ln_linear_h2", "mpl_ln_linear_x3_workspace_bytes", "mpl_ln_linear_x3", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_device_error", "mpl_device_error_clear", "mpl_x3_spin_limit", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
-           "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_prepare_inputs", "mpl_profile_start",
+           "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_pose_metrics_ex", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head")
 
@@ -191,6 +191,8 @@ def load():
         lib.mpl_pose_metrics_size.argtypes = [C.c_int]
         lib.mpl_pose_metrics.restype = C.c_int
         lib.mpl_pose_metrics.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _fp]
+        lib.mpl_pose_metrics_ex.restype = C.c_int
+        lib.mpl_pose_metrics_ex.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, _fp, _fp]
         lib.mpl_prepare_inputs.restype = C.c_int
         lib.mpl_prepare_inputs.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                            C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), _fp]

@@ -637,7 +637,13 @@ int mpl_pose_metrics_size(int joints) { return 4 + 2 * (joints + 1) + 3 * joints
 int mpl_pose_metrics(const float* output, const float* target, const float* weight, int batch, int joints,
                      const float* scale3, const float* offset3, float* result, void* stream) {
     clear_stale_hip_error();
-    return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, result, (hipStream_t)stream);
+    return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, 0u, result, (hipStream_t)stream);
+}
+
+int mpl_pose_metrics_ex(const float* output, const float* target, const float* weight, int batch, int joints,
+                        const float* scale3, const float* offset3, uint32_t not_consider_mask, float* result, void* stream) {
+    clear_stale_hip_error();
+    return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, not_consider_mask, result, (hipStream_t)stream);
 }
 
 int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* out, void* workspace,

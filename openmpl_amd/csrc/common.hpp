@@ -175,7 +175,7 @@ int launch_linear_act(const float* xa, int Ka, int lda, const float* xb, int Kb,
                       const float* bn_var, float bn_eps, int relu, float* y, int ldy, hipStream_t s);
 
 int launch_pose_metrics(const float* out, const float* tgt, const float* wgt, int B, int J, const float* scale3,
-                        const float* offset3, float* res, hipStream_t s);
+                        const float* offset3, unsigned skip_mask, float* res, hipStream_t s);
 
 int launch_prepare_inputs(const float* px, const float* conf, const double* cams_dev, int B, int V, int J, float w, float h,
                           int norm_in, int norm_cam, float* const* poses, float* const* rays, float* const* centers,

@@ -75,13 +75,18 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #define H2_DBG 0
 #endif
 #ifndef H2_ABL
-#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no in-place conversion
+#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no in-place conversion, 32 no per-stage barrier
 #endif
 #ifndef H2_WT_AUX
 #define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
 #endif
 #ifndef H2_STAGGER
 #define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
+#endif
+#ifndef H2_SCHED
+#define H2_SCHED 0     // schedule of a stage (A/B switch): bit 0 = all fragment reads of the next stage in ONE burst at the head
+                       // of the stage (waves 0..3) / behind the first product row (waves 4..7); bit 1 = the DMA refill at the
+                       // END of the stage (in the shadow of the barrier skew) instead of between the product rows
 #endif
 
 __host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
@@ -813,7 +818,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
             if (H2_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(H2_ABL & 32)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (H2_DBG && a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
         }
@@ -835,25 +840,61 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 if (t == t_ops) epilogue_operands();
             }
         };
+        auto all_reads = [&]() {
+            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+            rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
+        };
+        if constexpr ((H2_SCHED & 4) != 0) {
+            // the two waves of a SIMD out of phase: waves 0..3 multiply first and load afterwards, waves 4..7 the other way
+            // round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe
+            __builtin_amdgcn_sched_barrier(0);
+            if (!HAS_A) {
+                all_reads();
+                refill();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_row(accp, a_cur[1], b_cur, 0);
+            mfma_row(accp, a_cur[0], b_cur, 1);
+            mfma_row(accp, a_cur[0], b_cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAS_A) {
+                all_reads();
+                refill();
+                if (cv) convert(slot_after(slot_n));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot_c = slot_n;
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((H2_SCHED & 1) && HAS_A) all_reads();
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[1], b_cur, 0);             // lo . hi
         __builtin_amdgcn_sched_barrier(0);
-        if (!(H2_STAGGER && !HAS_A)) refill();
-        if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-        rd_b(0);
-        if (!next_has_a) rd_b(1);
+        if ((H2_SCHED & 1) && !HAS_A) all_reads();
+        if (!(H2_SCHED & 2) && !(H2_STAGGER && !HAS_A)) refill();
+        if (!(H2_SCHED & 1)) {
+            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+            rd_b(0);
+            if (!next_has_a) rd_b(1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 1);             // hi . lo
         __builtin_amdgcn_sched_barrier(0);
-        if (next_has_a) rd_b(1);
-        rd_b(2);
-        if (H2_STAGGER && !HAS_A) refill();
+        if (!(H2_SCHED & 1)) {
+            if (next_has_a) rd_b(1);
+            rd_b(2);
+        }
+        if (!(H2_SCHED & 2) && H2_STAGGER && !HAS_A) refill();
         if (cv) convert(slot_after(slot_n));
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 0);             // hi . hi
         __builtin_amdgcn_sched_barrier(0);
-        rd_b(3);
-        rd_b(4);
+        if (!(H2_SCHED & 1)) {
+            rd_b(3);
+            rd_b(4);
+        }
+        if (H2_SCHED & 2) refill();
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };

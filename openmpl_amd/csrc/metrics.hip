@@ -17,7 +17,7 @@ constexpr int MACC = 12;
 
 __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                             const float* __restrict__ wgt, int B, int J, float sx, float sy,
-                                                            float sz, float ox, float oy, float oz,
+                                                            float sz, float ox, float oy, float oz, unsigned skip_mask,
                                                             float* __restrict__ res) {
     __shared__ double acc[MS][MJ][MACC];
     const int tid = threadIdx.x;
@@ -73,10 +73,14 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restri
     __syncthreads();
     if (tid == 0) {
         double loss = 0, ax[3] = {0, 0, 0}, ma = 0, mr = 0, dm[3] = {0, 0, 0};
+        int kept = 0;          // evaluate.py:101-104, :110-113: joints in not_consider_kp are deleted from the MEAN only
         for (int q = 0; q < J; ++q) {
             loss += acc[0][q][0];
-            ma += acc[0][q][4] / B;
-            mr += acc[0][q][5] / B;
+            if (!((skip_mask >> q) & 1u)) {
+                ma += acc[0][q][4] / B;
+                mr += acc[0][q][5] / B;
+                ++kept;
+            }
             for (int d = 0; d < 3; ++d) {
                 ax[d] += acc[0][q][1 + d];
                 dm[d] += acc[0][q][6 + d] / acc[0][q][9 + d];
@@ -87,18 +91,18 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restri
             res[1 + d] = (float)(ax[d] / ((double)B * J));
             res[4 + 2 * (J + 1) + 3 * J + d] = (float)(dm[d] / J);
         }
-        res[4 + J] = (float)(ma / J);
-        res[4 + (J + 1) + J] = (float)(mr / J);
+        res[4 + J] = (float)(ma / kept);              // kept == 0: NaN, like numpy's mean of an empty array
+        res[4 + (J + 1) + J] = (float)(mr / kept);
     }
 }
 
 int launch_pose_metrics(const float* out, const float* tgt, const float* wgt, int B, int J, const float* scale3,
-                        const float* offset3, float* res, hipStream_t s) {
+                        const float* offset3, unsigned skip_mask, float* res, hipStream_t s) {
     if (!out || !tgt || !res || B <= 0 || J <= 0 || J > MJ) return MPL_E_INVALID;
     const float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
     const float ox = offset3 ? offset3[0] : 0.f, oy = offset3 ? offset3[1] : 0.f, oz = offset3 ? offset3[2] : 0.f;
     ProfScope prof(MPL_K_FUSE_HEAD, s);
-    hipLaunchKernelGGL(pose_metrics_kernel, dim3(1), dim3(256), 0, s, out, tgt, wgt, B, J, sx, sy, sz, ox, oy, oz, res);
+    hipLaunchKernelGGL(pose_metrics_kernel, dim3(1), dim3(256), 0, s, out, tgt, wgt, B, J, sx, sy, sz, ox, oy, oz, skip_mask, res);
     return hip_check_launch();
 }
 

@@ -49,3 +49,36 @@ def prepare_inputs(joints_px: torch.Tensor, conf: Optional[torch.Tensor], cams: 
                                     arr(poses), arr(rays), arr(centers), torch.cuda.current_stream().cuda_stream)
     cabi.check(rc, "mpl_prepare_inputs")
     return poses, rays, centers
+
+
+class HostStager:
+    """One pinned staging buffer + ONE host-to-device copy per batch for callers that hold the inputs on the host (the
+    loop of validate(), function_mpl.py:334-351, hands `model(input, centers=, rays=)` CPU tensors): the V x {(B,J,3) poses,
+    (B,J,3) rays, (B,1,3) centers} are packed back to back into pinned memory and cross PCIe as one transfer instead of
+    3V small ones; the returned lists are views into one device buffer (layouts exactly those the model expects)."""
+
+    def __init__(self, batch: int, views: int, joints: int, device):
+        self.shape = (batch, views, joints)
+        self.sizes = [batch * joints * 3, batch * joints * 3, batch * 3]
+        n = views * sum(self.sizes)
+        self.host = torch.empty(n, dtype=torch.float32).pin_memory()
+        self.dev = torch.empty(n, dtype=torch.float32, device=device)
+        self._copied = None          # event behind the last host-to-device copy out of self.host
+
+    def stage(self, poses, rays, centers):
+        B, V, J = self.shape
+        if self._copied is not None:
+            self._copied.synchronize()      # the previous transfer has read the pinned buffer before it is overwritten
+        if len(poses) != V or poses[0].shape[0] != B:
+            raise RuntimeError("HostStager was built for %d views of batch %d" % (V, B))
+        off, views = 0, ([], [], [])
+        for k, (lst, n, shp) in enumerate(((poses, self.sizes[0], (B, J, 3)), (rays, self.sizes[1], (B, J, 3)),
+                                           (centers, self.sizes[2], (B, 1, 3)))):
+            for t in lst:
+                self.host[off:off + n].view(shp).copy_(t)
+                views[k].append(self.dev[off:off + n].view(shp))
+                off += n
+        self.dev.copy_(self.host, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record(torch.cuda.current_stream(self.dev.device))
+        return views

@@ -14,9 +14,11 @@ from . import cabi
 
 
 def pose_metrics(output: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor] = None,
-                 scale: Optional[Sequence[float]] = None, offset: Optional[Sequence[float]] = None) -> Dict[str, torch.Tensor]:
+                 scale: Optional[Sequence[float]] = None, offset: Optional[Sequence[float]] = None,
+                 not_consider_kp: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
     """output/target (B,J,3) float32 on the GPU; weight (B,J) or (B,J,1) optional (Weighted_MPJPE);
-    scale/offset: per-axis room de-normalisation (function_mpl.py:476-488).  Returns device tensors:
+    scale/offset: per-axis room de-normalisation (function_mpl.py:476-488); not_consider_kp: joints deleted from the means
+    mpjpe_abs / mpjpe_rel (config.NOT_CONSIDER_SOME_KP_IN_EVAL, evaluate.py:101-104, np.delete semantics).  Returns device tensors:
     loss, loss_axis(3), pjpe_abs(J), mpjpe_abs, pjpe_rel(J), mpjpe_rel, dist(J,3), dist_mean(3)."""
     if output.device.type != "cuda" or target.device != output.device:
         raise RuntimeError("pose_metrics has no CPU path: tensors must live on the same GPU")
@@ -33,9 +35,14 @@ def pose_metrics(output: torch.Tensor, target: torch.Tensor, weight: Optional[to
     res = torch.empty(n, dtype=torch.float32, device=output.device)
     sc = (C.c_float * 3)(*[float(v) for v in scale]) if scale is not None else None
     of = (C.c_float * 3)(*[float(v) for v in offset]) if offset is not None else None
+    mask = 0
+    for k in (not_consider_kp if not_consider_kp is not None else ()):
+        if not -J <= int(k) < J:
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(k), J))      # what np.delete raises
+        mask |= 1 << (int(k) % J)
     with torch.cuda.device(output.device):
-        rc = lib.mpl_pose_metrics(output.data_ptr(), target.data_ptr(), None if weight is None else weight.data_ptr(), B, J,
-                                  sc, of, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc = lib.mpl_pose_metrics_ex(output.data_ptr(), target.data_ptr(), None if weight is None else weight.data_ptr(), B, J,
+                                     sc, of, mask, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
     cabi.check(rc, "mpl_pose_metrics")
     o = 4
     return dict(loss=res[0], loss_axis=res[1:4], pjpe_abs=res[o:o + J], mpjpe_abs=res[o + J],

@@ -280,9 +280,9 @@ class MultiView_MPL(nn.Module):
 
     def _replicate_for_data_parallel(self):
         """DataParallel replicas (valid_mpl.py:177-178) get fresh broadcast copies of every parameter on every forward,
-        so derived operand copies could never be reused: replicas run the engines that read the nn.Parameter storage in
-        place (native fp32 MFMA) instead of re-splitting ~180 MB of weights per forward.  The persistent one-process-
-        per-GPU path (openmpl_amd/dist.py) keeps the split-operand engine."""
+        so derived operand copies can never be reused: a replica re-packs the operands of the default engine on every
+        forward (cheap next to what the engine saves, see _marshal); the persistent one-process-per-GPU path
+        (openmpl_amd/dist.py) packs once."""
         r = super()._replicate_for_data_parallel()
         r._hip_cache = {}
         r._dp_replica = True
@@ -354,10 +354,15 @@ class MultiView_MPL(nn.Module):
         key = tuple(map(torch.Tensor.data_ptr, plist))
         bf16 = self.matmul_precision == "bf16" and not self._dp_replica and self._x3_supported()
         x3 = self.matmul_precision == "fp32x3" and not self._dp_replica and self._x3_supported()
-        h2 = self.matmul_precision == "fp32" and not self._dp_replica and self._x3_supported()
+        # DataParallel replicas get fresh parameter storage every forward, so their derived operands are rebuilt every
+        # forward: ~60 us of packing kernels for the default engine (114 MB read, 120 MB written) against a forward that is
+        # 2x faster than on the fp32 matrix instructions -- worth it for "fp32"; the 6 B / element operands of the older
+        # engines are not rebuilt per forward (replicas of those precisions run the native fp32 MFMA kernels)
+        h2 = self.matmul_precision == "fp32" and self._x3_supported()
         # the SPT Linear layers also run from split operands (fp32 arithmetic on the bf16 matrix cores) unless the native
-        # fp32 matrix instructions were asked for or this is a DataParallel replica
-        spt3 = self.matmul_precision != "fp32_mfma" and not self._dp_replica and not self.no_transformer_spt
+        # fp32 matrix instructions were asked for (or this is a replica of one of the older engines)
+        spt3 = self.matmul_precision != "fp32_mfma" and not (self._dp_replica and self.matmul_precision != "fp32") \
+            and not self.no_transformer_spt
         if bf16 or x3 or h2:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
         if spt3:

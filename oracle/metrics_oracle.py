@@ -14,12 +14,18 @@ def denormalise(x, scale, offset):
     return x * np.asarray(scale, dtype=x.dtype).reshape(1, 1, 3) + np.asarray(offset, dtype=x.dtype).reshape(1, 1, 3)
 
 
-def calc_mpjpe(output, target, mode="absolute"):
-    """evaluate.py:91-114.  NaN terms are skipped inside the squared sum (np.nansum)."""
+def calc_mpjpe(output, target, mode="absolute", not_consider_kp=None):
+    """evaluate.py:91-114.  NaN terms are skipped inside the squared sum (np.nansum); joints listed in not_consider_kp
+    (config.NOT_CONSIDER_SOME_KP_IN_EVAL) are left out of the mean over joints, np.delete semantics (:101-104, :110-113)."""
     if mode == "relative":                                   # :105-107 root-relative
         output = output - output[:, 0:1, :]
         target = target - target[:, 0:1, :]
     pjpe = np.sqrt(np.nansum((output - target) ** 2, axis=2)).mean(axis=0)     # :100 / :108
+    if not_consider_kp is not None:
+        J = pjpe.shape[0]
+        keep = np.ones(J, dtype=bool)
+        keep[[int(k) % J for k in not_consider_kp]] = False  # np.delete: duplicates count once, negative indices wrap
+        return pjpe, pjpe[keep].mean()
     return pjpe, pjpe.mean()
 
 
@@ -38,12 +44,12 @@ def mpjpe_loss(output, target, w=None):
     return err.mean(), axis
 
 
-def all_metrics(output, target, w=None, scale=(1, 1, 1), offset=(0, 0, 0)):
+def all_metrics(output, target, w=None, scale=(1, 1, 1), offset=(0, 0, 0), not_consider_kp=None):
     """Everything mpl_pose_metrics returns, in its result order."""
     loss, axis = mpjpe_loss(output, target, w)
     o, t = denormalise(output, scale, offset), denormalise(target, scale, offset)
-    pa, ma = calc_mpjpe(o, t, "absolute")
-    pr, mr = calc_mpjpe(o, t, "relative")
+    pa, ma = calc_mpjpe(o, t, "absolute", not_consider_kp)
+    pr, mr = calc_mpjpe(o, t, "relative", not_consider_kp)
     d, dm = calc_distance_per_dim(o, t)
     return dict(loss=np.float64(loss), loss_axis=np.array(axis), pjpe_abs=pa, mpjpe_abs=ma, pjpe_rel=pr, mpjpe_rel=mr,
                 dist=d, dist_mean=dm)

@@ -52,5 +52,11 @@ for tag, B, with_nan in (("a", 37, False), ("b", 300, True)):
     pr, mr = ev.calc_mpjpe(o, t, mode="relative")
     d, dm = ev.calc_distance_per_dim(o, t)
     rec.update(pjpe_abs=pa, mpjpe_abs=ma, pjpe_rel=pr, mpjpe_rel=mr, dist=d, dist_mean=dm)
+    # evaluate.py:101-104 / :110-113: joints left out of the MEAN (config.NOT_CONSIDER_SOME_KP_IN_EVAL), per-joint errors unchanged
+    nck = [0, 9, 10] if tag == "a" else [16, 3, 3, -2]
+    pa2, ma2 = ev.calc_mpjpe(o, t, mode="absolute", not_consider_kp=nck)
+    pr2, mr2 = ev.calc_mpjpe(o, t, mode="relative", not_consider_kp=nck)
+    assert np.array_equal(pa2, pa) and np.array_equal(pr2, pr)
+    rec.update(nck=np.array(nck), mpjpe_abs_nck=ma2, mpjpe_rel_nck=mr2)
     np.savez_compressed(os.path.join(HERE, "metrics_%s.npz" % tag), **rec)
     print(tag, float(ma), float(mr), dm)

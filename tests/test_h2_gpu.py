@@ -201,3 +201,27 @@ def test_x3_engine_still_matches_goldens(name):
     with torch.no_grad():
         out = m(P, rays=R, centers=Cn)
     _assert_close(out, torch.from_numpy(g["out"]), name + " fp32x3")
+
+
+def test_data_parallel_replicas_run_the_default_engine():
+    """A DataParallel replica (torch re-creates them on every forward with fresh parameter storage, valid_mpl.py:177-178) packs its
+    own operands and runs the default engine -- not the slower fp32 matrix instructions it fell back to in round 2."""
+    m, g = _model("chosen_v4_b8_l2")
+    P, R, Cn = _big_inputs(64, 4, 3)
+    with torch.no_grad():
+        want = m(P, rays=R, centers=Cn)
+        rep = m._replicate_for_data_parallel()
+        assert rep._dp_replica and rep._hip_cache == {}
+        got = rep(P, rays=R, centers=Cn)
+    assert torch.equal(got, want)
+    blk = rep._hip_cache[0]["fpt_blocks"][0]
+    assert bool(blk.qkv_h2) and rep._hip_cache[0]["weights"].spt_packed
+    m.set_matmul_precision("bf16")
+    with pytest.warns(RuntimeWarning, match="DataParallel replicas"):
+        rep = m._replicate_for_data_parallel()
+    with torch.no_grad():
+        out = rep(P, rays=R, centers=Cn)            # replicas of the older engines: native fp32 MFMA kernels
+    assert not rep._hip_cache[0]["keep"][4]
+    mx, nw = mpl_oracle.rel_errors(out.cpu(), want.cpu())
+    assert mx < 5e-6
+    m.set_matmul_precision("fp32")

@@ -21,6 +21,11 @@ def test_metrics_oracle_matches_reference_golden(tag):
         np.testing.assert_allclose(m["loss"], g["loss"], rtol=1e-6)
         np.testing.assert_allclose(m["loss_axis"], g["loss_axis"], rtol=1e-6)
         np.testing.assert_allclose(mo.mpjpe_loss(g["out"], g["tgt"], g["w"])[0], g["loss_weighted"], rtol=1e-6)
+    # evaluate.py:101-104, :110-113: not_consider_kp (duplicates and negative indices included in fixture b)
+    m2 = mo.all_metrics(g["out"], g["tgt"], None, g["scale"], g["offset"], not_consider_kp=g["nck"].tolist())
+    np.testing.assert_allclose(m2["mpjpe_abs"], g["mpjpe_abs_nck"], rtol=1e-6)
+    np.testing.assert_allclose(m2["mpjpe_rel"], g["mpjpe_rel_nck"], rtol=1e-6)
+    np.testing.assert_allclose(m2["pjpe_abs"], g["pjpe_abs"], rtol=1e-6)
 
 
 @pytest.mark.gpu
@@ -37,6 +42,12 @@ def test_pose_metrics_kernel_matches_reference_golden(tag):
         np.testing.assert_allclose(m["loss_axis"].cpu().numpy(), g["loss_axis"], rtol=2e-5)
         mw = pose_metrics(out, tgt, weight=torch.from_numpy(g["w"]).cuda())
         np.testing.assert_allclose(float(mw["loss"]), g["loss_weighted"], rtol=2e-5)
+    m2 = pose_metrics(out, tgt, scale=g["scale"], offset=g["offset"], not_consider_kp=g["nck"].tolist())
+    np.testing.assert_allclose(float(m2["mpjpe_abs"]), g["mpjpe_abs_nck"], rtol=2e-5)
+    np.testing.assert_allclose(float(m2["mpjpe_rel"]), g["mpjpe_rel_nck"], rtol=2e-5)
+    np.testing.assert_allclose(m2["pjpe_abs"].cpu().numpy(), g["pjpe_abs"], rtol=2e-5, atol=1e-6)
+    with pytest.raises(IndexError):
+        pose_metrics(out, tgt, not_consider_kp=[17])
 
 
 @pytest.mark.gpu

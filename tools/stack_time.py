@@ -14,7 +14,7 @@ for M in ([int(a) for a in sys.argv[1:]] or [512, 2048, 3072, 4096, 512]):
     wsb = lib.mpl_block_stack_workspace_bytes(M // 4, 4, D)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     run = lambda: cabi.check(lib.mpl_block_stack(x.data_ptr(), M // 4, 4, D, 8, blks, sched, NB, ws.data_ptr(), wsb, st()), "stack")
-    for _ in range(5): run()
+    for _ in range(30): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
