@@ -570,6 +570,20 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
             torch.cuda.synchronize()
         extra["v2_b1_latency_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
     del m0
+    # batch curve (the reference's shipped call shape is TEST.BATCH_SIZE 256 with two views, configs/h36m/mpl_amass/h36m.yaml:107,
+    # :37-39): whole forward, CHOSEN flag set, depth 12.  The block stack is a chain of 52 dependent GEMMs per 64-row tile that
+    # one team of D / 136 workgroups walks serially, so its time (~1 ms) does not shrink with the batch: small batches leave
+    # CUs idle ("small batches")
+    curve = {}
+    for Vc in (2, 4):
+        fc = model_flags("chosen", Vc, a.depth)
+        mc = build_model(fc, dev)
+        for Bc in (1, 32, 256, 1024):
+            bc = [make_batch(Bc, Vc, dev, seed=5000 + Bc, step=s) for s in range(2)]
+            nc = max(10, a.steps // 3)
+            curve["v%d_b%d" % (Vc, Bc)] = round(Bc * nc / timed_steps(mc, bc, nc, 3), 1)
+        del mc
+    extra["batch_curve_poses_per_s"] = curve
     # BASELINE.json configs[4]: large-view stress V=31, batch 256 (31-token FPT), and the 17V = 527-token joints x views
     # grid (KPTOK, LDS-resident K/V of one head)
     for tag, fl in (("v31_b256_chosen", {}), ("v31_b256_kptok", dict(FPT_blocks_view_keypoint_tokens=True))):

@@ -212,8 +212,9 @@ int mpl_ln_linear_bf16(const float *x, int M, int K, int has_ln, float eps, cons
  * the buffer must hold 64 bytes per wave of the largest launch.  NULL (the default) switches it off.  The stamps are
  * compiled only into a library built with -DX3_DBG=1 (MPL_HIPCC_FLAGS); in the product build the call is a no-op. */
 int mpl_x3_debug_buffer(void *device_buffer);
-/* Diagnostics / A-B: 0 (default) = a block stack on split operands is ONE persistent launch (row-tile chains of
- * workgroups, csrc/x3_gemm.hip x3_stack_kernel); 1 = one launch per GEMM.  Results agree to <= 4 ulp (each mode is bitwise deterministic). */
+/* Diagnostics / A-B: 0 (default) = a block stack on packed operands is ONE persistent launch (row-tile chains of
+ * workgroups, x3_stack_kernel / h2_stack_kernel); 1 = one launch per GEMM (results agree to <= 4 ulp, each mode is bitwise
+ * deterministic).  Bits 8.. = stop after that many GEMM phases (tools/chain_phase.py). */
 int mpl_x3_stack_mode(int one_launch_per_gemm);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */

@@ -242,15 +242,15 @@ int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
 int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
                    int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
     const int M = n_seq * n_tok, rpt = h2_rows_per_tile(n_tok);
+    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
+    if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
     const H2Ws w = carve_h2_ws(ws, (size_t)M, (size_t)D, rpt);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const int n_tiles = (M + rpt - 1) / rpt;
     if (err_ws) *err_ws = w.counters + n_tiles;
-    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     int rc;
     // entry of the stack, one launch: LayerNorm slice partials of the incoming rows, zeroed arrival counters + error word
     if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, n_tiles + 1, s))) return rc;
-    if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
     if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
         const unsigned short* ops[MPL_MAX_APPS * 4];
         for (int a = 0; a < n_apps; ++a) {

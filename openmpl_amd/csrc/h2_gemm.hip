@@ -84,9 +84,11 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
 #endif
 #ifndef H2_SCHED
-#define H2_SCHED 0     // schedule of a stage (A/B switch): bit 0 = all fragment reads of the next stage in ONE burst at the head
-                       // of the stage (waves 0..3) / behind the first product row (waves 4..7); bit 1 = the DMA refill at the
-                       // END of the stage (in the shadow of the barrier skew) instead of between the product rows
+#define H2_SCHED 4     // schedule of a stage (A/B switch, measured in one call on 32 / 256 workgroups: 0 = 1.026 / 1.125 ms per stack,
+                       // 1 = +1 %, 2 = +1.5 %, 3 = +3 %, 4 = -3 % / -1 %).  bit 0: all fragment reads of the next stage in ONE burst
+                       // at the head of the stage (waves 0..3) / behind the first product row (waves 4..7); bit 1: the DMA refill
+                       // at the END of the stage; bit 2 (default): the two waves of a SIMD out of phase -- waves 0..3 multiply
+                       // first and load afterwards, waves 4..7 the other way round
 #endif
 
 __host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
@@ -476,7 +478,9 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
 // CHAIN = false: the GEMM is a launch of its own.  CHAIN = true: one phase of h2_stack_kernel (see there): `chain` counts
 // the arrivals of the team, the A operand (and the LayerNorm partials) may be read once it reaches `chain_need`, and this
 // workgroup arrives when its outputs are written.  Returns false when the wait timed out (error words set, nothing computed).
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN>
+// WC = W pieces this wave requests per stage (1 for the waves 0..3, 4 for the waves 4, 5, 3 for the waves 6, 7): a template
+// parameter, so that neither the requests nor the counted waits need a branch in the k loop.
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = H2_NST;
@@ -500,7 +504,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
     // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.
     const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
-    const int w_cnt = HAS_A ? 1 : (wave < 6 ? 4 : 3);
+    constexpr int w_cnt = WC;
+    static_assert(HAS_A ? WC == 1 : (WC == 3 || WC == 4), "W pieces per wave");
     unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
     // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
@@ -519,6 +524,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     for (int g = 0; g < NPASS; ++g) is_w[g] = a.W2 + (size_t)(colbase(g) / BN) * KT * H2_W;
     const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
                            : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
+    // one W piece (i-th of this wave's run) / one A piece, for the schedules that spread the requests over the product rows
+    auto w_piece_i = [&](const char* src, unsigned dst, int i) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voW), "s"(src + i * 1024), "s"(dst + (unsigned)(i * 1024)) : "memory");
+    };
     auto w_pieces = [&](const char* src, unsigned dst) {
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
@@ -783,8 +792,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
-            if (w_cnt == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * WC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -808,8 +816,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (more) {
             if (FAST) {
                 if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
-                else if (w_cnt == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
                 // tail: every stage < T has been requested; conservative counts from the pieces per stage of this wave
                 const int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
@@ -1207,8 +1214,9 @@ __global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, 1>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 4>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 3>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -1261,16 +1269,18 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
                                    nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -1282,8 +1292,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
                     const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
                                    s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
             }

@@ -35,6 +35,10 @@ def test_lost_handoff_is_reported_never_ignored():
     lib = cabi.load()
     m = _model()
     P, R, C = _inputs(256, 1)
+    _lost_handoff(lib, m, P, R, C)
+
+
+def _lost_handoff(lib, m, P, R, C):
     with torch.no_grad():
         good = m(P, rays=R, centers=C)
         torch.cuda.synchronize()

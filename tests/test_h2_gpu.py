@@ -203,6 +203,21 @@ def test_x3_engine_still_matches_goldens(name):
     _assert_close(out, torch.from_numpy(g["out"]), name + " fp32x3")
 
 
+def _replica(m):
+    """What torch.nn.parallel.replicate does for one device: shallow copies of every module (through the module's own
+    _replicate_for_data_parallel) whose parameters are plain tensors sharing the originals' storage."""
+    mods = list(m.modules())
+    copies = {mod: mod._replicate_for_data_parallel() for mod in mods}
+    for mod, rep in copies.items():
+        for k, child in mod._modules.items():
+            rep._modules[k] = copies[child] if child is not None else None
+        for k, p in mod._parameters.items():
+            rep._parameters[k] = None if p is None else p.detach()
+        for k, b in mod._buffers.items():
+            rep._buffers[k] = b
+    return copies[m]
+
+
 def test_data_parallel_replicas_run_the_default_engine():
     """A DataParallel replica (torch re-creates them on every forward with fresh parameter storage, valid_mpl.py:177-178) packs its
     own operands and runs the default engine -- not the slower fp32 matrix instructions it fell back to in round 2."""
@@ -210,7 +225,7 @@ def test_data_parallel_replicas_run_the_default_engine():
     P, R, Cn = _big_inputs(64, 4, 3)
     with torch.no_grad():
         want = m(P, rays=R, centers=Cn)
-        rep = m._replicate_for_data_parallel()
+        rep = _replica(m)
         assert rep._dp_replica and rep._hip_cache == {}
         got = rep(P, rays=R, centers=Cn)
     assert torch.equal(got, want)
@@ -218,10 +233,22 @@ def test_data_parallel_replicas_run_the_default_engine():
     assert bool(blk.qkv_h2) and rep._hip_cache[0]["weights"].spt_packed
     m.set_matmul_precision("bf16")
     with pytest.warns(RuntimeWarning, match="DataParallel replicas"):
-        rep = m._replicate_for_data_parallel()
+        rep = _replica(m)
     with torch.no_grad():
         out = rep(P, rays=R, centers=Cn)            # replicas of the older engines: native fp32 MFMA kernels
     assert not rep._hip_cache[0]["keep"][4]
     mx, nw = mpl_oracle.rel_errors(out.cpu(), want.cpu())
     assert mx < 5e-6
     m.set_matmul_precision("fp32")
+
+
+
+def test_shipped_call_shape_b256_v2():
+    """configs/h36m/mpl_amass/h36m.yaml: TEST.BATCH_SIZE 256, two views, depth 12 -- the shape validate() actually calls with."""
+    m, g = _model("chosen_v2_b1_l12")
+    P, R, Cn = _big_inputs(256, 2, 77)
+    with torch.no_grad():
+        out = m(P, rays=R, centers=Cn)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
+    _assert_close(out, ref, "B=256 V=2 vs fp64 oracle")
