@@ -214,6 +214,38 @@ def timed_steps(model, batches, steps, warmup, lifter=None, global_batch=None):
         return time.perf_counter() - t0
 
 
+def stack_roofline(model, flags, batch, batches, precision, n_prof=5):
+    """Roofline-shaped entry of the dominant kernel (the persistent block-stack launch) of any configuration: mean launch
+    duration from HIP events on the launch stream, executed MFMA FLOP/s = algorithmic FLOPs x products per product x 144/136
+    column padding (x K padding of the bf16 engine), against the dense 16-bit matrix peak."""
+    import torch
+    from openmpl_amd import cabi
+    P, R, C = batches[0]
+    with torch.no_grad():
+        for _ in range(2):
+            model(P, rays=R, centers=C)
+        cabi.profile_start()
+        for _ in range(n_prof):
+            model(P, rays=R, centers=C)
+        torch.cuda.synchronize()
+        prof = cabi.profile_stop()
+    gemm_ms, gemm_n = prof["gemm"]
+    fl, gemms = gemm_flops_per_forward(flags, batch)
+    D = fpt_width(flags)
+    np_ = {"bf16": 1, "fp32": 2}.get(precision, 3)
+    kpad = ((-(-(D // 32) // 3) * 3) / (D // 32)) if np_ == 1 else 1.0
+    products = {3: 6.0, 2: 3.0, 1: 1.0}[np_]
+    launches = max(1, gemm_n // n_prof)
+    us = gemm_ms / max(1, gemm_n) * 1e3
+    ex = (fl / launches) * products * 144.0 / 136.0 * kpad / (us * 1e-6) / 1e12
+    total = sum(t for t, _ in prof.values())
+    return dict(kernel={1: "x3_stack_kernel<1>", 2: "h2_stack_kernel", 3: "x3_stack_kernel<3>"}[np_], bound="mfma",
+                launches_per_step=launches, avg_launch_us=round(us, 1), achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS,
+                unit="TFLOP/s", frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
+                share_of_kernel_time=round(gemm_ms / total, 3) if total else None)
+
+
 def time_cpu(flags, sd, P, R, C, budget_s, label):
     """Oracle (port of the reference CPU path) on the host cores: forwards of the given batch for ~budget_s seconds."""
     from oracle import mpl_oracle
@@ -516,12 +548,25 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
     r3 = mpl_oracle.forward(sd3, f3, cpu(P3, 64), cpu(R3, 64), cpu(C3, 64))
     mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
-    extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1),
+    roof16 = stack_roofline(m3, f3, a.batch, b3, "bf16")
+    extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1), "bf16_ms_per_step": round(a.batch / v16 * 1e3, 4),
+                              "bf16_roofline": roof16,
                               "bf16_tflops": round(v16 * mpl_oracle.flop_count(f3) / 1e12, 1),
                               "bf16_frac_of_bf16_peak": round(v16 * mpl_oracle.flop_count(f3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                               "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
                               "bf16_mpjpe_vs_ref": float("%.3e" % mpl_oracle.mpjpe(o16, r3))}
     del m3
+    # the same shape at depth 12 (config 3 at L = 2 and L = 12)
+    f3d = model_flags("chosen", 8, 12)
+    m3d = build_model(f3d, dev)
+    n3d = max(5, a.steps // 4)
+    v32d = a.batch * n3d / timed_steps(m3d, b3, n3d, 2)
+    m3d.set_matmul_precision("bf16")
+    v16d = a.batch * n3d / timed_steps(m3d, b3, n3d, 2)
+    extra["cmu_v8_depth12"] = {"fp32_poses_per_s": round(v32d, 1), "bf16_poses_per_s": round(v16d, 1),
+                               "bf16_ms_per_step": round(a.batch / v16d * 1e3, 4),
+                               "bf16_roofline": stack_roofline(m3d, f3d, a.batch, b3, "bf16")}
+    del m3d
     # PCIe-inclusive rate of the headline workload: the same forwards fed from pinned host tensors, H2D
     # of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
     host = [tuple([t.cpu().pin_memory() for t in lst] for lst in b) for b in batches[:2]]
