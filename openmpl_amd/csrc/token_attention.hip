@@ -165,13 +165,80 @@ __global__ __launch_bounds__(256) void token_attention_lds_kernel(const float* _
 // two passes, three LDS reads per (row, key): LDS-instruction bound, 504 us per launch at V = 31, B = 256.)
 // Same result as the reference's softmax(-1) up to the rounding of the (mathematically exact) rescaling.
 // NR query rows of one thread (i0, i0 + 256, ..) against all keys of the head
+// One chunk of CH keys for the NR rows of a thread.  FULL (compile time): every key of the chunk exists -- no masking at all;
+// else the chunk is the ragged last one.  The scores are kept in the exp2 domain: q was scaled by hd^-0.5 log2(e), so that
+// the softmax numerators are exp2(s - m) -- one v_exp_f32 per score, no multiply in front of it.
+template <int HD4, int NR, bool FULL>
+__device__ __forceinline__ void attend_chunk(const float4 (&q)[NR][HD4], float4 (&o)[NR][HD4], float (&m)[NR], float (&l)[NR],
+                                             const float* Ks, const float* Vs, int n_tok, int j0) {
+    constexpr int HD = 4 * HD4, CH = 16;
+    float sc[NR][CH];
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const int j = (FULL || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
+        float4 k[HD4];
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) k[c] = ld4(Ks + j * HD + 4 * c);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float s = q[r][0].x * k[0].x;
+            s = fmaf(q[r][0].y, k[0].y, s);
+            s = fmaf(q[r][0].z, k[0].z, s);
+            s = fmaf(q[r][0].w, k[0].w, s);
+#pragma unroll
+            for (int c = 1; c < HD4; ++c) {
+                s = fmaf(q[r][c].x, k[c].x, s);
+                s = fmaf(q[r][c].y, k[c].y, s);
+                s = fmaf(q[r][c].z, k[c].z, s);
+                s = fmaf(q[r][c].w, k[c].w, s);
+            }
+            sc[r][jj] = (FULL || j0 + jj < n_tok) ? s : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float mc = sc[r][0];
+#pragma unroll
+        for (int jj = 1; jj < CH; ++jj) mc = fmaxf(mc, sc[r][jj]);
+        // rescale what has been accumulated under the old maximum (factor 1 when the chunk does not raise it)
+        const float mn = fmaxf(m[r], mc);
+        const float f = __builtin_amdgcn_exp2f(m[r] - mn);
+        l[r] *= f;
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) { o[r][c].x *= f; o[r][c].y *= f; o[r][c].z *= f; o[r][c].w *= f; }
+        m[r] = mn;
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) sc[r][jj] = __builtin_amdgcn_exp2f(sc[r][jj] - mn);
+    }
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const int j = (FULL || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
+        float4 v[HD4];
+#pragma unroll
+        for (int c = 0; c < HD4; ++c) v[c] = ld4(Vs + j * HD + 4 * c);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float e = sc[r][jj];
+            l[r] += e;
+#pragma unroll
+            for (int c = 0; c < HD4; ++c) {
+                o[r][c].x = fmaf(e, v[c].x, o[r][c].x);
+                o[r][c].y = fmaf(e, v[c].y, o[r][c].y);
+                o[r][c].z = fmaf(e, v[c].z, o[r][c].z);
+                o[r][c].w = fmaf(e, v[c].w, o[r][c].w);
+            }
+        }
+    }
+}
+
 template <int HD4, int NR>
 __device__ __forceinline__ void attend_rows(const float* __restrict__ base, size_t ld, const float* Ks, const float* Vs,
                                             int n_tok, int i0, int stride, float scale, float* __restrict__ out_row0,
                                             size_t out_ld) {
-    constexpr int HD = 4 * HD4, CH = 16;
+    constexpr int CH = 16;
     float4 q[NR][HD4], o[NR][HD4];
     float m[NR], l[NR];
+    const float qs = scale * 1.4426950408889634f;        // scores in the exp2 domain
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int i = i0 + stride * r;
@@ -179,72 +246,15 @@ __device__ __forceinline__ void attend_rows(const float* __restrict__ base, size
 #pragma unroll
         for (int c = 0; c < HD4; ++c) {
             q[r][c] = ld4(base + ic * ld + 4 * c);
-            q[r][c].x *= scale; q[r][c].y *= scale; q[r][c].z *= scale; q[r][c].w *= scale;   // (q k) scale = (q scale) k up to rounding
+            q[r][c].x *= qs; q[r][c].y *= qs; q[r][c].z *= qs; q[r][c].w *= qs;
             o[r][c] = float4{0.f, 0.f, 0.f, 0.f};
         }
         m[r] = -INFINITY;
         l[r] = 0.f;
     }
-    for (int j0 = 0; j0 < n_tok; j0 += CH) {
-        float sc[NR][CH];
-        const bool full = j0 + CH <= n_tok;          // uniform: only the last chunk is ragged
-#pragma unroll
-        for (int jj = 0; jj < CH; ++jj) {
-            const int j = (full || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
-            float4 k[HD4];
-#pragma unroll
-            for (int c = 0; c < HD4; ++c) k[c] = ld4(Ks + j * HD + 4 * c);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float s = q[r][0].x * k[0].x;
-                s = fmaf(q[r][0].y, k[0].y, s);
-                s = fmaf(q[r][0].z, k[0].z, s);
-                s = fmaf(q[r][0].w, k[0].w, s);
-#pragma unroll
-                for (int c = 1; c < HD4; ++c) {
-                    s = fmaf(q[r][c].x, k[c].x, s);
-                    s = fmaf(q[r][c].y, k[c].y, s);
-                    s = fmaf(q[r][c].z, k[c].z, s);
-                    s = fmaf(q[r][c].w, k[c].w, s);
-                }
-                sc[r][jj] = (full || j0 + jj < n_tok) ? s : -INFINITY;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float mc = sc[r][0];
-#pragma unroll
-            for (int jj = 1; jj < CH; ++jj) mc = fmaxf(mc, sc[r][jj]);
-            // rescale what has been accumulated under the old maximum (factor 1 when the chunk does not raise it)
-            const float mn = fmaxf(m[r], mc);
-            const float f = __expf(m[r] - mn);
-            l[r] *= f;
-#pragma unroll
-            for (int c = 0; c < HD4; ++c) { o[r][c].x *= f; o[r][c].y *= f; o[r][c].z *= f; o[r][c].w *= f; }
-            m[r] = mn;
-#pragma unroll
-            for (int jj = 0; jj < CH; ++jj) sc[r][jj] = __expf(sc[r][jj] - mn);
-        }
-#pragma unroll
-        for (int jj = 0; jj < CH; ++jj) {
-            const int j = (full || j0 + jj < n_tok) ? j0 + jj : n_tok - 1;
-            float4 v[HD4];
-#pragma unroll
-            for (int c = 0; c < HD4; ++c) v[c] = ld4(Vs + j * HD + 4 * c);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float e = sc[r][jj];
-                l[r] += e;
-#pragma unroll
-                for (int c = 0; c < HD4; ++c) {
-                    o[r][c].x = fmaf(e, v[c].x, o[r][c].x);
-                    o[r][c].y = fmaf(e, v[c].y, o[r][c].y);
-                    o[r][c].z = fmaf(e, v[c].z, o[r][c].z);
-                    o[r][c].w = fmaf(e, v[c].w, o[r][c].w);
-                }
-            }
-        }
-    }
+    int j0 = 0;
+    for (; j0 + CH <= n_tok; j0 += CH) attend_chunk<HD4, NR, true>(q, o, m, l, Ks, Vs, n_tok, j0);
+    if (j0 < n_tok) attend_chunk<HD4, NR, false>(q, o, m, l, Ks, Vs, n_tok, j0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int i = i0 + stride * r;
