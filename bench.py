@@ -418,6 +418,19 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     else:
         spt_roof = dict(kernel="spt_kernel", instruction="v_mfma_f32_16x16x4_f32 + VALU attention", achieved=round(spt_t, 2),
                         peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(spt_t / PEAK_FP32_MFMA_TFLOPS, 4))
+    # second view of the same launch: the operand bytes it moves from L2 into LDS by LDS-DMA (26 KiB per stage = one k-tile of
+    # one pass: A 8 KiB + W 18 KiB, fp16x2 engine) against what that path delivers on this chip (tools/h2_probe.hip,
+    # profiles/r03_h2_probe.txt: 33 TB/s from an L2-resident shared region, 15 TB/s from per-workgroup regions beyond L2, 21 TB/s
+    # from the shared region beside the engine's MFMA + ds_read pattern): this, not the matrix pipe, is what bounds the kernel
+    lds_dma = None
+    if split and np_ == 2 and launches == 1:
+        stages = (flags["depth"] + 1) * 8 * (D // 32)            # per workgroup: (3 + 1 + 2) D/32 + 2 D/32 (fc2: K = 2 D) stages per application
+        tiles = -(-M // 64)
+        dma_bytes = float(stages) * 26624 * tiles * (D // 136)
+        lds_dma = dict(bytes_per_launch=dma_bytes, achieved=round(dma_bytes / (avg_launch_ms * 1e-3) / 1e12, 2), unit="TB/s",
+                       peak_beside_matrix_work=21.4, peak_l2_resident=33.4, peak_beyond_l2=15.0,
+                       frac_of_contended_peak=round(dma_bytes / (avg_launch_ms * 1e-3) / 1e12 / 21.4, 3),
+                       source="profiles/r03_h2_probe.txt")
     alg_bytes_per_gemm = alg_bytes
     alg_bytes *= gemms / launches             # per LAUNCH from here on (one launch = every GEMM of the stack by default)
     kernels = [dict(kernel=gemm_kernel, launches_per_step=launches, gemms_per_launch=gemms // launches, avg_launch_us=round(avg_launch_ms * 1e3, 2),
@@ -427,7 +440,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                dict(spt_roof, launches_per_step=1, avg_launch_us=round(spt_us, 2), flops_per_launch=spt_fl, bound="mfma",
                     share_of_kernel_time=round(spt_ms / sum(t for t, _ in prof.values()), 3))]
     roof.update(traffic=traffic, traffic_source=traffic_src,
-                traffic_ratio=(round(traffic / alg_bytes, 3) if traffic else None),
+                traffic_ratio=(round(traffic / alg_bytes, 3) if traffic else None), lds_dma=lds_dma,
                 avg_launch_us=round(avg_launch_ms * 1e3, 2),
                 launches_per_step=launches, gemms_per_launch=gemms // launches, flops_per_launch=fl / launches,
                 algorithmic_bytes_per_launch=round(alg_bytes), kernels=kernels,
