@@ -83,18 +83,10 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #ifndef H2_STAGGER
 #define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
 #endif
-#ifndef H2_KPS2
-#define H2_KPS2 0      // 1: the one-pass GEMMs with a packed A operand (proj, fc2) synchronise every SECOND stage: a barrier
-                       // publishes two stages at once; the refill then targets 5 stages ahead (one ring slot of slack).
-                       // Measured (tools/ab_check.sh, same call): 0.948 / 1.127 ms per stack with, 0.948 / 1.123 without (32 / 256
-                       // workgroups) -- no gain, so off: the stage time is not the barrier's
-#endif
 #ifndef H2_SCHED
-#define H2_SCHED 4     // schedule of a stage (A/B switch, measured in one call on 32 / 256 workgroups: 0 = 1.026 / 1.125 ms per stack,
-                       // 1 = +1 %, 2 = +1.5 %, 3 = +3 %, 4 = -3 % / -1 %).  bit 0: all fragment reads of the next stage in ONE burst
-                       // at the head of the stage (waves 0..3) / behind the first product row (waves 4..7); bit 1: the DMA refill
-                       // at the END of the stage; bit 2 (default): the two waves of a SIMD out of phase -- waves 0..3 multiply
-                       // first and load afterwards, waves 4..7 the other way round
+#define H2_SCHED 4     // 4 (default): the two waves of a SIMD out of phase -- waves 0..3 multiply first and load afterwards, waves 4..7
+                       // the other way round; 0: product rows, fragment reads and DMA requests interleaved (A/B: +1..3 % time).
+                       // Other orders that were measured and removed again: DESIGN.md section 4
 #endif
 
 __host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
@@ -490,12 +482,6 @@ template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = H2_NST;
-    // P2: one barrier per TWO stages.  At the barrier in front of an even stage e every wave has its pieces of the stages
-    // <= e + 2 landed and has finished reading the fragments of the stages <= e, so stage e may refill the slot of stage e - 1
-    // and stage e + 1 the slot of stage e: a refill goes DIST = NST - 1 stages ahead.  Only where the A operand arrives packed
-    // (no in-place conversion, whose publication would need the barrier in front of every A stage).
-    constexpr bool P2 = H2_KPS2 && NPASS == 1 && !LNF;
-    constexpr int DIST = P2 ? NST - 1 : NST;
     constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF, convert) the A pieces
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
@@ -536,10 +522,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     for (int g = 0; g < NPASS; ++g) is_w[g] = a.W2 + (size_t)(colbase(g) / BN) * KT * H2_W;
     const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
                            : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
-    // one W piece (i-th of this wave's run) / one A piece, for the schedules that spread the requests over the product rows
-    auto w_piece_i = [&](const char* src, unsigned dst, int i) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voW), "s"(src + i * 1024), "s"(dst + (unsigned)(i * 1024)) : "memory");
-    };
     auto w_pieces = [&](const char* src, unsigned dst) {
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
@@ -581,25 +563,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         ++ia_kt;
     };
-    // the same, one piece at a time (schedules that spread the requests over the product rows): j = 0, 1; the source
-    // position advances with the second piece
-    auto a_piece_j = [&](unsigned slot, int j) {
-        const unsigned dst = lds0 + slot + (unsigned)(wave * H2_RG + j * 1024);
-        if (!LNF) {
-            const char* src = is_a + j * 1024;
-            if (CHAIN) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(voA), "s"(src), "s"(dst) : "memory");
-            else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voA), "s"(src), "s"(dst) : "memory");
-            if (j) is_a += H2_RG;
-        } else {
-            const bool full = ia_kt < 4 * G;
-            const char* src = full ? is_a + (size_t)(136 * (ia_kt >> 2) + 32 * (ia_kt & 3)) * 4 : is_a + (size_t)(136 * 4 * (ia_kt - 4 * G)) * 4;
-            if (j) src += full ? 64 : 16;
-            const unsigned vo = full ? voA : voT;
-            if (CHAIN) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(vo), "s"(src), "s"(dst) : "memory");
-            else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(src), "s"(dst) : "memory");
-            if (j) ++ia_kt;
-        }
-    };
     auto issue_w = [&]() {
         const unsigned keep = dma_m0_save();
 #pragma unroll
@@ -635,11 +598,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (with_a && HAS_A) a_pieces(slot);
         dma_m0_restore(keep);
     };
-    // generic bookkeeping <- the state after fast stages, before generic stage t_next (slot = the ring slot of stage t_next)
+    // generic bookkeeping <- the state after fast stages, before generic stage t_next
     auto resync = [&](int t_next, unsigned slot) {
-        iw_t = ia_t = t_next + DIST;
+        iw_t = ia_t = t_next + NST;
         iw_g = iw_t % NPASS;
-        iw_slot = ia_slot = P2 ? (slot == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot - H2_STAGE) : slot;
+        iw_slot = ia_slot = slot;
     };
     static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
 
@@ -712,7 +675,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
     }
 #pragma unroll
-    for (int t = 1; t < DIST; ++t) {
+    for (int t = 1; t < NST; ++t) {
         issue_w();
         issue_a();
     }
@@ -791,8 +754,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     constexpr int A_ALLOW = LNF ? (NPASS == 1 ? 9 : 5) : (NPASS == 1 ? 12 : (NPASS == 2 ? 8 : 6));
     {   // stage 0 (LNF: and what the prologue converts) landed
         if (HAS_A) {
-            // P2: stages 0, 1, 2 landed, 3 and 4 (three pieces each) may stay in flight
-            constexpr int LATER = P2 ? 6 : (LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7)));
+            constexpr int LATER = LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
             if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
@@ -825,7 +787,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * WC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -839,27 +801,20 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // with the fragment reads of stage t+1 -- and, waves 0..3 of a LayerNorm GEMM, the in-place conversion of the A pieces
     // of stage t+2 (CV) -- in between.  FAST: a stage of the steady state (t + NST < T).
     auto stage = [&](auto fast_c, auto wp_c, auto ai_c, auto cv_c, int t, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
-                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a, auto sync_c) {
+                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a) {
         constexpr bool FAST = decltype(fast_c)::value;
-        constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
         const unsigned slot_n = slot_after(slot_c);
-        const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot_c - H2_STAGE;   // ring slot of stage t - 1
         const bool more = FAST || t + 1 < T;
         const bool cv = LNF && HAS_A && (FAST ? decltype(cv_c)::value : (t + 2 < T && (t + 2) % NPASS == 0));
         unsigned long long w0 = 0, w1 = 0;
         if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
-        if (more && SYNC) {
+        if (more) {
             if (FAST) {
-                if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
-                } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
+                if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
-                // tail: conservative counts from the pieces per stage of this wave.  Requested so far: every stage < T, or (P2,
-                // where a refill goes DIST stages ahead) the stages <= t + DIST - 1
-                int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
-                if (P2 && later > DIST - 2) later = DIST - 2;
+                // tail: every stage < T has been requested; conservative counts from the pieces per stage of this wave
+                const int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
                 const int per = HAS_A ? (NPASS == 1 ? 3 : 1) : w_cnt;
                 wait_vm(later > 0 ? later * per : 0);
             }
@@ -878,7 +833,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         };
         auto refill = [&]() {
             if constexpr (FAST) {
-                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, P2 ? slot_p : slot_c);
+                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, slot_c);
             } else {
                 if (more && iw_t < T && !((H2_ABL & 2) && t > 0)) {
                     issue_w();
@@ -891,47 +846,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
             rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
         };
-        if constexpr ((H2_SCHED & 8) != 0 && FAST) {
-            // one DMA request behind every product row instead of a burst of 3-4: the TA of the CU takes ~19-29 cycles per KiB,
-            // a burst from several waves at once makes each of them wait for all the others
-            constexpr int g = decltype(wp_c)::value;
-            constexpr bool with_a = decltype(ai_c)::value && HAS_A;
-            const unsigned rslot = P2 ? slot_p : slot_c;
-            const unsigned wdst = lds0 + rslot + (unsigned)(H2_A + w_first * 1024);
-            const unsigned keep = dma_m0_save();
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(accp, a_cur[1], b_cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(H2_ABL & 2)) w_piece_i(is_w[g], wdst, 0);
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            rd_b(0);
-            if (!next_has_a) rd_b(1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(accp, a_cur[0], b_cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(H2_ABL & 2)) {
-                if (WC > 1) w_piece_i(is_w[g], wdst, 1);
-                else if (with_a) a_piece_j(rslot, 0);
-            }
-            if (next_has_a) rd_b(1);
-            rd_b(2);
-            if (cv) convert(slot_after(slot_n));
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(accp, a_cur[0], b_cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(H2_ABL & 2)) {
-                if (WC > 2) w_piece_i(is_w[g], wdst, 2);
-                if (WC > 3) w_piece_i(is_w[g], wdst, 3);
-                if (WC == 1 && with_a) a_piece_j(rslot, 1);
-            }
-            rd_b(3);
-            rd_b(4);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_m0_restore(keep);
-            is_w[g] += H2_W;
-            slot_c = slot_n;
-            return;
-        }
         if constexpr ((H2_SCHED & 4) != 0) {
             // the two waves of a SIMD out of phase: waves 0..3 multiply first and load afterwards, waves 4..7 the other way
             // round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe
@@ -955,34 +869,24 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             return;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if ((H2_SCHED & 1) && HAS_A) all_reads();
-        __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[1], b_cur, 0);             // lo . hi
         __builtin_amdgcn_sched_barrier(0);
-        if ((H2_SCHED & 1) && !HAS_A) all_reads();
-        if (!(H2_SCHED & 2) && !(H2_STAGGER && !HAS_A)) refill();
-        if (!(H2_SCHED & 1)) {
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            rd_b(0);
-            if (!next_has_a) rd_b(1);
-        }
+        if (!(H2_STAGGER && !HAS_A)) refill();
+        if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+        rd_b(0);
+        if (!next_has_a) rd_b(1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 1);             // hi . lo
         __builtin_amdgcn_sched_barrier(0);
-        if (!(H2_SCHED & 1)) {
-            if (next_has_a) rd_b(1);
-            rd_b(2);
-        }
-        if (!(H2_SCHED & 2) && H2_STAGGER && !HAS_A) refill();
+        if (next_has_a) rd_b(1);
+        rd_b(2);
+        if (H2_STAGGER && !HAS_A) refill();
         if (cv) convert(slot_after(slot_n));
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 0);             // hi . hi
         __builtin_amdgcn_sched_barrier(0);
-        if (!(H2_SCHED & 1)) {
-            rd_b(3);
-            rd_b(4);
-        }
-        if (H2_SCHED & 2) refill();
+        rd_b(3);
+        rd_b(4);
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };
@@ -995,65 +899,63 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     using AN = std::integral_constant<bool, false>;
     using CY = std::integral_constant<bool, true>;
     using CN = std::integral_constant<bool, false>;
-    using SY = std::integral_constant<bool, true>;
-    using SN = std::integral_constant<bool, false>;
     // head -> steady state (fast) -> tail (generic).  Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of
     // stage t + 2 when (j + 2) % NPASS == 0.
     if constexpr (NPASS == 1) {
         int kt = 0;
         for (; kt + 1 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
-            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true, SN{});
+            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
         }
         resync(kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true);
         }
-        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
+        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
     } else if constexpr (NPASS == 2) {
         int kt = 0;
         for (; 2 * kt + 3 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
         }
         resync(2 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
         }
         if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
         }
     } else {
         // three stages per k-tile flip the B parity every k-tile
         int kt = 0;
         for (; 3 * kt + 5 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
         }
         resync(3 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
         }
         if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
         }
     }
 
