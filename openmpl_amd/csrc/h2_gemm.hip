@@ -83,6 +83,19 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #ifndef H2_STAGGER
 #define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
 #endif
+#ifndef H2_REBAL
+#define H2_REBAL 1     // 1: in LayerNorm GEMMs the waves 0..3 request no W piece (waves 4, 5 five, waves 6, 7 four); 0: as in the plain GEMMs
+#endif
+#ifndef H2_CVSPLIT
+#define H2_CVSPLIT 1   // 1: in-place conversion read in front of the product rows, converted + written behind them; 0: in one piece behind
+#endif
+#ifndef H2_KPS2
+#define H2_KPS2 1      // 1: the one-pass GEMMs with a packed A operand (proj, fc2) synchronise every SECOND stage: a barrier
+                       // publishes two stages at once; the refill then targets 5 stages ahead (one ring slot of slack)
+#endif
+#ifndef H2_PHASE_MAJOR
+#define H2_PHASE_MAJOR 0
+#endif
 #ifndef H2_SCHED
 #define H2_SCHED 4     // 4 (default): the two waves of a SIMD out of phase -- waves 0..3 multiply first and load afterwards, waves 4..7
                        // the other way round; 0: product rows, fragment reads and DMA requests interleaved (A/B: +1..3 % time).
@@ -482,6 +495,12 @@ template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = H2_NST;
+    // P2: one barrier per TWO stages in the one-pass GEMMs with a packed A operand (proj, fc2).  At the barrier in front of an
+    // even stage e every wave has its pieces of the stages <= e + 2 landed and has finished reading the fragments of the
+    // stages <= e, so stage e may refill the slot of stage e - 1 and stage e + 1 the slot of stage e: a refill goes
+    // DIST = NST - 1 stages ahead.  Not where the A operand is converted in place (its publication needs every barrier).
+    constexpr bool P2 = H2_KPS2 && NPASS == 1 && !LNF;
+    constexpr int DIST = P2 ? NST - 1 : NST;
     constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF, convert) the A pieces
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
@@ -501,9 +520,16 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
 
     // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
     // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.
-    const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
+    // Plain A operand: waves 0..3 one W piece (14 + w) besides their two A pieces, waves 4, 5 four (0..3 / 4..7), waves 6, 7
+    // three (8..10 / 11..13).  LayerNorm GEMMs: the waves 0..3 also convert the A pieces in place, which made them the slow
+    // half of every stage (tools/chain_phase.py: 700 cycles of reads + requests + conversion per stage against 495 in the
+    // waves 4..7, which then sat 450 cycles at the barrier) -- there they request NO W piece, the waves 4, 5 take five
+    // (0..4 / 5..9), the waves 6, 7 four (10..13 / 14..17).
+    constexpr bool RB = LNF && H2_REBAL;
+    const int w_first = RB ? (HAS_A ? 0 : (wave < 6 ? 5 * (wave - 4) : 10 + 4 * (wave - 6)))
+                           : (HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6)));
     constexpr int w_cnt = WC;
-    static_assert(HAS_A ? WC == 1 : (WC == 3 || WC == 4), "W pieces per wave");
+    static_assert(RB ? (HAS_A ? WC == 0 : (WC == 4 || WC == 5)) : (HAS_A ? WC == 1 : (WC == 3 || WC == 4)), "W pieces per wave");
     unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
     // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
@@ -523,6 +549,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
                            : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
     auto w_pieces = [&](const char* src, unsigned dst) {
+        if (w_cnt == 0) return;
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
@@ -535,6 +562,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
         }
         if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
+        if (w_cnt > 4)      // the instruction offset is 13 bits signed: the fifth piece gets its own base and M0
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voW), "s"(src + 4096), "s"(dst + 4096u) : "memory");
     };
     // the two A pieces of this wave's row group for A k-tile ia_kt into stage slot `slot` (waves 0..3; M0 is the caller's)
     auto a_pieces = [&](unsigned slot) {
@@ -600,9 +629,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     };
     // generic bookkeeping <- the state after fast stages, before generic stage t_next
     auto resync = [&](int t_next, unsigned slot) {
-        iw_t = ia_t = t_next + NST;
+        iw_t = ia_t = t_next + DIST;
         iw_g = iw_t % NPASS;
-        iw_slot = ia_slot = slot;
+        iw_slot = ia_slot = P2 ? (slot == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot - H2_STAGE) : slot;
     };
     static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
 
@@ -675,7 +704,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
     }
 #pragma unroll
-    for (int t = 1; t < NST; ++t) {
+    for (int t = 1; t < DIST; ++t) {
         issue_w();
         issue_a();
     }
@@ -707,6 +736,31 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // ---- LNF: normalise + split the raw fp32 A pieces of a stage IN PLACE (waves 0..3, each its own row group: the wave
     // that requested the bytes waits for them with its own vmcnt, no other wave touches them before the next barrier)
     float cv_a = 0.f, cv_b = 0.f;               // z = x cv_a + cv_b = (x - mean) rstd 2^10
+    // in two halves for the k loop: the raw values are READ before the product rows of the stage and converted + written
+    // behind them -- in one piece behind the rows, the LDS round trip of the read (and ~450 cycles in all) sat on the
+    // critical path of the waves 0..3 (tools/chain_phase.py)
+    float4 cvr0 = {0.f, 0.f, 0.f, 0.f}, cvr1 = {0.f, 0.f, 0.f, 0.f};
+    auto convert_load = [&](unsigned slot) {
+        if (H2_ABL & 16) return;
+        const char* p = smem + slot + wave * H2_RG + lane * 16;
+        cvr0 = *reinterpret_cast<const float4*>(p);
+        cvr1 = *reinterpret_cast<const float4*>(p + 1024);
+    };
+    auto convert_store = [&](unsigned slot) {
+        if (H2_ABL & 16) return;
+        char* p = smem + slot + wave * H2_RG + lane * 16;
+        float z[8] = {cvr0.x, cvr0.y, cvr0.z, cvr0.w, cvr1.x, cvr1.y, cvr1.z, cvr1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            z[j] = fmaf(z[j], cv_a, cv_b);
+            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);
+            if (!row_ok) z[j] = 0.f;
+        }
+        f16x8 hi, lo;
+        split2(z, hi, lo);
+        *reinterpret_cast<f16x8*>(p) = hi;
+        *reinterpret_cast<f16x8*>(p + 1024) = lo;
+    };
     auto convert = [&](unsigned slot) {
         if (H2_ABL & 16) return;
         char* p = smem + slot + wave * H2_RG + lane * 16;
@@ -751,10 +805,15 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // pieces in the A stages (every NPASS-th).  Stages t+1 (.. t+5) are in flight when stage t starts; the waves 4..7 need
     // their pieces of stage t+1, the waves 0..3 of stage t+2 when they convert it during stage t (LNF) else of stage t+1.
     // Smallest number of pieces of this wave in the stages that may stay in flight:
-    constexpr int A_ALLOW = LNF ? (NPASS == 1 ? 9 : 5) : (NPASS == 1 ? 12 : (NPASS == 2 ? 8 : 6));
+    // (waves 0..3 of a LayerNorm GEMM request only their two A pieces, in the A stages: of any three consecutive stages one
+    // (NPASS = 3), one or two (NPASS = 2), all three (NPASS = 1) are A stages)
+    constexpr int A_ALLOW = RB ? (NPASS == 1 ? 6 : 2) : (LNF ? (NPASS == 1 ? 9 : 5) : (NPASS == 1 ? 12 : (NPASS == 2 ? 8 : 6)));
     {   // stage 0 (LNF: and what the prologue converts) landed
         if (HAS_A) {
-            constexpr int LATER = LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7));
+            // LNF: the A pieces of the stages after those the prologue converts (stage 0; 0 and 1 for NPASS = 1)
+            // P2: stages 0, 1, 2 landed, 3 and 4 (three pieces each) may stay in flight
+            constexpr int LATER = P2 ? 6 : RB ? (NPASS == 1 ? 8 : (NPASS == 2 ? 4 : 2))
+                                     : (LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7)));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
             if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
@@ -787,7 +846,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * WC) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -795,27 +854,33 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         read_b(0, B0);
     }
     const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    unsigned long long t_vm = 0, t_bar = 0;
+    unsigned long long t_vm = 0, t_bar = 0, t_mm = 0;      // bench-only sums: counted DMA wait, lgkm + barrier, the MFMA rows of a stage
     unsigned slot_c = 0;
     // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage t
     // with the fragment reads of stage t+1 -- and, waves 0..3 of a LayerNorm GEMM, the in-place conversion of the A pieces
     // of stage t+2 (CV) -- in between.  FAST: a stage of the steady state (t + NST < T).
     auto stage = [&](auto fast_c, auto wp_c, auto ai_c, auto cv_c, int t, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
-                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a) {
+                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a, auto sync_c) {
         constexpr bool FAST = decltype(fast_c)::value;
+        constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
         const unsigned slot_n = slot_after(slot_c);
+        const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot_c - H2_STAGE;   // ring slot of stage t - 1
         const bool more = FAST || t + 1 < T;
         const bool cv = LNF && HAS_A && (FAST ? decltype(cv_c)::value : (t + 2 < T && (t + 2) % NPASS == 0));
         unsigned long long w0 = 0, w1 = 0;
         if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
-        if (more) {
+        if (more && SYNC) {
             if (FAST) {
-                if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
+                if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
+                    if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
+                } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
                 // tail: every stage < T has been requested; conservative counts from the pieces per stage of this wave
-                const int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
-                const int per = HAS_A ? (NPASS == 1 ? 3 : 1) : w_cnt;
+                int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
+                if (P2 && later > DIST - 2) later = DIST - 2;     // P2: requested so far are only the stages <= t + DIST - 1
+                const int per = HAS_A ? (RB ? (NPASS == 1 ? 2 : 0) : (NPASS == 1 ? 3 : 1)) : w_cnt;
                 wait_vm(later > 0 ? later * per : 0);
             }
             if (H2_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
@@ -833,7 +898,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         };
         auto refill = [&]() {
             if constexpr (FAST) {
-                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, slot_c);
+                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, P2 ? slot_p : slot_c);
             } else {
                 if (more && iw_t < T && !((H2_ABL & 2) && t > 0)) {
                     issue_w();
@@ -855,14 +920,24 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 refill();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            unsigned long long m0 = 0;
+            if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
+            if (HAS_A && cv && H2_CVSPLIT) {
+                convert_load(slot_after(slot_n));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mfma_row(accp, a_cur[1], b_cur, 0);
             mfma_row(accp, a_cur[0], b_cur, 1);
             mfma_row(accp, a_cur[0], b_cur, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
             if (HAS_A) {
                 all_reads();
                 refill();
-                if (cv) convert(slot_after(slot_n));
+                if (cv) {
+                    if (H2_CVSPLIT) convert_store(slot_after(slot_n));
+                    else convert(slot_after(slot_n));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot_c = slot_n;
@@ -899,63 +974,65 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     using AN = std::integral_constant<bool, false>;
     using CY = std::integral_constant<bool, true>;
     using CN = std::integral_constant<bool, false>;
+    using SY = std::integral_constant<bool, true>;
+    using SN = std::integral_constant<bool, false>;
     // head -> steady state (fast) -> tail (generic).  Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of
     // stage t + 2 when (j + 2) % NPASS == 0.
     if constexpr (NPASS == 1) {
         int kt = 0;
         for (; kt + 1 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true);
-            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
+            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true, SN{});
         }
         resync(kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
-            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true, SY{});
         }
-        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true);
+        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
     } else if constexpr (NPASS == 2) {
         int kt = 0;
         for (; 2 * kt + 3 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
+            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
+            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
         }
         resync(2 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
         }
         if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
         }
     } else {
         // three stages per k-tile flip the B parity every k-tile
         int kt = 0;
         for (; 3 * kt + 5 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
+            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
+            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
+            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
         }
         resync(3 * kt, slot_c);
         for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
         }
         if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false);
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true);
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
+            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
         }
     }
 
@@ -1175,7 +1252,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
             unsigned long long* o = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
-            o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar;
+            o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar; o[7] = t_mm;
         }
     }
     return true;
@@ -1199,9 +1276,9 @@ __global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, 1>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 4>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 3>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, ((LNF && H2_REBAL) ? 0 : 1)>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, ((LNF && H2_REBAL) ? 5 : 4)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, ((LNF && H2_REBAL) ? 4 : 3)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -1237,12 +1314,17 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     auto vecs = [&](const char* w2, int N, int K) -> const float* {
         return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
     };
-    // With more row tiles than teams a team walks ITS tiles phase by phase (phase p of every tile, then phase p + 1): the
-    // hand-off latency of one tile (team mates finishing, the first operand pieces crossing the fabric) hides behind the k loop
-    // of the next one, and the weights of a phase are still in L2 for the second tile.
+#if H2_PHASE_MAJOR
+    // a team walks ITS tiles phase by phase (phase p of every tile, then phase p + 1).  Measured: no gain with two tiles per
+    // team, and the loop nest costs 3-5 % through the code the compiler makes of it (more scalar spills inside the phases)
     unsigned need = 0;
     for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
         for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
+#else
+    for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
+        unsigned need = 0;
+        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+#endif
             int tidp = tid, tile = tile0, tnp = tn;
             asm volatile("" : "+v"(tidp));
             asm volatile("" : "+s"(tile), "+s"(tnp));
@@ -1257,18 +1339,18 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, (H2_REBAL ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, (H2_REBAL ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, (H2_REBAL ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
                                    nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, (H2_REBAL ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, (H2_REBAL ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, (H2_REBAL ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both

@@ -34,4 +34,11 @@ for stop in range(4 * (NB - 1) - 1, 4 * NB + 1):
     print("stop %2d %-9s waves %4d | entry->loop %6.0f (min %6.0f max %6.0f) | k loop %7.0f (%5.0f/stage, %d stages) | epilogue %6.0f | drain %5.0f | total %7.0f | DMA wait/stage %4.0f  bar/stage %4.0f"
           % (stop, names[ph], len(t), (loop - ent).mean(), (loop - ent).min(), (loop - ent).max(), (epi - loop).mean(), (epi - loop).mean() / nst, nst,
              (sto - epi).mean(), (end - sto).mean(), (end - ent).mean(), t[:, 5].mean() / nst, t[:, 6].mean() / nst))
+    # by wave role (rows of t are (block, wave): wave = index % 8): per stage DMA wait | lgkm + barrier | MFMA rows | everything else
+    for role, sel in (("waves 0-3 (5 tiles, A pieces)", np.arange(len(t)) % 8 < 4), ("waves 4-7 (4 tiles)", np.arange(len(t)) % 8 >= 4)):
+        if sel.sum() and t.shape[1] > 7:
+            u = t[sel]
+            kl = (u[:, 2] - u[:, 1])
+            print("      %-30s per stage: DMA wait %4.0f | lgkm+barrier %4.0f | MFMA rows %4.0f | rest (reads, DMA requests, conversion, scalar) %4.0f"
+                  % (role, u[:, 5].mean() / nst, u[:, 6].mean() / nst, u[:, 7].mean() / nst, (kl - u[:, 5] - u[:, 6] - u[:, 7]).mean() / nst))
 lib.mpl_x3_stack_mode(0)
