@@ -627,12 +627,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (with_a && HAS_A) a_pieces(slot);
         dma_m0_restore(keep);
     };
-    // generic bookkeeping <- the state after fast stages, before generic stage t_next
-    auto resync = [&](int t_next, unsigned slot) {
-        iw_t = ia_t = t_next + DIST;
-        iw_g = iw_t % NPASS;
-        iw_slot = ia_slot = P2 ? (slot == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot - H2_STAGE) : slot;
-    };
     static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
 
     // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue)
@@ -725,7 +719,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         }
     };
-    const int t_ops = T - 4;                    // always a generic stage (the fast ones end before T - NST)
 
     f32x4 acc[NPASS][NTW];
 #pragma unroll
@@ -858,15 +851,24 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     unsigned slot_c = 0;
     // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage t
     // with the fragment reads of stage t+1 -- and, waves 0..3 of a LayerNorm GEMM, the in-place conversion of the A pieces
-    // of stage t+2 (CV) -- in between.  FAST: a stage of the steady state (t + NST < T).
-    auto stage = [&](auto fast_c, auto wp_c, auto ai_c, auto cv_c, int t, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
-                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], bool next_has_a, auto sync_c) {
-        constexpr bool FAST = decltype(fast_c)::value;
+    // of stage t+2 (CV) -- in between.  REM = 0: a stage of the steady state (t + NST < T); REM > 0: a stage of the tail with
+    // REM stages left including this one -- a compile-time number, so that the counted waits, the last refills and the end of
+    // the fragment reads need neither bookkeeping nor branches (a tail stage with run-time bookkeeping cost ~1500 cycles
+    // against ~800 of a steady-state one, and a quarter of all stages are tail stages).
+    auto stage = [&](auto rem_c, auto wp_c, auto ai_c, auto cv_c, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
+                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], auto nha_c, auto sync_c) {
+        constexpr int REM = decltype(rem_c)::value;
+        constexpr bool FAST = REM == 0;
         constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
+        constexpr bool next_has_a = decltype(nha_c)::value;
+        constexpr bool more = FAST || REM > 1;
+        constexpr bool cv = LNF && HAS_A && decltype(cv_c)::value && (FAST || REM > 2);
+        constexpr bool RF = FAST || REM > DIST;                              // this stage requests stage t + DIST
+        // the ring position is opaque here: in the straight-line tail the compiler otherwise forms the LDS addresses of all the
+        // remaining stages up front (+40 VGPRs, spills)
+        asm volatile("" : "+s"(slot_c));
         const unsigned slot_n = slot_after(slot_c);
         const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot_c - H2_STAGE;   // ring slot of stage t - 1
-        const bool more = FAST || t + 1 < T;
-        const bool cv = LNF && HAS_A && (FAST ? decltype(cv_c)::value : (t + 2 < T && (t + 2) % NPASS == 0));
         unsigned long long w0 = 0, w1 = 0;
         if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
         if (more && SYNC) {
@@ -877,11 +879,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
-                // tail: every stage < T has been requested; conservative counts from the pieces per stage of this wave
-                int later = HAS_A ? (LNF ? T - 3 - t : T - 2 - t) : T - 2 - t;
-                if (P2 && later > DIST - 2) later = DIST - 2;     // P2: requested so far are only the stages <= t + DIST - 1
-                const int per = HAS_A ? (RB ? (NPASS == 1 ? 2 : 0) : (NPASS == 1 ? 3 : 1)) : w_cnt;
-                wait_vm(later > 0 ? later * per : 0);
+                // tail.  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed: <= t + 1 (<= t + 2 where this wave
+                // converts).  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
+                constexpr int need = (LNF && HAS_A) ? 2 : 1;
+                constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - need;
+                constexpr int per = HAS_A ? (RB ? (NPASS == 1 ? 2 : 0) : (NPASS == 1 ? 3 : 1)) : WC;
+                constexpr int allow = ahead > 0 ? ahead * per : 0;
+                static_assert(allow < 64, "vmcnt is 6 bits");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
             }
             if (H2_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -897,15 +902,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         };
         auto refill = [&]() {
-            if constexpr (FAST) {
-                if (!(H2_ABL & 2)) refill_fast(wp_c, ai_c, P2 ? slot_p : slot_c);
-            } else {
-                if (more && iw_t < T && !((H2_ABL & 2) && t > 0)) {
-                    issue_w();
-                    issue_a();
-                }
-                if (t == t_ops) epilogue_operands();
-            }
+            if (RF && !(H2_ABL & 2)) refill_fast(wp_c, ai_c, P2 ? slot_p : slot_c);
+            if (REM == 4) epilogue_operands();
         };
         auto all_reads = [&]() {
             if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
@@ -965,76 +963,57 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };
-    using GEN = std::integral_constant<bool, false>;
-    using FST = std::integral_constant<bool, true>;
     using W0 = std::integral_constant<int, 0>;
     using W1 = std::integral_constant<int, 1>;
     using W2 = std::integral_constant<int, 2>;
-    using AY = std::integral_constant<bool, true>;
-    using AN = std::integral_constant<bool, false>;
-    using CY = std::integral_constant<bool, true>;
-    using CN = std::integral_constant<bool, false>;
-    using SY = std::integral_constant<bool, true>;
-    using SN = std::integral_constant<bool, false>;
-    // head -> steady state (fast) -> tail (generic).  Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of
-    // stage t + 2 when (j + 2) % NPASS == 0.
-    if constexpr (NPASS == 1) {
-        int kt = 0;
-        for (; kt + 1 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
-            stage(FST{}, W0{}, AY{}, CY{}, kt + 1, acc[0], A1, A0, B1, B0, true, SN{});
+    using YES = std::integral_constant<bool, true>;
+    using NO = std::integral_constant<bool, false>;
+    // Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of stage t + 2 when (j + 2) % NPASS == 0; the
+    // fragment registers alternate per k-tile (A) and per stage (B).  POS = t mod 2 NPASS picks the row of that table.
+    constexpr int U = 2 * NPASS;
+    auto step = [&](auto rem_c, auto pos_c) {
+        constexpr int POS = decltype(pos_c)::value;
+        if constexpr (NPASS == 1) {
+            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A0, A1, B0, B1, YES{}, YES{});
+            else stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A0, B1, B0, YES{}, NO{});
+        } else if constexpr (NPASS == 2) {
+            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, NO{}, acc[1], A0, A1, B1, B0, YES{}, YES{});
+            else if constexpr (POS == 2) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A1, B0, B1, NO{}, YES{});
+            else stage(rem_c, W1{}, NO{}, NO{}, acc[1], A1, A0, B1, B0, YES{}, YES{});
+        } else {
+            // three stages per k-tile flip the B parity every k-tile
+            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A0, A0, B1, B0, NO{}, YES{});
+            else if constexpr (POS == 2) stage(rem_c, W2{}, NO{}, NO{}, acc[2], A0, A1, B0, B1, YES{}, YES{});
+            else if constexpr (POS == 3) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A1, A1, B1, B0, NO{}, YES{});
+            else if constexpr (POS == 4) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A1, A1, B0, B1, NO{}, YES{});
+            else stage(rem_c, W2{}, NO{}, NO{}, acc[2], A1, A0, B1, B0, YES{}, YES{});
         }
-        resync(kt, slot_c);
-        for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, kt + 1, acc[0], A1, A0, B1, B0, true, SY{});
+    };
+    auto tail = [&](auto self, auto rem_c, auto pos_c) -> void {
+        constexpr int REM = decltype(rem_c)::value, POS = decltype(pos_c)::value;
+        step(rem_c, pos_c);
+        if constexpr (REM > 1) self(self, std::integral_constant<int, REM - 1>{}, std::integral_constant<int, (POS + 1) % U>{});
+    };
+    using R0 = std::integral_constant<int, 0>;
+    // steady state: whole groups of U stages while the last of them still has a stage to request; what is left is NST or
+    // NST + NPASS stages (T = NPASS KT is 0 or NPASS modulo U), both starting at POS 0
+    int t = 0;
+    for (; t + U - 1 + NST < T; t += U) {
+        step(R0{}, std::integral_constant<int, 0>{});
+        step(R0{}, std::integral_constant<int, 1 % U>{});
+        if constexpr (NPASS >= 2) {
+            step(R0{}, std::integral_constant<int, 2 % U>{});
+            step(R0{}, std::integral_constant<int, 3 % U>{});
         }
-        if (kt < KT) stage(GEN{}, W0{}, AY{}, CN{}, kt, acc[0], A0, A1, B0, B1, true, SY{});
-    } else if constexpr (NPASS == 2) {
-        int kt = 0;
-        for (; 2 * kt + 3 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
-            stage(FST{}, W0{}, AY{}, CY{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
-        }
-        resync(2 * kt, slot_c);
-        for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 2, acc[0], A1, A1, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 3, acc[1], A1, A0, B1, B0, true, SY{});
-        }
-        if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 2 * kt + 1, acc[1], A0, A1, B1, B0, true, SY{});
-        }
-    } else {
-        // three stages per k-tile flip the B parity every k-tile
-        int kt = 0;
-        for (; 3 * kt + 5 + NST < T; kt += 2) {
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
-            stage(FST{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
-            stage(FST{}, W1{}, AN{}, CY{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
-            stage(FST{}, W2{}, AN{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
-        }
-        resync(3 * kt, slot_c);
-        for (; kt + 1 < KT; kt += 2) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 3, acc[0], A1, A1, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 4, acc[1], A1, A1, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 5, acc[2], A1, A0, B1, B0, true, SY{});
-        }
-        if (kt < KT) {
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt, acc[0], A0, A0, B0, B1, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 1, acc[1], A0, A0, B1, B0, false, SY{});
-            stage(GEN{}, W0{}, AY{}, CN{}, 3 * kt + 2, acc[2], A0, A1, B0, B1, true, SY{});
+        if constexpr (NPASS == 3) {
+            step(R0{}, std::integral_constant<int, 4 % U>{});
+            step(R0{}, std::integral_constant<int, 5 % U>{});
         }
     }
+    if (T - t == NST) tail(tail, std::integral_constant<int, NST>{}, std::integral_constant<int, 0>{});
+    else tail(tail, std::integral_constant<int, NST + NPASS>{}, std::integral_constant<int, 0>{});
 
     // ------------------------------------------------------------------------------------------ epilogue
     const unsigned long long t_epi = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
