@@ -525,7 +525,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // half of every stage (tools/chain_phase.py: 700 cycles of reads + requests + conversion per stage against 495 in the
     // waves 4..7, which then sat 450 cycles at the barrier) -- there they request NO W piece, the waves 4, 5 take five
     // (0..4 / 5..9), the waves 6, 7 four (10..13 / 14..17).
-    constexpr bool RB = LNF && H2_REBAL;
+    constexpr bool RB = LNF ? (H2_REBAL & 1) != 0 : (H2_REBAL & 2) != 0;
     const int w_first = RB ? (HAS_A ? 0 : (wave < 6 ? 5 * (wave - 4) : 10 + 4 * (wave - 6)))
                            : (HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6)));
     constexpr int w_cnt = WC;
@@ -800,13 +800,17 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // Smallest number of pieces of this wave in the stages that may stay in flight:
     // (waves 0..3 of a LayerNorm GEMM request only their two A pieces, in the A stages: of any three consecutive stages one
     // (NPASS = 3), one or two (NPASS = 2), all three (NPASS = 1) are A stages)
-    constexpr int A_ALLOW = RB ? (NPASS == 1 ? 6 : 2) : (LNF ? (NPASS == 1 ? 9 : 5) : (NPASS == 1 ? 12 : (NPASS == 2 ? 8 : 6)));
+    // -> pieces of this wave in S consecutive stages, at least: S WC + 2 (A stages among them: S, S / 2, S / 3 for NPASS 1, 2, 3)
+    constexpr int S_ALLOW = LNF ? 3 : 4;
+    constexpr int A_ALLOW = S_ALLOW * WC + 2 * (S_ALLOW / NPASS);
+    constexpr int PA = WC + (HAS_A ? 2 : 0);     // pieces of this wave in a stage that carries A
     {   // stage 0 (LNF: and what the prologue converts) landed
         if (HAS_A) {
             // LNF: the A pieces of the stages after those the prologue converts (stage 0; 0 and 1 for NPASS = 1)
             // P2: stages 0, 1, 2 landed, 3 and 4 (three pieces each) may stay in flight
-            constexpr int LATER = P2 ? 6 : RB ? (NPASS == 1 ? 8 : (NPASS == 2 ? 4 : 2))
-                                     : (LNF ? (NPASS == 1 ? 12 : (NPASS == 2 ? 9 : 7)) : (NPASS == 1 ? 15 : (NPASS == 2 ? 9 : 7)));
+            // (the A stages among the stages 1 .. 5 are 5 / 2 / 1 of them for NPASS 1 / 2 / 3; NPASS = 1 converts stage 1 here as well)
+            constexpr int LATER = P2 ? 2 * PA
+                                     : (LNF && NPASS == 1) ? 4 * PA : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
             if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
@@ -874,7 +878,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (more && SYNC) {
             if (FAST) {
                 if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
                 } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
@@ -883,7 +887,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 // converts).  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
                 constexpr int need = (LNF && HAS_A) ? 2 : 1;
                 constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - need;
-                constexpr int per = HAS_A ? (RB ? (NPASS == 1 ? 2 : 0) : (NPASS == 1 ? 3 : 1)) : WC;
+                constexpr int per = HAS_A ? WC + (NPASS == 1 ? 2 : 0) : WC;
                 constexpr int allow = ahead > 0 ? ahead * per : 0;
                 static_assert(allow < 64, "vmcnt is 6 bits");
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
@@ -1255,9 +1259,9 @@ __global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, ((LNF && H2_REBAL) ? 0 : 1)>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, ((LNF && H2_REBAL) ? 5 : 4)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, ((LNF && H2_REBAL) ? 4 : 3)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 0 : 1)>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 5 : 4)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 4 : 3)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -1318,18 +1322,18 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, (H2_REBAL ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, (H2_REBAL ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, (H2_REBAL ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, ((H2_REBAL & 1) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, ((H2_REBAL & 1) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, ((H2_REBAL & 1) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
                                    nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, (H2_REBAL ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, (H2_REBAL ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, (H2_REBAL ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, ((H2_REBAL & 1) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, ((H2_REBAL & 1) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, ((H2_REBAL & 1) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -1341,9 +1345,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
                     const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
                                    s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, ((H2_REBAL & 2) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, ((H2_REBAL & 2) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, ((H2_REBAL & 2) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
             }
