@@ -715,16 +715,21 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 }
             }
             phase_sync();
-            // ---------------- attention (:55-64): lane = (sequence li, head h), its <= 5 query joints against all 17 keys
+            // ---------------- attention (:55-64): lane = (sequence li, head h), its <= 5 query joints against all 17 keys.
+            // Scores in the exp2 domain (q carries hd^-0.5 log2 e = 0.5 log2 e), the probabilities stay unnormalised until
+            // the output row is complete (one multiplication per output instead of one per probability).
             {
                 const int h = 4 * hg + kq;
                 float sc[5][SJ];
+                constexpr float QS = 0.5f * 1.4426950408889634f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) q[t] = float4{q[t].x * QS, q[t].y * QS, q[t].z * QS, q[t].w * QS};
 #pragma unroll
                 for (int j = 0; j < SJ; ++j) {
                     const float4 k = ::mpl::ld4(Kb + ((j * SH + h) * SEQ + li) * 4);
 #pragma unroll
                     for (int t = 0; t < 5; ++t)
-                        sc[t][j] = 0.5f * (fmaf(q[t].x, k.x, q[t].y * k.y) + fmaf(q[t].z, k.z, q[t].w * k.w));   // hd^-0.5 = 0.5
+                        sc[t][j] = fmaf(q[t].x, k.x, q[t].y * k.y) + fmaf(q[t].z, k.z, q[t].w * k.w);
                 }
                 float inv[5];
 #pragma unroll
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     float l = 0.f;
 #pragma unroll
                     for (int j = 0; j < SJ; ++j) {
-                        sc[t][j] = __expf(sc[t][j] - mx);
+                        sc[t][j] = __builtin_amdgcn_exp2f(sc[t][j] - mx);
                         l += sc[t][j];
                     }
                     inv[t] = 1.0f / l;
@@ -752,13 +757,15 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     const float4 v = ::mpl::ld4(Vb + ((j * SH + h) * SEQ + li) * 4);
 #pragma unroll
                     for (int t = 0; t < 5; ++t) {
-                        const float pj = sc[t][j] * inv[t];
+                        const float pj = sc[t][j];
                         o[t].x = fmaf(pj, v.x, o[t].x);
                         o[t].y = fmaf(pj, v.y, o[t].y);
                         o[t].z = fmaf(pj, v.z, o[t].z);
                         o[t].w = fmaf(pj, v.w, o[t].w);
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 5; ++t) o[t] = float4{o[t].x * inv[t], o[t].y * inv[t], o[t].z * inv[t], o[t].w * inv[t]};
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
                     if (t < nj) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
