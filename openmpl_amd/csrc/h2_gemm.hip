@@ -680,9 +680,13 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
             const int hpr = ns >> 1;
             if (lane < 16 * hpr) {
-                int r = m0 + 16 * wave + lane / hpr;
+                // lane / hpr by a multiplication (lane < 64, hpr <= 8: exact): a division by a run-time number costs a
+                // reciprocal sequence that the compiler hoists out of the phase loop and keeps alive (it spilled)
+                const unsigned inv = 65536u / (unsigned)hpr + 1u;
+                const int lq = (int)(((unsigned)lane * inv) >> 16);
+                int r = m0 + 16 * wave + lq;
                 r = r < M ? r : M - 1;
-                const float* g = a.stats + ((size_t)r * ns + 2 * (lane % hpr)) * 2;
+                const float* g = a.stats + ((size_t)r * ns + 2 * (lane - lq * hpr)) * 2;
                 unsigned keep;
                 if (CHAIN)
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
@@ -1284,6 +1288,7 @@ struct H2StackArgs {
 __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = s.G, D = s.D;
     int team, tn;
     {
@@ -1308,10 +1313,13 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
         unsigned need = 0;
         for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
 #endif
-            int tidp = tid, tile = tile0, tnp = tn;
+            // the thread id is rebuilt from the wave index (a scalar) and the lane number every phase: kept in a register
+            // across the phases it was the one value the 256-register budget spilled to scratch
+            int wvp = wave_s, tile = tile0, tnp = tn;
+            asm volatile("" : "+s"(wvp), "+s"(tile), "+s"(tnp));
+            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(tidp));
-            asm volatile("" : "+s"(tile), "+s"(tnp));
-            const int wv = __builtin_amdgcn_readfirstlane(tidp >> 6);
+            const int wv = wvp;
             unsigned* ctr = s.counters + tile;
             const char* const* w = s.w[ph >> 2];
             bool ok = true;
