@@ -84,14 +84,19 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
 #endif
 #ifndef H2_REBAL
-#define H2_REBAL 1     // 1: in LayerNorm GEMMs the waves 0..3 request no W piece (waves 4, 5 five, waves 6, 7 four); 0: as in the plain GEMMs
+#define H2_REBAL 0     // 1: in LayerNorm GEMMs the waves 0..3 request no W piece (waves 4, 5 five, waves 6, 7 four); 0: as in the plain GEMMs
 #endif
 #ifndef H2_CVSPLIT
 #define H2_CVSPLIT 1   // 1: in-place conversion read in front of the product rows, converted + written behind them; 0: in one piece behind
 #endif
 #ifndef H2_KPS2
-#define H2_KPS2 1      // 1: the one-pass GEMMs with a packed A operand (proj, fc2) synchronise every SECOND stage: a barrier
+#define H2_KPS2 2      // 1: the one-pass GEMMs with a packed A operand (proj, fc2) synchronise every SECOND stage: a barrier
                        // publishes two stages at once; the refill then targets 5 stages ahead (one ring slot of slack)
+#endif
+#ifndef H2_LNREG
+#define H2_LNREG 1     // 1: the raw fp32 A pieces of a LayerNorm GEMM stay raw in LDS; BOTH waves of a row group read their lane's
+                       // eight values and normalise + split them in registers (same arithmetic, done twice) -- nothing to publish,
+                       // no conversion pass of the waves 0..3.  0: the requesting wave converts in place two stages ahead
 #endif
 #ifndef H2_PHASE_MAJOR
 #define H2_PHASE_MAJOR 0
@@ -499,9 +504,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // even stage e every wave has its pieces of the stages <= e + 2 landed and has finished reading the fragments of the
     // stages <= e, so stage e may refill the slot of stage e - 1 and stage e + 1 the slot of stage e: a refill goes
     // DIST = NST - 1 stages ahead.  Not where the A operand is converted in place (its publication needs every barrier).
-    constexpr bool P2 = H2_KPS2 && NPASS == 1 && !LNF;
+    constexpr bool P2 = (H2_KPS2 == 1 && NPASS == 1 && !LNF) || (H2_KPS2 >= 2 && (!LNF || (LNF && H2_LNREG)));
     constexpr int DIST = P2 ? NST - 1 : NST;
-    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF, convert) the A pieces
+    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF without LR, convert) the A pieces
+    constexpr bool LR = LNF && H2_LNREG;         // LayerNorm operand converted in registers by every wave that multiplies it
+    constexpr bool ST = LNF && (HAS_A || LR);    // this wave needs the row statistics
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
     const int rg = wave & 3;
@@ -674,7 +681,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
     constexpr unsigned ST_LDS = H2_STAGE;
     float4 st_raw[4];
-    if (LNF && HAS_A) {
+    if (ST) {
         const int ns = K / BN;
         if constexpr (NPASS >= 2) {
             // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
@@ -684,7 +691,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 // reciprocal sequence that the compiler hoists out of the phase loop and keeps alive (it spilled)
                 const unsigned inv = 65536u / (unsigned)hpr + 1u;
                 const int lq = (int)(((unsigned)lane * inv) >> 16);
-                int r = m0 + 16 * wave + lq;
+                int r = m0 + 16 * rg + lq;
                 r = r < M ? r : M - 1;
                 const float* g = a.stats + ((size_t)r * ns + 2 * (lane - lq * hpr)) * 2;
                 unsigned keep;
@@ -777,10 +784,28 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
 
     f16x8 A0[2], A1[2];
     f16x8 B0[NTW][2], B1[NTW][2];
+    // LR: the lane's eight raw values of its row (the same bytes the in-place form converted) wait in cvr0 / cvr1 until
+    // finish_a() normalises and splits them at the end of the stage
     auto read_a = [&](unsigned slot, f16x8 (&f)[2]) {
-        const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + rg * H2_RG) + lane;
-        f[0] = as[0];
-        f[1] = as[64];
+        if constexpr (LR) {
+            const char* p = smem + slot + rg * H2_RG + lane * 16;
+            cvr0 = *reinterpret_cast<const float4*>(p);
+            cvr1 = *reinterpret_cast<const float4*>(p + 1024);
+        } else {
+            const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + rg * H2_RG) + lane;
+            f[0] = as[0];
+            f[1] = as[64];
+        }
+    };
+    auto finish_a = [&](f16x8 (&f)[2]) {
+        float z[8] = {cvr0.x, cvr0.y, cvr0.z, cvr0.w, cvr1.x, cvr1.y, cvr1.z, cvr1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            z[j] = fmaf(z[j], cv_a, cv_b);
+            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
+            if (!row_ok) z[j] = 0.f;
+        }
+        split2(z, f[0], f[1]);
     };
     auto read_b = [&](unsigned slot, f16x8 (&f)[NTW][2]) {
         const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot + H2_A) + slot0 * 2 * 64 + lane;
@@ -805,7 +830,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // (waves 0..3 of a LayerNorm GEMM request only their two A pieces, in the A stages: of any three consecutive stages one
     // (NPASS = 3), one or two (NPASS = 2), all three (NPASS = 1) are A stages)
     // -> pieces of this wave in S consecutive stages, at least: S WC + 2 (A stages among them: S, S / 2, S / 3 for NPASS 1, 2, 3)
-    constexpr int S_ALLOW = LNF ? 3 : 4;
+    constexpr int S_ALLOW = (LNF && !LR) ? 3 : 4;
     constexpr int A_ALLOW = S_ALLOW * WC + 2 * (S_ALLOW / NPASS);
     constexpr int PA = WC + (HAS_A ? 2 : 0);     // pieces of this wave in a stage that carries A
     {   // stage 0 (LNF: and what the prologue converts) landed
@@ -813,10 +838,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             // LNF: the A pieces of the stages after those the prologue converts (stage 0; 0 and 1 for NPASS = 1)
             // P2: stages 0, 1, 2 landed, 3 and 4 (three pieces each) may stay in flight
             // (the A stages among the stages 1 .. 5 are 5 / 2 / 1 of them for NPASS 1 / 2 / 3; NPASS = 1 converts stage 1 here as well)
-            constexpr int LATER = P2 ? 2 * PA
-                                     : (LNF && NPASS == 1) ? 4 * PA : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
+            constexpr int LATER = P2 ? 2 * WC + 2 * (NPASS == 1 ? 2 : 1)
+                                     : (LNF && !LR && NPASS == 1) ? 4 * PA : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
-            if (LNF) {
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
+        }
+        {
+            if (ST) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
                 const int ns = K / BN;
                 if constexpr (NPASS >= 2) {
@@ -842,16 +871,17 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
                 cv_a = rs * H2_SA;
                 cv_b = -mean * cv_a;
-                convert(0);
-                if (NPASS == 1) convert(H2_STAGE);
+                if (!LR) {
+                    convert(0);
+                    if (NPASS == 1) convert(H2_STAGE);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_a(0, A0);
+        if (LR) finish_a(A0);
         read_b(0, B0);
     }
     const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
@@ -870,7 +900,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
         constexpr bool next_has_a = decltype(nha_c)::value;
         constexpr bool more = FAST || REM > 1;
-        constexpr bool cv = LNF && HAS_A && decltype(cv_c)::value && (FAST || REM > 2);
+        constexpr bool cv = LNF && !LR && HAS_A && decltype(cv_c)::value && (FAST || REM > 2);
         constexpr bool RF = FAST || REM > DIST;                              // this stage requests stage t + DIST
         // the ring position is opaque here: in the straight-line tail the compiler otherwise forms the LDS addresses of all the
         // remaining stages up front (+40 VGPRs, spills)
@@ -882,14 +912,16 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (more && SYNC) {
             if (FAST) {
                 if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
+                    constexpr int g0 = decltype(wp_c)::value;
+                    constexpr int na = ((g0 + 3) % NPASS == 0 ? 1 : 0) + ((g0 + 4) % NPASS == 0 ? 1 : 0);   // A stages among them
+                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC + 2 * na) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
                 } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
                 // tail.  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed: <= t + 1 (<= t + 2 where this wave
                 // converts).  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
-                constexpr int need = (LNF && HAS_A) ? 2 : 1;
+                constexpr int need = (LNF && !LR && HAS_A) ? 2 : 1;
                 constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - need;
                 constexpr int per = HAS_A ? WC + (NPASS == 1 ? 2 : 0) : WC;
                 constexpr int allow = ahead > 0 ? ahead * per : 0;
@@ -910,7 +942,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         };
         auto refill = [&]() {
-            if (RF && !(H2_ABL & 2)) refill_fast(wp_c, ai_c, P2 ? slot_p : slot_c);
+            // the requested stage t + DIST has the pass of this one when DIST is a multiple of NPASS (DIST = NST), else (P2)
+            // the pass (g + DIST) mod NPASS, and carries A when that pass is 0
+            constexpr int gr = (decltype(wp_c)::value + DIST) % NPASS;
+            if (RF && !(H2_ABL & 2))
+                refill_fast(std::integral_constant<int, gr>{}, std::integral_constant<bool, gr == 0>{}, P2 ? slot_p : slot_c);
             if (REM == 4) epilogue_operands();
         };
         auto all_reads = [&]() {
@@ -937,9 +973,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             mfma_row(accp, a_cur[0], b_cur, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
+            if (LR && more && next_has_a && !HAS_A) {
+                finish_a(a_nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (HAS_A) {
                 all_reads();
                 refill();
+                if (LR && more && next_has_a) finish_a(a_nxt);
                 if (cv) {
                     if (H2_CVSPLIT) convert_store(slot_after(slot_n));
                     else convert(slot_after(slot_n));
@@ -968,6 +1009,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         __builtin_amdgcn_sched_barrier(0);
         rd_b(3);
         rd_b(4);
+        if (LR && more && next_has_a) finish_a(a_nxt);
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };
@@ -986,17 +1028,17 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             else stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A0, B1, B0, YES{}, NO{});
         } else if constexpr (NPASS == 2) {
             if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, NO{}, acc[1], A0, A1, B1, B0, YES{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, NO{}, acc[1], A0, A1, B1, B0, YES{}, NO{});
             else if constexpr (POS == 2) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W1{}, NO{}, NO{}, acc[1], A1, A0, B1, B0, YES{}, YES{});
+            else stage(rem_c, W1{}, NO{}, NO{}, acc[1], A1, A0, B1, B0, YES{}, NO{});
         } else {
             // three stages per k-tile flip the B parity every k-tile
             if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A0, A0, B1, B0, NO{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A0, A0, B1, B0, NO{}, NO{});
             else if constexpr (POS == 2) stage(rem_c, W2{}, NO{}, NO{}, acc[2], A0, A1, B0, B1, YES{}, YES{});
-            else if constexpr (POS == 3) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A1, A1, B1, B0, NO{}, YES{});
+            else if constexpr (POS == 3) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A1, A1, B1, B0, NO{}, NO{});
             else if constexpr (POS == 4) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W2{}, NO{}, NO{}, acc[2], A1, A0, B1, B0, YES{}, YES{});
+            else stage(rem_c, W2{}, NO{}, NO{}, acc[2], A1, A0, B1, B0, YES{}, NO{});
         }
     };
     auto tail = [&](auto self, auto rem_c, auto pos_c) -> void {
