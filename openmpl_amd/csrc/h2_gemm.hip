@@ -30,8 +30,8 @@
 // Nothing overflows for ANY input; the unit-test entry (mpl_ln_linear_h2) scales a plain A operand by its measured amax.
 //
 // Data flow of a block application (x = fp32 residual stream, the ONLY activation kept in fp32):
-//   qkv : A = x (fp32 rows, LDS-DMA'd raw into the stage, normalised + split IN PLACE by the wave that brought them -- 32 B
-//         of fp32 become 16 B hi + 16 B lo in the same LDS bytes), epilogue = attention in registers -> att2 (packed)
+//   qkv : A = x (fp32 rows, LDS-DMA'd raw into the stage; each of the two waves that multiply a row group reads its lane's
+//         32 B of fp32 and normalises + splits them in registers), epilogue = attention in registers -> att2 (packed)
 //   proj: A = att2 (packed, LDS-DMA), epilogue: x += ..., LayerNorm slice partials
 //   fc1 : A = x as above, epilogue GELU -> hid2 (packed);   fc2: A = hid2, epilogue: x += ..., partials
 // x3 handed x from GEMM to GEMM as a split copy; here the residual epilogues write only fp32 x (write-through) and the
@@ -75,36 +75,14 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #define H2_DBG 0
 #endif
 #ifndef H2_ABL
-#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no in-place conversion, 32 no per-stage barrier
+#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier
 #endif
 #ifndef H2_WT_AUX
 #define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
 #endif
-#ifndef H2_STAGGER
-#define H2_STAGGER 1   // 1: the waves 4..7 request their DMA pieces one product row later than the waves 0..3
-#endif
-#ifndef H2_REBAL
-#define H2_REBAL 0     // 1: in LayerNorm GEMMs the waves 0..3 request no W piece (waves 4, 5 five, waves 6, 7 four); 0: as in the plain GEMMs
-#endif
-#ifndef H2_CVSPLIT
-#define H2_CVSPLIT 1   // 1: in-place conversion read in front of the product rows, converted + written behind them; 0: in one piece behind
-#endif
 #ifndef H2_KPS2
-#define H2_KPS2 2      // 1: the one-pass GEMMs with a packed A operand (proj, fc2) synchronise every SECOND stage: a barrier
-                       // publishes two stages at once; the refill then targets 5 stages ahead (one ring slot of slack)
-#endif
-#ifndef H2_LNREG
-#define H2_LNREG 1     // 1: the raw fp32 A pieces of a LayerNorm GEMM stay raw in LDS; BOTH waves of a row group read their lane's
-                       // eight values and normalise + split them in registers (same arithmetic, done twice) -- nothing to publish,
-                       // no conversion pass of the waves 0..3.  0: the requesting wave converts in place two stages ahead
-#endif
-#ifndef H2_PHASE_MAJOR
-#define H2_PHASE_MAJOR 0
-#endif
-#ifndef H2_SCHED
-#define H2_SCHED 4     // 4 (default): the two waves of a SIMD out of phase -- waves 0..3 multiply first and load afterwards, waves 4..7
-                       // the other way round; 0: product rows, fragment reads and DMA requests interleaved (A/B: +1..3 % time).
-                       // Other orders that were measured and removed again: DESIGN.md section 4
+#define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
+                       // ring slot of slack); 0: a barrier in front of every stage, refill 6 stages ahead
 #endif
 
 __host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
@@ -500,15 +478,15 @@ template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need) {
     constexpr int NST = H2_NST;
-    // P2: one barrier per TWO stages in the one-pass GEMMs with a packed A operand (proj, fc2).  At the barrier in front of an
-    // even stage e every wave has its pieces of the stages <= e + 2 landed and has finished reading the fragments of the
-    // stages <= e, so stage e may refill the slot of stage e - 1 and stage e + 1 the slot of stage e: a refill goes
-    // DIST = NST - 1 stages ahead.  Not where the A operand is converted in place (its publication needs every barrier).
-    constexpr bool P2 = (H2_KPS2 == 1 && NPASS == 1 && !LNF) || (H2_KPS2 >= 2 && (!LNF || (LNF && H2_LNREG)));
+    // P2: one barrier per TWO stages.  At the barrier in front of an even stage e every wave has its pieces of the stages
+    // <= e + 2 landed and has finished reading the fragments of the stages <= e, so stage e may refill the slot of stage e - 1
+    // and stage e + 1 the slot of stage e: a refill goes DIST = NST - 1 stages ahead.  Nothing but the DMA landing has to be
+    // published: the LayerNorm operand stays RAW in LDS and every wave that multiplies it normalises + splits its lane's eight
+    // values in registers (both waves of a row group do the same arithmetic; the in-place conversion by the requesting wave
+    // that this replaced needed every barrier and made the waves 0..3 the slow half of the stage).
+    constexpr bool P2 = H2_KPS2 != 0;
     constexpr int DIST = P2 ? NST - 1 : NST;
-    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring (and, LNF without LR, convert) the A pieces
-    constexpr bool LR = LNF && H2_LNREG;         // LayerNorm operand converted in registers by every wave that multiplies it
-    constexpr bool ST = LNF && (HAS_A || LR);    // this wave needs the row statistics
+    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring the A pieces
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
     const int rg = wave & 3;
@@ -526,17 +504,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const int row = row_ok ? m0 + row_l : (M - 1);
 
     // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
-    // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.
-    // Plain A operand: waves 0..3 one W piece (14 + w) besides their two A pieces, waves 4, 5 four (0..3 / 4..7), waves 6, 7
-    // three (8..10 / 11..13).  LayerNorm GEMMs: the waves 0..3 also convert the A pieces in place, which made them the slow
-    // half of every stage (tools/chain_phase.py: 700 cycles of reads + requests + conversion per stage against 495 in the
-    // waves 4..7, which then sat 450 cycles at the barrier) -- there they request NO W piece, the waves 4, 5 take five
-    // (0..4 / 5..9), the waves 6, 7 four (10..13 / 14..17).
-    constexpr bool RB = LNF ? (H2_REBAL & 1) != 0 : (H2_REBAL & 2) != 0;
-    const int w_first = RB ? (HAS_A ? 0 : (wave < 6 ? 5 * (wave - 4) : 10 + 4 * (wave - 6)))
-                           : (HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6)));
+    // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.  (Moving the W pieces of the waves
+    // 0..3 to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm operand in place, -3 %; it costs 1-3 % now.)
+    const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
     constexpr int w_cnt = WC;
-    static_assert(RB ? (HAS_A ? WC == 0 : (WC == 4 || WC == 5)) : (HAS_A ? WC == 1 : (WC == 3 || WC == 4)), "W pieces per wave");
+    static_assert(HAS_A ? WC == 1 : (WC == 3 || WC == 4), "W pieces per wave");
     unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
     // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
@@ -556,7 +528,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
                            : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
     auto w_pieces = [&](const char* src, unsigned dst) {
-        if (w_cnt == 0) return;
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
             "s_nop 0\n\t"
@@ -569,8 +540,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
         }
         if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
-        if (w_cnt > 4)      // the instruction offset is 13 bits signed: the fifth piece gets its own base and M0
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voW), "s"(src + 4096), "s"(dst + 4096u) : "memory");
     };
     // the two A pieces of this wave's row group for A k-tile ia_kt into stage slot `slot` (waves 0..3; M0 is the caller's)
     auto a_pieces = [&](unsigned slot) {
@@ -681,7 +650,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
     constexpr unsigned ST_LDS = H2_STAGE;
     float4 st_raw[4];
-    if (ST) {
+    if (LNF) {
         const int ns = K / BN;
         if constexpr (NPASS >= 2) {
             // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
@@ -737,57 +706,16 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
 #pragma unroll
         for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- LNF: normalise + split the raw fp32 A pieces of a stage IN PLACE (waves 0..3, each its own row group: the wave
-    // that requested the bytes waits for them with its own vmcnt, no other wave touches them before the next barrier)
-    float cv_a = 0.f, cv_b = 0.f;               // z = x cv_a + cv_b = (x - mean) rstd 2^10
-    // in two halves for the k loop: the raw values are READ before the product rows of the stage and converted + written
-    // behind them -- in one piece behind the rows, the LDS round trip of the read (and ~450 cycles in all) sat on the
-    // critical path of the waves 0..3 (tools/chain_phase.py)
+    // ---- LNF: z = x cv_a + cv_b = (x - mean) rstd 2^10 of this lane's row, applied when the raw values are taken out of LDS
+    float cv_a = 0.f, cv_b = 0.f;
     float4 cvr0 = {0.f, 0.f, 0.f, 0.f}, cvr1 = {0.f, 0.f, 0.f, 0.f};
-    auto convert_load = [&](unsigned slot) {
-        if (H2_ABL & 16) return;
-        const char* p = smem + slot + wave * H2_RG + lane * 16;
-        cvr0 = *reinterpret_cast<const float4*>(p);
-        cvr1 = *reinterpret_cast<const float4*>(p + 1024);
-    };
-    auto convert_store = [&](unsigned slot) {
-        if (H2_ABL & 16) return;
-        char* p = smem + slot + wave * H2_RG + lane * 16;
-        float z[8] = {cvr0.x, cvr0.y, cvr0.z, cvr0.w, cvr1.x, cvr1.y, cvr1.z, cvr1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            z[j] = fmaf(z[j], cv_a, cv_b);
-            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);
-            if (!row_ok) z[j] = 0.f;
-        }
-        f16x8 hi, lo;
-        split2(z, hi, lo);
-        *reinterpret_cast<f16x8*>(p) = hi;
-        *reinterpret_cast<f16x8*>(p + 1024) = lo;
-    };
-    auto convert = [&](unsigned slot) {
-        if (H2_ABL & 16) return;
-        char* p = smem + slot + wave * H2_RG + lane * 16;
-        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 1024);
-        float z[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            z[j] = fmaf(z[j], cv_a, cv_b);
-            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
-            if (!row_ok) z[j] = 0.f;
-        }
-        f16x8 hi, lo;
-        split2(z, hi, lo);
-        *reinterpret_cast<f16x8*>(p) = hi;
-        *reinterpret_cast<f16x8*>(p + 1024) = lo;
-    };
 
     f16x8 A0[2], A1[2];
     f16x8 B0[NTW][2], B1[NTW][2];
-    // LR: the lane's eight raw values of its row (the same bytes the in-place form converted) wait in cvr0 / cvr1 until
+    // LNF: the lane's eight raw values of its row wait in cvr0 / cvr1 until
     // finish_a() normalises and splits them at the end of the stage
     auto read_a = [&](unsigned slot, f16x8 (&f)[2]) {
-        if constexpr (LR) {
+        if constexpr (LNF) {
             const char* p = smem + slot + rg * H2_RG + lane * 16;
             cvr0 = *reinterpret_cast<const float4*>(p);
             cvr1 = *reinterpret_cast<const float4*>(p + 1024);
@@ -823,29 +751,21 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         for (int n = 0; n < NTW; ++n)
             if (!(H2_ABL & 8)) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[n][bp], af, accp[n], 0, 0, 0);
     };
-    // counted waits.  Per stage a wave of the waves 4..7 requests w_cnt (4 or 3) pieces, a wave 0..3 one W piece plus two A
-    // pieces in the A stages (every NPASS-th).  Stages t+1 (.. t+5) are in flight when stage t starts; the waves 4..7 need
-    // their pieces of stage t+1, the waves 0..3 of stage t+2 when they convert it during stage t (LNF) else of stage t+1.
-    // Smallest number of pieces of this wave in the stages that may stay in flight:
-    // (waves 0..3 of a LayerNorm GEMM request only their two A pieces, in the A stages: of any three consecutive stages one
-    // (NPASS = 3), one or two (NPASS = 2), all three (NPASS = 1) are A stages)
-    // -> pieces of this wave in S consecutive stages, at least: S WC + 2 (A stages among them: S, S / 2, S / 3 for NPASS 1, 2, 3)
-    constexpr int S_ALLOW = (LNF && !LR) ? 3 : 4;
-    constexpr int A_ALLOW = S_ALLOW * WC + 2 * (S_ALLOW / NPASS);
-    constexpr int PA = WC + (HAS_A ? 2 : 0);     // pieces of this wave in a stage that carries A
-    {   // stage 0 (LNF: and what the prologue converts) landed
+    // counted waits.  Per stage a wave of the waves 4..7 requests WC (4 or 3) pieces, a wave 0..3 one W piece plus two A
+    // pieces in the A stages (every NPASS-th).  One barrier per stage: the stages t+1 .. t+5 are in flight when stage t
+    // starts and stage t+1 is needed, so four stages may stay in flight -- at least 4 WC + 2 (A stages among four consecutive
+    // ones: 4, 2, 1 for NPASS 1, 2, 3) pieces of this wave.  P2: see the stage.
+    constexpr int A_ALLOW = 4 * WC + 2 * (4 / NPASS);
+    {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
+        // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
         if (HAS_A) {
-            // LNF: the A pieces of the stages after those the prologue converts (stage 0; 0 and 1 for NPASS = 1)
-            // P2: stages 0, 1, 2 landed, 3 and 4 (three pieces each) may stay in flight
-            // (the A stages among the stages 1 .. 5 are 5 / 2 / 1 of them for NPASS 1 / 2 / 3; NPASS = 1 converts stage 1 here as well)
-            constexpr int LATER = P2 ? 2 * WC + 2 * (NPASS == 1 ? 2 : 1)
-                                     : (LNF && !LR && NPASS == 1) ? 4 * PA : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
+            constexpr int LATER = P2 ? 2 * WC + 2 * (NPASS == 1 ? 2 : 1) : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
         }
         {
-            if (ST) {
+            if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
                 const int ns = K / BN;
                 if constexpr (NPASS >= 2) {
@@ -871,37 +791,32 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
                 cv_a = rs * H2_SA;
                 cv_b = -mean * cv_a;
-                if (!LR) {
-                    convert(0);
-                    if (NPASS == 1) convert(H2_STAGE);
-                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         read_a(0, A0);
-        if (LR) finish_a(A0);
+        if (LNF) finish_a(A0);
         read_b(0, B0);
     }
     const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_vm = 0, t_bar = 0, t_mm = 0;      // bench-only sums: counted DMA wait, lgkm + barrier, the MFMA rows of a stage
     unsigned slot_c = 0;
-    // one stage: publish stage t+1 (which frees the slot of stage t for the DMA of stage t+NST), then the MFMAs of stage t
-    // with the fragment reads of stage t+1 -- and, waves 0..3 of a LayerNorm GEMM, the in-place conversion of the A pieces
-    // of stage t+2 (CV) -- in between.  REM = 0: a stage of the steady state (t + NST < T); REM > 0: a stage of the tail with
-    // REM stages left including this one -- a compile-time number, so that the counted waits, the last refills and the end of
-    // the fragment reads need neither bookkeeping nor branches (a tail stage with run-time bookkeeping cost ~1500 cycles
-    // against ~800 of a steady-state one, and a quarter of all stages are tail stages).
-    auto stage = [&](auto rem_c, auto wp_c, auto ai_c, auto cv_c, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
+    // one stage: publish the landed stages (which frees a slot for the DMA of stage t + DIST), then the MFMAs of stage t and the
+    // fragment reads of stage t+1.  REM = 0: a stage of the steady state (t + NST < T); REM > 0: a stage of the tail with REM
+    // stages left including this one -- a compile-time number, so that the counted waits, the last refills and the end of the
+    // fragment reads need neither bookkeeping nor branches (a tail stage with run-time bookkeeping cost ~1500 cycles against
+    // ~800 of a steady-state one, and a quarter of all stages are tail stages).
+    auto stage = [&](auto rem_c, auto wp_c, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
                      const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], auto nha_c, auto sync_c) {
         constexpr int REM = decltype(rem_c)::value;
         constexpr bool FAST = REM == 0;
         constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
         constexpr bool next_has_a = decltype(nha_c)::value;
         constexpr bool more = FAST || REM > 1;
-        constexpr bool cv = LNF && !LR && HAS_A && decltype(cv_c)::value && (FAST || REM > 2);
         constexpr bool RF = FAST || REM > DIST;                              // this stage requests stage t + DIST
+        constexpr int g0 = decltype(wp_c)::value;                            // pass of this stage
         // the ring position is opaque here: in the straight-line tail the compiler otherwise forms the LDS addresses of all the
         // remaining stages up front (+40 VGPRs, spills)
         asm volatile("" : "+s"(slot_c));
@@ -912,17 +827,15 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (more && SYNC) {
             if (FAST) {
                 if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
-                    constexpr int g0 = decltype(wp_c)::value;
                     constexpr int na = ((g0 + 3) % NPASS == 0 ? 1 : 0) + ((g0 + 4) % NPASS == 0 ? 1 : 0);   // A stages among them
                     if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC + 2 * na) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
                 } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
             } else {
-                // tail.  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed: <= t + 1 (<= t + 2 where this wave
-                // converts).  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
-                constexpr int need = (LNF && !LR && HAS_A) ? 2 : 1;
-                constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - need;
+                // tail (a barrier in front of every stage).  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed:
+                // <= t + 1.  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
+                constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - 1;
                 constexpr int per = HAS_A ? WC + (NPASS == 1 ? 2 : 0) : WC;
                 constexpr int allow = ahead > 0 ? ahead * per : 0;
                 static_assert(allow < 64, "vmcnt is 6 bits");
@@ -941,75 +854,32 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 b_nxt[n][1] = bs[(n * 2 + 1) * 64];
             }
         };
-        auto refill = [&]() {
-            // the requested stage t + DIST has the pass of this one when DIST is a multiple of NPASS (DIST = NST), else (P2)
-            // the pass (g + DIST) mod NPASS, and carries A when that pass is 0
-            constexpr int gr = (decltype(wp_c)::value + DIST) % NPASS;
+        auto loads = [&]() {
+            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+            rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
+            // the requested stage t + DIST has the pass (g + DIST) mod NPASS (= g when DIST = NST) and carries A when that is 0
+            constexpr int gr = (g0 + DIST) % NPASS;
             if (RF && !(H2_ABL & 2))
                 refill_fast(std::integral_constant<int, gr>{}, std::integral_constant<bool, gr == 0>{}, P2 ? slot_p : slot_c);
             if (REM == 4) epilogue_operands();
         };
-        auto all_reads = [&]() {
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
-        };
-        if constexpr ((H2_SCHED & 4) != 0) {
-            // the two waves of a SIMD out of phase: waves 0..3 multiply first and load afterwards, waves 4..7 the other way
-            // round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe
+        // The two waves of a SIMD run out of phase: the waves 0..3 multiply first and load afterwards, the waves 4..7 the other
+        // way round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe.
+        // (Interleaving rows, reads and requests, or reads first in both halves: +1 .. +11 % time)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!HAS_A) {
+            loads();
             __builtin_amdgcn_sched_barrier(0);
-            if (!HAS_A) {
-                all_reads();
-                refill();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            unsigned long long m0 = 0;
-            if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
-            if (HAS_A && cv && H2_CVSPLIT) {
-                convert_load(slot_after(slot_n));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mfma_row(accp, a_cur[1], b_cur, 0);
-            mfma_row(accp, a_cur[0], b_cur, 1);
-            mfma_row(accp, a_cur[0], b_cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
-            if (LR && more && next_has_a && !HAS_A) {
-                finish_a(a_nxt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (HAS_A) {
-                all_reads();
-                refill();
-                if (LR && more && next_has_a) finish_a(a_nxt);
-                if (cv) {
-                    if (H2_CVSPLIT) convert_store(slot_after(slot_n));
-                    else convert(slot_after(slot_n));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            slot_c = slot_n;
-            return;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long m0 = 0;
+        if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
         mfma_row(accp, a_cur[1], b_cur, 0);             // lo . hi
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(H2_STAGGER && !HAS_A)) refill();
-        if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-        rd_b(0);
-        if (!next_has_a) rd_b(1);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 1);             // hi . lo
-        __builtin_amdgcn_sched_barrier(0);
-        if (next_has_a) rd_b(1);
-        rd_b(2);
-        if (H2_STAGGER && !HAS_A) refill();
-        if (cv) convert(slot_after(slot_n));
-        __builtin_amdgcn_sched_barrier(0);
         mfma_row(accp, a_cur[0], b_cur, 0);             // hi . hi
         __builtin_amdgcn_sched_barrier(0);
-        rd_b(3);
-        rd_b(4);
-        if (LR && more && next_has_a) finish_a(a_nxt);
+        if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
+        if (HAS_A) loads();
+        if (LNF && more && next_has_a && !(H2_ABL & 16)) finish_a(a_nxt);
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };
@@ -1018,27 +888,28 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     using W2 = std::integral_constant<int, 2>;
     using YES = std::integral_constant<bool, true>;
     using NO = std::integral_constant<bool, false>;
-    // Stage t = NPASS kt + j: pass j, carries A when j == 0, converts the A of stage t + 2 when (j + 2) % NPASS == 0; the
-    // fragment registers alternate per k-tile (A) and per stage (B).  POS = t mod 2 NPASS picks the row of that table.
+    // Stage t = NPASS kt + j: pass j, carries A when j == 0; the fragment registers alternate per k-tile (A) and per stage (B);
+    // the last two arguments: the NEXT stage carries A / (P2) a barrier stands in front of this stage.  POS = t mod 2 NPASS
+    // picks the row of that table.
     constexpr int U = 2 * NPASS;
     auto step = [&](auto rem_c, auto pos_c) {
         constexpr int POS = decltype(pos_c)::value;
         if constexpr (NPASS == 1) {
-            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A0, A1, B0, B1, YES{}, YES{});
-            else stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A0, B1, B0, YES{}, NO{});
+            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A1, B0, B1, YES{}, YES{});
+            else stage(rem_c, W0{}, acc[0], A1, A0, B1, B0, YES{}, NO{});
         } else if constexpr (NPASS == 2) {
-            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, NO{}, acc[1], A0, A1, B1, B0, YES{}, NO{});
-            else if constexpr (POS == 2) stage(rem_c, W0{}, YES{}, YES{}, acc[0], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W1{}, NO{}, NO{}, acc[1], A1, A0, B1, B0, YES{}, NO{});
+            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, acc[1], A0, A1, B1, B0, YES{}, NO{});
+            else if constexpr (POS == 2) stage(rem_c, W0{}, acc[0], A1, A1, B0, B1, NO{}, YES{});
+            else stage(rem_c, W1{}, acc[1], A1, A0, B1, B0, YES{}, NO{});
         } else {
             // three stages per k-tile flip the B parity every k-tile
-            if constexpr (POS == 0) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A0, A0, B1, B0, NO{}, NO{});
-            else if constexpr (POS == 2) stage(rem_c, W2{}, NO{}, NO{}, acc[2], A0, A1, B0, B1, YES{}, YES{});
-            else if constexpr (POS == 3) stage(rem_c, W0{}, YES{}, NO{}, acc[0], A1, A1, B1, B0, NO{}, NO{});
-            else if constexpr (POS == 4) stage(rem_c, W1{}, NO{}, YES{}, acc[1], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W2{}, NO{}, NO{}, acc[2], A1, A0, B1, B0, YES{}, NO{});
+            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
+            else if constexpr (POS == 1) stage(rem_c, W1{}, acc[1], A0, A0, B1, B0, NO{}, NO{});
+            else if constexpr (POS == 2) stage(rem_c, W2{}, acc[2], A0, A1, B0, B1, YES{}, YES{});
+            else if constexpr (POS == 3) stage(rem_c, W0{}, acc[0], A1, A1, B1, B0, NO{}, NO{});
+            else if constexpr (POS == 4) stage(rem_c, W1{}, acc[1], A1, A1, B0, B1, NO{}, YES{});
+            else stage(rem_c, W2{}, acc[2], A1, A0, B1, B0, YES{}, NO{});
         }
     };
     auto tail = [&](auto self, auto rem_c, auto pos_c) -> void {
@@ -1305,9 +1176,9 @@ __global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 0 : 1)>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 5 : 4)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, (((LNF ? H2_REBAL & 1 : H2_REBAL & 2)) ? 4 : 3)>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, 1>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 4>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 3>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -1344,17 +1215,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     auto vecs = [&](const char* w2, int N, int K) -> const float* {
         return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
     };
-#if H2_PHASE_MAJOR
-    // a team walks ITS tiles phase by phase (phase p of every tile, then phase p + 1).  Measured: no gain with two tiles per
-    // team, and the loop nest costs 3-5 % through the code the compiler makes of it (more scalar spills inside the phases)
-    unsigned need = 0;
-    for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
-        for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
-#else
     for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
         unsigned need = 0;
         for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
-#endif
             // the thread id is rebuilt from the wave index (a scalar) and the lane number every phase: kept in a register
             // across the phases it was the one value the 256-register budget spilled to scratch
             int wvp = wave_s, tile = tile0, tnp = tn;
@@ -1372,18 +1235,18 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, ((H2_REBAL & 1) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, ((H2_REBAL & 1) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, ((H2_REBAL & 1) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
                                    nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, ((H2_REBAL & 1) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, ((H2_REBAL & 1) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, ((H2_REBAL & 1) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -1395,9 +1258,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
                     const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
                                    s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, ((H2_REBAL & 2) ? 0 : 1)>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, ((H2_REBAL & 2) ? 5 : 4)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, ((H2_REBAL & 2) ? 4 : 3)>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
             }
