@@ -80,6 +80,12 @@ constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm 
 #ifndef H2_WT_AUX
 #define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
 #endif
+#ifndef H2_WSPLIT
+#define H2_WSPLIT 1    // W pieces per stage and wave: 0 = 1 (waves 0..3) / 4 (waves 4, 5) / 3 (waves 6, 7); 1 = 2 / 3 / 2
+#endif
+#define H2_WC0 (H2_WSPLIT == 1 ? 2 : 1)
+#define H2_WC1 (H2_WSPLIT == 1 ? 3 : 4)
+#define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
 #ifndef H2_KPS2
 #define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
                        // ring slot of slack); 0: a barrier in front of every stage, refill 6 stages ahead
@@ -506,9 +512,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
     // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.  (Moving the W pieces of the waves
     // 0..3 to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm operand in place, -3 %; it costs 1-3 % now.)
+#if H2_WSPLIT == 1
+    const int w_first = HAS_A ? 10 + 2 * wave : (wave < 6 ? 3 * (wave - 4) : 6 + 2 * (wave - 6));
+    static_assert(HAS_A ? WC == 2 : (WC == 3 || WC == 2), "W pieces per wave");
+#else
     const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
-    constexpr int w_cnt = WC;
     static_assert(HAS_A ? WC == 1 : (WC == 3 || WC == 4), "W pieces per wave");
+#endif
+    constexpr int w_cnt = WC;
     unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
     // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
@@ -535,10 +546,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             :
             : "v"(voW), "s"(src), "s"(dst)
             : "memory");
-        if (w_cnt > 1) {
-            asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voW), "s"(src) : "memory");
-            asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
-        }
+        if (w_cnt > 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voW), "s"(src) : "memory");
+        if (w_cnt > 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
         if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
     };
     // the two A pieces of this wave's row group for A k-tile ia_kt into stage slot `slot` (waves 0..3; M0 is the caller's)
@@ -865,7 +874,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         };
         // The two waves of a SIMD run out of phase: the waves 0..3 multiply first and load afterwards, the waves 4..7 the other
         // way round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe.
-        // (Interleaving rows, reads and requests, or reads first in both halves: +1 .. +11 % time)
+        // (Interleaving rows, reads and requests -- down to one load operation behind every MFMA --, or reads first in both
+        // halves: +1 .. +11 % time)
         __builtin_amdgcn_sched_barrier(0);
         if (!HAS_A) {
             loads();
@@ -1176,9 +1186,9 @@ __global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
             tn = b / a.grid_m;
         }
     }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, 1>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 4>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, 3>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, H2_WC0>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
+    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, H2_WC1>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
+    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, H2_WC2>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- whole block stack
@@ -1235,18 +1245,18 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
                     const float* v = vecs(w[2], 2 * D, D);
                     const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
                                    nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
@@ -1258,9 +1268,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
                     const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
                                    s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, 1>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 4>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, 3>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
+                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
+                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
             }
