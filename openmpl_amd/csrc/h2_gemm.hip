@@ -652,6 +652,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             return false;
         }
     }
+    const unsigned long long t_chain = (H2_DBG == 2 && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     issue_a();
     // LNF: the row statistics (slice partials {mean, M2} written by the producers of x) of this wave's 16 rows, requested
     // right behind A(0).  NPASS >= 2: by LDS-DMA (L1-bypassing in chain mode) into the A region of stage slot 1, which a
@@ -765,6 +766,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // starts and stage t+1 is needed, so four stages may stay in flight -- at least 4 WC + 2 (A stages among four consecutive
     // ones: 4, 2, 1 for NPASS 1, 2, 3) pieces of this wave.  P2: see the stage.
     constexpr int A_ALLOW = 4 * WC + 2 * (4 / NPASS);
+    unsigned long long t_land = 0;
     {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
         // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
         if (HAS_A) {
@@ -773,6 +775,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
         }
+        if (H2_DBG == 2 && a.dbg) t_land = __builtin_amdgcn_s_memtime();
         {
             if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
@@ -1163,6 +1166,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (lane == 0) {
             unsigned long long* o = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
             o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar; o[7] = t_mm;
+            if (H2_DBG == 2) { o[5] = t_chain; o[6] = t_land; }      // prologue split: hand-off wait | first operands landed
         }
     }
     return true;
