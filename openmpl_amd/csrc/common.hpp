@@ -32,6 +32,21 @@ __device__ __forceinline__ f32x4 mfma16_k16(const float4& a, const float4& b, f3
     return c;
 }
 
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in every lane by the gfx950 row / half swaps (one VALU instruction, no trip through
+// the LDS crossbar that __shfl_xor takes as ds_bpermute_b32: ~100 cycles each in a dependent chain of four per LayerNorm
+// fragment).  a = b = v; the swap exchanges the odd rows of a with the even rows of b (the upper half of a with the lower half
+// of b), after which a + b is the pair sum in both partners -- the same two addends as v + shfl(v), so bitwise the same.
+__device__ __forceinline__ float xor16_add(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_add(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -69,15 +69,15 @@ __device__ __forceinline__ void ln_frags(const float* X, int m, int li, int kq, 
     const float* xr = X + (m * 16 + li) * XS + 4 * kq;
     float4 x0 = ld4(xr), x1 = ld4(xr + 16);
     float s = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = xor16_add(s);
+    s = xor32_add(s);
     const float mean = s * (1.0f / 32.0f);
     x0.x -= mean; x0.y -= mean; x0.z -= mean; x0.w -= mean;
     x1.x -= mean; x1.y -= mean; x1.z -= mean; x1.w -= mean;
     float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
                ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss = xor16_add(ss);
+    ss = xor32_add(ss);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
     a0.x = x0.x * rstd * g0.x + b0.x; a0.y = x0.y * rstd * g0.y + b0.y;
     a0.z = x0.z * rstd * g0.z + b0.z; a0.w = x0.w * rstd * g0.w + b0.w;
@@ -661,15 +661,13 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         const float* xr = X + (m * 16 + li) * XS + 8 * kq;
         float4 x0 = ::mpl::ld4(xr), x1 = ::mpl::ld4(xr + 4);
         float sm = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
-        sm += __shfl_xor(sm, 16, 64);
-        sm += __shfl_xor(sm, 32, 64);
+        sm = ::mpl::xor32_add(::mpl::xor16_add(sm));
         const float mean = sm * (1.0f / 32.0f);
         x0.x -= mean; x0.y -= mean; x0.z -= mean; x0.w -= mean;
         x1.x -= mean; x1.y -= mean; x1.z -= mean; x1.w -= mean;
         float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
                    ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = ::mpl::xor32_add(::mpl::xor16_add(ss));
         const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
         const float y[8] = {x0.x * rstd * g0.x + e0.x, x0.y * rstd * g0.y + e0.y, x0.z * rstd * g0.z + e0.z, x0.w * rstd * g0.w + e0.w,
                             x1.x * rstd * g1.x + e1.x, x1.y * rstd * g1.y + e1.y, x1.z * rstd * g1.z + e1.z, x1.w * rstd * g1.w + e1.w};

@@ -1032,8 +1032,8 @@ __device__ __forceinline__ bool x3_phase(const X3Args& a, char* smem, int tid, i
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s0[j] += __shfl_xor(s0[j], 16, 64); s0[j] += __shfl_xor(s0[j], 32, 64);
-            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+            s0[j] = xor16_add(s0[j]); s0[j] = xor32_add(s0[j]);
+            s1[j] = xor16_add(s1[j]); s1[j] = xor32_add(s1[j]);
         }
         float* xs = reinterpret_cast<float*>(smem);        // [2 halves][64 rows][8]
         const int half = slot0 ? 1 : 0;
@@ -1150,8 +1150,8 @@ __device__ __forceinline__ bool x3_phase(const X3Args& a, char* smem, int tid, i
                 float sum = 0.f;
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) sum += (vals[n][0] + vals[n][1]) + (vals[n][2] + vals[n][3]);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = xor16_add(sum);
+                sum = xor32_add(sum);
                 __syncthreads();                    // every wave is done with the ring
                 if (kq == 0) xch[half * 64 + row_l] = sum;
                 __syncthreads();
@@ -1166,8 +1166,8 @@ __device__ __forceinline__ bool x3_phase(const X3Args& a, char* smem, int tid, i
                         q = ok ? fmaf(d, d, q) : q;
                     }
                 }
-                q += __shfl_xor(q, 16, 64);
-                q += __shfl_xor(q, 32, 64);
+                q = xor16_add(q);
+                q = xor32_add(q);
                 if (kq == 0) xch[128 + half * 64 + row_l] = q;
                 __syncthreads();
                 if (half == 0 && kq == 0 && row_ok)
