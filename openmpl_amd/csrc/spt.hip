@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
                    ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
         ss = ::mpl::xor32_add(::mpl::xor16_add(ss));
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / 32.0f) + 1e-6f);
+        const float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / 32.0f) + 1e-6f);   // v_rsq_f32 (1 ulp): not the ~20-instruction IEEE 1 / sqrt
         const float y[8] = {x0.x * rstd * g0.x + e0.x, x0.y * rstd * g0.y + e0.y, x0.z * rstd * g0.z + e0.z, x0.w * rstd * g0.w + e0.w,
                             x1.x * rstd * g1.x + e1.x, x1.y * rstd * g1.y + e1.y, x1.z * rstd * g1.z + e1.z, x1.w * rstd * g1.w + e1.w};
         spt_split3(y, ah, am, al);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                         sc[t][j] = __builtin_amdgcn_exp2f(sc[t][j] - mx);
                         l += sc[t][j];
                     }
-                    inv[t] = 1.0f / l;
+                    inv[t] = __builtin_amdgcn_rcpf(l);                      // v_rcp_f32 (1 ulp)
                     if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales the query row
                         const int b = b0 + li;
                         inv[t] *= (b < p.B && t < nj) ? pose[((size_t)b * SJ + (part + 4 * t)) * 3 + 2] : 0.f;
