@@ -277,7 +277,7 @@ int mpl_pose_metrics_ex(const float *output, const float *target, const float *w
 /* ---- fp16x2 split-operand engine (csrc/h2_gemm.hip): "fp32" precision of MultiView_MPL (the default).
  * mpl_pack_h2: derived operand of one nn.Linear (W (N,K) row-major, bias (N)), optionally with the LayerNorm in front of it
  * folded in (ln_w, ln_b of length K, or both NULL).  dst: mpl_pack_h2_bytes(N, K) bytes (0 = the shape has no layout:
- * N % 136 == 0, K % 544 == 0 required; with a LayerNorm folded in also K <= 2048).
+ * N % 136 == 0, K % 544 == 0 required; with a LayerNorm folded in also K <= 1088: K in {544, 1088}).
  * mpl_ln_linear_h2: y[M,N] = epi(LN?(x) W^T + b) from that operand -- the unit-test entry of one GEMM (the forward runs all
  * GEMMs of a stack in ONE launch, mpl_block_stack); has_ln: x is normalised with eps (stats: 2 * M * K/136 floats of
  * scratch); else x is packed with its measured amax.  workspace: mpl_ln_linear_h2_workspace_bytes(M, K). */

@@ -97,7 +97,7 @@ __host__ __device__ inline int h2_col(int t, int kq, int j, int G) {
     return 136 * (4 * (t - 4 * G) + kq) + 128 + j;
 }
 
-// K <= 2048 is needed only where a LayerNorm is folded in (the static 2^10 scale of a normalised row, |z| <= sqrt(K) 2^10);
+// A folded LayerNorm needs K <= 1088 (the kernel combines at most 8 slice partials per row; the static 2^10 scale of a normalised row, |z| <= sqrt(K) 2^10, would allow K <= 2048);
 // launch_pack_h2 checks that; the packed layout itself exists for every multiple of 544
 bool h2_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 * BN) == 0 && K <= 8704; }
 
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict_
 int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
                    hipStream_t s) {
     if (!W || !dst || !bias || !h2_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr))) return MPL_E_INVALID;
-    if (ln_w && K > 2048) return MPL_E_UNSUPPORTED;
+    if (ln_w && K > 1088) return MPL_E_UNSUPPORTED;      // the kernel combines at most 8 slice partials per row (K = 136 x 8)
     float* tr = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * (K / BK) * H2_W);
     hipLaunchKernelGGL(h2_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, tr);
     hipLaunchKernelGGL(h2_meta_kernel, dim3(1), dim3(256), 0, s, N, tr);
@@ -1306,7 +1306,7 @@ int launch_h2_gemm(const float* X, const unsigned short* A2, const float* a_inv,
                    float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, const float* o_scale, float* stats_out,
                    int M, int N, int K, int rpt, int epi, hipStream_t s) {
     if (M <= 0 || !W2 || (!C && !C2) || !h2_shape_ok(N, K) || rpt <= 0 || rpt > BM) return MPL_E_INVALID;
-    if (ln ? (!X || !stats || K > 2048) : !A2) return MPL_E_INVALID;
+    if (ln ? (!X || !stats || K > 1088) : !A2) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
     if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
     if (C2 && (N % (4 * BN) || !o_scale)) return MPL_E_INVALID;
