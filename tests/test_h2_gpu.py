@@ -165,6 +165,12 @@ def test_h2_shapes_are_validated():
     W = torch.zeros(544, 544, device=DEV)
     assert lib.mpl_pack_h2(W.data_ptr(), x.data_ptr(), x.data_ptr(), None, 544, 544, big.data_ptr(), _stream()) != 0    # half a LayerNorm
     assert lib.mpl_pack_h2_bytes(136, 2176) > 0              # fc2 of the FULL flag set (plain operand: any multiple of 544)
+    # a folded LayerNorm combines at most 8 slice partials per row: K = 1632 packs as a plain operand only
+    W3 = torch.zeros(136, 1632, device=DEV)
+    g3 = torch.ones(1632, device=DEV)
+    big3 = torch.zeros(lib.mpl_pack_h2_bytes(136, 1632), dtype=torch.uint8, device=DEV)
+    assert lib.mpl_pack_h2(W3.data_ptr(), x.data_ptr(), None, None, 136, 1632, big3.data_ptr(), _stream()) == 0
+    assert lib.mpl_pack_h2(W3.data_ptr(), x.data_ptr(), g3.data_ptr(), g3.data_ptr(), 136, 1632, big3.data_ptr(), _stream()) != 0
     assert lib.mpl_ln_linear_h2(x.data_ptr(), 64, 544, 0, 1e-6, big.data_ptr(), 544, 0, None, W.data_ptr(), None,
                                 W.data_ptr(), 16, _stream()) == -3
 
