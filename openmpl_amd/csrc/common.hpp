@@ -82,8 +82,9 @@ __device__ __forceinline__ float gelu_as(float x) {
     pl = fmaf(pl, t, -0.284496736f);
     pl = fmaf(pl, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
-    const float er = copysignf(fmaf(-pl * t, e, 1.0f), z);
-    return 0.5f * x * (1.0f + er);
+    // 0.5 x (1 + sign(x) (1 - p t e)) = h + |h| - |h| (p t e),  h = x / 2: no copysign, no 1 + erf
+    const float h = 0.5f * x, ah = fabsf(h);
+    return fmaf(-ah, (pl * t) * e, h + ah);
 }
 
 

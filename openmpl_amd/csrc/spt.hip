@@ -727,7 +727,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     const float4 k = ::mpl::ld4(Kb + ((j * SH + h) * SEQ + li) * 4);
 #pragma unroll
                     for (int t = 0; t < 5; ++t)
-                        sc[t][j] = fmaf(q[t].x, k.x, q[t].y * k.y) + fmaf(q[t].z, k.z, q[t].w * k.w);
+                        sc[t][j] = fmaf(q[t].w, k.w, fmaf(q[t].z, k.z, fmaf(q[t].y, k.y, q[t].x * k.x)));
                 }
                 float inv[5];
 #pragma unroll
