@@ -59,14 +59,21 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
         // ONCE, four views at a time with all their loads in flight together: one memory round trip per four views
         // instead of three per view.
         constexpr int NF = 9, VC = 4;
-        float acc[NF], gam[NF], bet[NF];
+        float acc[NF], gam[NF], bet[NF], hlw[NF], hlb[NF];
+        // EVERY parameter this wave needs is requested up front, together with the first rows: one memory round trip for the
+        // whole per-pose part (requested where they are used, the head LayerNorm vectors and the view weights each cost their
+        // own ~2 us round trip behind the wave reductions: 14 us of this 28-us kernel at any batch size)
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = lane + 64 * i;
             acc[i] = 0.f;
             gam[i] = f < E ? vn_w[f] : 0.f;
             bet[i] = f < E ? vn_b[f] : 0.f;
+            hlw[i] = (!y_out && f < E) ? hl_w[f] : 0.f;
+            hlb[i] = (!y_out && f < E) ? hl_b[f] : 0.f;
         }
+        const float wv_l = lane < V ? wm_w[lane] : 0.f;      // view weight v in lane v (V <= 32), broadcast by readlane below
+        const float wb = wm_b[0];
         for (int v0 = 0; v0 < V; v0 += VC) {
             float xv[VC][NF];
 #pragma unroll
@@ -92,12 +99,11 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
                     ss += t * t;
                 }
                 const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)E + 1e-6f);
-                const float wv = wm_w[v0 + u];
+                const float wv = __shfl(wv_l, v0 + u, 64);
 #pragma unroll
                 for (int i = 0; i < NF; ++i) acc[i] = fmaf(wv, (xv[u][i] - mean) * rstd * gam[i] + bet[i], acc[i]);
             }
         }
-        const float wb = wm_b[0];
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -129,15 +135,16 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int f = lane + 64 * i;
-                if (f < E) y[wave][f] = (acc[i] - mean) * rstd * hl_w[f] + hl_b[f];
+                if (f < E) y[wave][f] = (acc[i] - mean) * rstd * hlw[i] + hlb[i];
             }
         }
     }
     if (y_out) return;
     __syncthreads();
-    // Linear(E -> 3J) for the four poses out of LDS: thread = (pose, output), a complete dot product without any
-    // cross-lane reduction.  Thread o walks its weight row rotated by o (f = (i + o) mod E), so the 32 rows a half-wave
-    // reads -- E is a multiple of 32 banks -- hit 32 different banks.
+    // Linear(E -> 3J) for the four poses out of LDS: thread = (pose, output), a complete dot product without any cross-lane
+    // reduction, read as float4.  Thread o walks its weight row rotated by 4 o floats (f = (i + 4 o) mod E): the 16 lanes a
+    // ds_read_b128 serves together then sit on 16 different 16-byte bank groups (E = 544: row stride 544 + 4 = 548 = 36 mod 64
+    // dwords, and 36 o mod 64 is distinct for 16 consecutive o).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int np = (B - blockIdx.x * FH_POSES) < FH_POSES ? (B - blockIdx.x * FH_POSES) : FH_POSES;
@@ -145,15 +152,25 @@ __global__ __launch_bounds__(256) void fuse_head_kernel(const float* __restrict_
         const int p = t / n_out, o = t - p * n_out;
         const float* wr = hws + o * E;
         const float* yr = y[p];
-        float s0 = 0.f, s1 = 0.f;
-        int f = o % E;
-        for (int i = 0; i < E; i += 2) {
-            s0 = fmaf(yr[f], wr[f], s0);
-            f = f + 1 == E ? 0 : f + 1;
-            s1 = fmaf(yr[f], wr[f], s1);
-            f = f + 1 == E ? 0 : f + 1;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        int f = (4 * o) % E;
+        if ((E & 3) == 0) {
+#pragma unroll 4
+            for (int i = 0; i < E; i += 4) {
+                const float4 a4 = ld4(yr + f), w4 = ld4(wr + f);
+                sx = fmaf(a4.x, w4.x, sx);
+                sy = fmaf(a4.y, w4.y, sy);
+                sz = fmaf(a4.z, w4.z, sz);
+                sw = fmaf(a4.w, w4.w, sw);
+                f = f + 4 == E ? 0 : f + 4;
+            }
+        } else {
+            for (int i = 0; i < E; ++i) {
+                sx = fmaf(yr[f], wr[f], sx);
+                f = f + 1 == E ? 0 : f + 1;
+            }
         }
-        out[(size_t)(blockIdx.x * FH_POSES + p) * n_out + o] = poisoned ? __builtin_nanf("") : (s0 + s1) + hb[o];
+        out[(size_t)(blockIdx.x * FH_POSES + p) * n_out + o] = poisoned ? __builtin_nanf("") : ((sx + sy) + (sz + sw)) + hb[o];
     }
 }
 
