@@ -255,17 +255,25 @@ __global__ __launch_bounds__(256) void h2_entry_kernel(const float* __restrict__
     const int row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int ns = K / BN;
-    for (int sidx = 0; sidx < ns; ++sidx) {
-        const float* xr = X + (size_t)row * ldx + sidx * BN;
-        const bool on = lane < BN / 4;
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (on) v = ld4(xr + 4 * lane);
-        const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)BN;
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        const float ss = wave_sum(on ? (a * a + b * b) + (c * c + d * d) : 0.f);
-        if (lane == 0) {
-            stats[((size_t)row * ns + sidx) * 2] = mean;
-            stats[((size_t)row * ns + sidx) * 2 + 1] = ss;
+    const bool on = lane < BN / 4;
+    // the slices of the row are requested together (one memory round trip; one per slice made this kernel 8 us long)
+    for (int s0 = 0; s0 < ns; s0 += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = float4{0.f, 0.f, 0.f, 0.f};
+            if (on && s0 + u < ns) v[u] = ld4(X + (size_t)row * ldx + (s0 + u) * BN + 4 * lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u >= ns) break;
+            const float mean = wave_sum((v[u].x + v[u].y) + (v[u].z + v[u].w)) / (float)BN;
+            const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+            const float ss = wave_sum(on ? (a * a + b * b) + (c * c + d * d) : 0.f);
+            if (lane == 0) {
+                stats[((size_t)row * ns + s0 + u) * 2] = mean;
+                stats[((size_t)row * ns + s0 + u) * 2 + 1] = ss;
+            }
         }
     }
 }
