@@ -132,7 +132,7 @@ typedef struct mpl_weights {
     const float *head_ln_w, *head_ln_b;                    /* head.0 (J*d) */
     const float *head_w, *head_b;                          /* head.1 (3J, J*d),(3J) */
     uint32_t spt_packed;  /* != 0: EVERY block of every spt_set carries the operand of mpl_spt_pack in its qkv_w3 field: the
-                           * SPT Linear layers run as fp32 arithmetic on the bf16 matrix cores (spt3_kernel); 0: the fp32
+                           * SPT Linear layers run as fp32 arithmetic on the fp16 matrix cores (spt3_kernel); 0: the fp32
                            * matrix instructions read the nn.Linear weights in place */
     uint32_t reserved;
 } mpl_weights;
@@ -192,9 +192,13 @@ size_t mpl_ln_linear_x3_workspace_bytes(int M, int K);
 int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W3, int N, int epilogue,
                      const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Split operand of ONE SPT block (d = 32: qkv 96x32, proj 32x32, fc1 64x32, fc2 32x64): the four weights as three bf16
- * parts each in MFMA fragment order, mpl_spt_pack_bytes() = 48 KiB.  `block` is a HOST struct whose fp32 weight pointers
- * are device addresses; the result goes into the qkv_w3 field of the block's entry in the DEVICE array of mpl_spt_set. */
+/* Split operand of ONE SPT block (d = 32: qkv 96x32, proj 32x32, fc1 64x32, fc2 32x64): the four weights as two fp16 parts
+ * each (hi | lo, MFMA fragment order) under one exact power-of-two scale per output column, with norm1 / norm2 folded into
+ * the qkv / fc1 weights; behind them the epilogue vectors c_n (bias + folded LayerNorm offset), the multipliers sc_n and the
+ * static scales of the proj / fc2 inputs (the arithmetic of mpl_pack_h2).  mpl_spt_pack_bytes() = 48 KiB (34.6 KiB used).
+ * `block` is a HOST struct whose pointers are device addresses -- EVERY weight, bias and LayerNorm vector of the block must
+ * be set; the result goes into the qkv_w3 field of the block's entry in the DEVICE array of mpl_spt_set and is derived data:
+ * repack when any tensor of the block changes. */
 size_t mpl_spt_pack_bytes(void);
 int mpl_spt_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
 

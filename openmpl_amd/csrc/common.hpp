@@ -74,7 +74,10 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // value is as close to the fp64 one as with an fp32 libm erf: 4.7e-7 vs 4.4e-7 max abs over [-6, 6]) on the hardware
 // reciprocal and exp2: ~16 instructions instead of the ~40 of erff -- the MLP activation was a third of the SPT fc1 phase and
 // 16 k of the 76 k cycles of an FPT fc1 phase with erff.
-__device__ __forceinline__ float gelu_as(float x) {
+// gelu_as(x) * 2 hs for a power-of-two hs (hs = 1/2: the plain GELU): the static scale of a split operand rides on the 0.5
+__device__ __forceinline__ float gelu_as_scaled(float x, float hs);
+__device__ __forceinline__ float gelu_as(float x) { return gelu_as_scaled(x, 0.5f); }
+__device__ __forceinline__ float gelu_as_scaled(float x, float hs) {
     const float z = x * 0.70710678118654752440f, az = fabsf(z);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
     float pl = fmaf(1.061405429f, t, -1.453152027f);
@@ -83,7 +86,7 @@ __device__ __forceinline__ float gelu_as(float x) {
     pl = fmaf(pl, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
     // 0.5 x (1 + sign(x) (1 - p t e)) = h + |h| - |h| (p t e),  h = x / 2: no copysign, no 1 + erf
-    const float h = 0.5f * x, ah = fabsf(h);
+    const float h = hs * x, ah = fabsf(h);
     return fmaf(-ah, (pl * t) * e, h + ah);
 }
 

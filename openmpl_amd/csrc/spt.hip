@@ -495,10 +495,11 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
 //     q stays in registers, k / v go to LDS as K[j][h][s][4] (one ds_write_b128 per tile);
 //   * attention: the lane keeps its (sequence, head) and its <= 5 query joints; every K / V row is read once
 //     (contiguous 1-KiB wave reads) for all of them -- 34 ds_read_b128 per lane and block application instead of 145;
-//   * proj / fc1 / fc2: A fragments are read from LDS (attention output, LayerNorm-ed X, GELU output), split in
-//     registers (~45 VALU ops per fragment) and multiplied with weight fragments that the binding split once
-//     (mpl_spt_pack: 48 KiB per block, MFMA fragment order, prefetched one phase ahead); 1632 bf16 MFMAs of 16 cycles
-//     per block application instead of 2176 fp32 MFMAs of 32.
+//   * proj / fc1 / fc2: A fragments are read from LDS (attention output, normalised X, GELU output), split in registers
+//     into two fp16 parts (~20 VALU ops per fragment) and multiplied with weight fragments that the binding split once
+//     (mpl_spt_pack: fp16 hi | lo in MFMA fragment order under exact power-of-two scales, LayerNorm gain / offset and the
+//     biases folded in, prefetched one phase ahead): the arithmetic of h2_gemm.hip -- 816 fp16 MFMAs of 16 cycles per block
+//     application (round 2: 1632 on three bf16 parts; round 1: 2176 fp32 MFMAs of 32).
 // LDS: X[272][36] | K[17][8][16][4] | V[17][8][16][4] | ATT[272][36]; the MLP hidden HID[272][68] aliases K | V | ATT.
 constexpr int ATS = 36;                       // ATT row stride (floats)
 constexpr int HS = 68;                        // HID row stride (floats)
@@ -506,82 +507,164 @@ constexpr int KV_F = SJ * SH * SEQ * 4;       // 8704 floats each
 constexpr int SPT3_RING_BYTES = (ROWS * XS + 2 * KV_F + ROWS * ATS) * 4;   // 147968: X | K | V | ATT
 constexpr int SPT3_LDS_BYTES = 160 * 1024;          // + 15872 B: staged weights of the next phase | parameter vectors
 // Weights and parameter vectors of a phase are staged in LDS while the phase BEFORE it runs (LDS-DMA for the packed
-// weights, one float4 per thread for the 352 bias / LayerNorm values of a block): a phase that starts with ~16 global
+// weights, one float4 per thread for the 456 epilogue values of a block): a phase that starts with ~16 global
 // loads per lane waits ~1.5 k cycles for L2 before its first MFMA, five times per block application (14 % of the kernel).
-//   S_W   spare + 0      12 KiB  proj weights (staged during qkv + attention), then fc2 weights (staged during fc1)
-//   S_PAR spare + 12 KiB 2 x 352 floats, double buffered by block application (staged during fc2 of the one before)
-//   F1    K + 0          12 KiB  fc1 weights (staged during proj: K is dead after the attention); HID starts behind it
-//   Q     ATT + 20 KiB   18 KiB  qkv weights of the NEXT application (staged during fc2; HID ends at ATT + 16.3 KiB)
+//   S_W   spare + 0      8 KiB   proj weights (4 KiB, staged during qkv + attention), then fc2 weights (staged during fc1)
+//   S_PAR spare + 8 KiB  2 x 456 floats, double buffered by block application (staged during fc2 of the one before)
+//   F1    K + 0          8 KiB   fc1 weights (staged during proj: K is dead after the attention); HID starts 12 KiB in
+//   Q     ATT + 20 KiB   12 KiB  qkv weights of the NEXT application (staged during fc2; HID ends at ATT + 16.3 KiB)
 constexpr int SPT3_HID_OFF = 3072;                  // floats: HID = K + 12 KiB
 constexpr int SPT3_Q_OFF = 20480;                   // bytes into ATT
-constexpr int SPT3_NPAR = 352;                      // floats of parameter vectors per block
+constexpr int SPT3_NPAR = 456;                      // floats of epilogue vectors per block: c[224] | sc[224] | scalars[8]
 static_assert(SPT3_HID_OFF + ROWS * HS <= 2 * KV_F + ROWS * ATS, "HID does not fit its alias");
 static_assert((SPT3_HID_OFF + ROWS * HS - 2 * KV_F) * 4 <= SPT3_Q_OFF, "HID reaches into the staged qkv weights");
-static_assert(SPT3_Q_OFF + 18 * 1024 <= ROWS * ATS * 4, "staged qkv weights do not fit behind HID in ATT");
-static_assert(SPT3_RING_BYTES + 12 * 1024 + 2 * SPT3_NPAR * 4 <= SPT3_LDS_BYTES, "spare LDS too small");
-constexpr int SPT_PACK_QKV = 0, SPT_PACK_PROJ = 18 * 1024, SPT_PACK_FC1 = 24 * 1024, SPT_PACK_FC2 = 36 * 1024;
+static_assert(SPT3_Q_OFF + 12 * 1024 <= ROWS * ATS * 4, "staged qkv weights do not fit behind HID in ATT");
+static_assert(SPT3_RING_BYTES + 8 * 1024 + 2 * SPT3_NPAR * 4 <= SPT3_LDS_BYTES, "spare LDS too small");
+// packed block (mpl_spt_pack): fp16 hi | lo fragments of the four weight matrices (2 KiB per 16-column x 32-k unit), then
+// the epilogue vectors
+constexpr int SPT_PACK_QKV = 0, SPT_PACK_PROJ = 12 * 1024, SPT_PACK_FC1 = 16 * 1024, SPT_PACK_FC2 = 24 * 1024;
+constexpr int SPT_PACK_VEC = 32 * 1024;
 constexpr int SPT_PACK_BYTES = 48 * 1024;
+constexpr int SPT_C_QKV = 0, SPT_C_PROJ = 96, SPT_C_FC1 = 128, SPT_C_FC2 = 192, SPT_NCOL = 224;
+constexpr float SPT_SA = 1024.0f;                   // scale of a normalised LayerNorm input (|z| <= sqrt(32))
+constexpr float SPT_QS = 0.5f * 1.4426950408889634f;   // hd^-0.5 log2 e, folded into the q columns (scores in the exp2 domain)
 
-typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void spt_split3(const float (&x)[8], sbf16x8& hi, sbf16x8& mid, sbf16x8& lo) {
-    float r[8], r2[8];
+// 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept): h2_gemm.hip
+__device__ __forceinline__ void spt_split2(const float (&x)[8], sf16x8& hi, sf16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) hi[i] = (__bf16)x[i];
+    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = x[i] - (float)hi[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mid[i] = (__bf16)r[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r2[i] = r[i] - (float)mid[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lo[i] = (__bf16)r2[i];
+    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
+}
+// largest power of two p with p * v <= 2^15 (v > 0, finite); 1 for v == 0
+__device__ inline float spt_window_scale(float v) {
+    if (!(v > 0.f) || !(v < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(32768.0f / v, &e);
+    e = e - 1 < -100 ? -100 : (e - 1 > 100 ? 100 : e - 1);
+    return ldexpf(1.0f, e);
 }
 
-// one thread per (fragment, lane): fragment f of the packed block = 8 consecutive k of one weight row, three parts
-__global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__ qkv_w, const float* __restrict__ proj_w,
-                                                        const float* __restrict__ fc1_w, const float* __restrict__ fc2_w,
-                                                        sbf16x8* __restrict__ dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // (tile-k unit) * 64 + lane; 16 units: 6 qkv, 2 proj, 4 fc1, 4 fc2
-    if (idx >= 16 * 64) return;
-    const int lane = idx & 63, u = idx >> 6, li = lane & 15, kq = lane >> 4;
-    const float* src;
-    if (u < 6) src = qkv_w + (size_t)(16 * u + li) * SD + 8 * kq;
-    else if (u < 8) src = proj_w + (size_t)(16 * (u - 6) + li) * SD + 8 * kq;
-    else if (u < 12) src = fc1_w + (size_t)(16 * (u - 8) + li) * SD + 8 * kq;
-    else src = fc2_w + (size_t)(16 * ((u - 12) >> 1) + li) * (2 * SD) + 32 * ((u - 12) & 1) + 8 * kq;   // [n][ks]
-    float x[8];
+// The D = 32 Linear layers of an SPT block as split-operand fp16 GEMMs (the arithmetic of h2_gemm.hip: x = hi + lo, three
+// products, exact power-of-two scales): ONE workgroup packs a block.
+//   * LayerNorm GEMMs (qkv, fc1): gamma is folded into W, beta and the bias into c_n = b_n + sum_k beta_k W_nk; the kernel
+//     multiplies z = (x - mean) rstd 2^10;
+//   * every column n has its own scale sw_n (max_k |W'_nk| sw_n in [2^13, 2^14)) that the epilogue multiplier sc_n takes out;
+//   * the inputs of proj (attention output) and fc2 (GELU output) carry ONE static scale each from the data-free bound
+//     |LN(x) . W'_n + c_n| <= sqrt(32) |W'_n|_2 + |c_n| of the producing columns (v columns of qkv; fc1), window 2^15;
+//   * the q columns also carry hd^-0.5 log2 e (the scores are formed in the exp2 domain).
+// Layout: fragments [16 units][hi | lo][64 lanes][8 fp16] (units: 6 qkv, 2 proj, 4 fc1, 4 fc2 = (n tile, k step)), then at
+// SPT_PACK_VEC floats c[224] | sc[224] | {s_att, s_hid / 2, ...}: columns qkv 0..95, proj 96.., fc1 128.., fc2 192..
+__global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__ qkv_w, const float* __restrict__ qkv_b,
+                                                        const float* __restrict__ ln1_w, const float* __restrict__ ln1_b,
+                                                        const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+                                                        const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
+                                                        const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
+                                                        const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
+                                                        char* __restrict__ dst) {
+    __shared__ float Wf[8192];                  // qkv' [96][32] | proj [32][32] | fc1' [64][32] | fc2 [32][64]
+    __shared__ float cn[SPT_NCOL], sw[SPT_NCOL], bnd[SPT_NCOL], scal[2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8192; i += 256) {
+        float w;
+        if (i < 3072) w = qkv_w[i] * ln1_w[i & 31];
+        else if (i < 4096) w = proj_w[i - 3072];
+        else if (i < 6144) w = fc1_w[i - 4096] * ln2_w[i & 31];
+        else w = fc2_w[i - 6144];
+        Wf[i] = w;
+    }
+    __syncthreads();
+    if (tid < SPT_NCOL) {
+        const int n = tid;
+        const float *wr, *raw, *beta = nullptr;
+        int K = 32;
+        float bias;
+        if (n < 96) { wr = Wf + n * 32; raw = qkv_w + n * 32; beta = ln1_b; bias = qkv_b[n]; }
+        else if (n < 128) { wr = Wf + 3072 + (n - 96) * 32; raw = proj_w + (n - 96) * 32; bias = proj_b[n - 96]; }
+        else if (n < 192) { wr = Wf + 4096 + (n - 128) * 32; raw = fc1_w + (n - 128) * 32; beta = ln2_b; bias = fc1_b[n - 128]; }
+        else { wr = Wf + 6144 + (n - 192) * 64; raw = fc2_w + (n - 192) * 64; bias = fc2_b[n - 192]; K = 64; }
+        float amax = 0.f;
+        double ss = 0.0, c = (double)bias;
+        for (int k = 0; k < K; ++k) {
+            amax = fmaxf(amax, fabsf(wr[k]));
+            ss += (double)wr[k] * (double)wr[k];
+            if (beta) c += (double)raw[k] * (double)beta[k];
+        }
+        float s = 1.0f;
+        if (amax > 0.f && amax < 3.0e38f) {
+            int e;
+            (void)frexpf(amax, &e);             // amax = m 2^e, m in [0.5, 1): amax 2^(14 - e) in [2^13, 2^14)
+            e = 14 - e;
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            s = ldexpf(1.0f, e);
+        }
+        cn[n] = (float)c;
+        sw[n] = s;
+        bnd[n] = beta ? (float)(sqrt(32.0) * sqrt(ss)) + fabsf((float)c) : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float batt = 0.f, bhid = 0.f;
+        for (int n = 64; n < 96; ++n) batt = fmaxf(batt, bnd[n]);                    // v columns of qkv
+        for (int n = SPT_C_FC1; n < SPT_C_FC2; ++n) bhid = fmaxf(bhid, bnd[n]);
+        scal[0] = spt_window_scale(batt);
+        scal[1] = spt_window_scale(bhid);
+    }
+    __syncthreads();
+    float* vec = reinterpret_cast<float*>(dst + SPT_PACK_VEC);
+    if (tid < SPT_NCOL) {
+        const int n = tid;
+        float c = cn[n], sc;
+        if (n < 96) sc = 1.0f / (SPT_SA * sw[n]);
+        else if (n < 128) sc = 1.0f / (scal[0] * sw[n]);
+        else if (n < 192) sc = 1.0f / (SPT_SA * sw[n]);
+        else sc = 1.0f / (scal[1] * sw[n]);
+        if (n < 32) { c *= SPT_QS; sc *= SPT_QS; }
+        vec[n] = c;
+        vec[SPT_NCOL + n] = sc;
+    }
+    if (tid < 8) vec[2 * SPT_NCOL + tid] = tid == 0 ? scal[0] : (tid == 1 ? 0.5f * scal[1] : 0.f);
+    // fragment f of the packed block = 8 consecutive k of one weight row (scaled by its column scale), two parts
+    sf16x8* frag = reinterpret_cast<sf16x8*>(dst);
+    for (int idx = tid; idx < 16 * 64; idx += 256) {
+        const int lane = idx & 63, u = idx >> 6, li = lane & 15, kq = lane >> 4;
+        const float* src;
+        int n;
+        if (u < 6) { n = 16 * u + li; src = Wf + n * 32 + 8 * kq; }
+        else if (u < 8) { n = 16 * (u - 6) + li; src = Wf + 3072 + n * 32 + 8 * kq; n += SPT_C_PROJ; }
+        else if (u < 12) { n = 16 * (u - 8) + li; src = Wf + 4096 + n * 32 + 8 * kq; n += SPT_C_FC1; }
+        else { n = 16 * ((u - 12) >> 1) + li; src = Wf + 6144 + n * 64 + 32 * ((u - 12) & 1) + 8 * kq; n += SPT_C_FC2; }   // [n][ks]
+        float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = src[j];
-    sbf16x8 hi, mid, lo;
-    spt_split3(x, hi, mid, lo);
-    sbf16x8* o = dst + (size_t)u * 3 * 64 + lane;
-    o[0] = hi;
-    o[64] = mid;
-    o[128] = lo;
+        for (int j = 0; j < 8; ++j) x[j] = src[j] * sw[n];
+        sf16x8 hi, lo;
+        spt_split2(x, hi, lo);
+        frag[(size_t)(u * 2) * 64 + lane] = hi;
+        frag[(size_t)(u * 2 + 1) * 64 + lane] = lo;
+    }
 }
 
 int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s) {
-    if (!bw_host || !dst || !bw_host->qkv_w || !bw_host->proj_w || !bw_host->fc1_w || !bw_host->fc2_w) return MPL_E_INVALID;
-    hipLaunchKernelGGL(spt_pack_kernel, dim3(4), dim3(256), 0, s, bw_host->qkv_w, bw_host->proj_w, bw_host->fc1_w, bw_host->fc2_w,
-                       reinterpret_cast<sbf16x8*>(dst));
+    const mpl_block_weights* b = bw_host;
+    if (!b || !dst || !b->qkv_w || !b->proj_w || !b->fc1_w || !b->fc2_w || !b->qkv_b || !b->proj_b || !b->fc1_b || !b->fc2_b ||
+        !b->ln1_w || !b->ln1_b || !b->ln2_w || !b->ln2_b)
+        return MPL_E_INVALID;
+    hipLaunchKernelGGL(spt_pack_kernel, dim3(1), dim3(256), 0, s, b->qkv_w, b->qkv_b, b->ln1_w, b->ln1_b, b->proj_w, b->proj_b, b->fc1_w,
+                       b->fc1_b, b->ln2_w, b->ln2_b, b->fc2_w, b->fc2_b, reinterpret_cast<char*>(dst));
     return hip_check_launch();
 }
 
 size_t spt_pack_bytes() { return SPT_PACK_BYTES; }
 
-// acc(16 x 16, transposed) += sum of the six significant part products of A (hi, mid, lo) and W (hi, mid, lo)
-__device__ __forceinline__ f32x4 mfma6(const sbf16x8 (&w)[3], const sbf16x8& ah, const sbf16x8& am, const sbf16x8& al, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], al, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], ah, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], am, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], am, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], ah, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], ah, c, 0, 0, 0);
+// acc(16 x 16, transposed) += the three significant part products of A (hi, lo) and W (hi, lo): lo.hi, hi.lo, hi.hi
+__device__ __forceinline__ f32x4 mfma3(const sf16x8 (&w)[2], const sf16x8& ah, const sf16x8& al, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], al, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], ah, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], ah, c, 0, 0, 0);
     return c;
 }
-
-typedef const __attribute__((address_space(1))) sbf16x8* gwp;
 
 __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -591,7 +674,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     float* ATT = Vb + KV_F;
     float* HID = Kb + SPT3_HID_OFF;                // alias (K, V, ATT are dead between proj and the next qkv)
     char* S_W = reinterpret_cast<char*>(ATT + ROWS * ATS);
-    float* S_PAR = reinterpret_cast<float*>(S_W + 12 * 1024);
+    float* S_PAR = reinterpret_cast<float*>(S_W + 8 * 1024);
     char* R_F1 = reinterpret_cast<char*>(Kb);
     char* R_Q = reinterpret_cast<char*>(ATT) + SPT3_Q_OFF;
 
@@ -620,20 +703,10 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
             ::mpl::dma16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(pack) + byte_off + i * 1024) + lane * 4,
                          l0 + (unsigned)(i * 1024));
     };
-    // the 352 parameter values of a block, one float4 per thread (tid < 88):
-    // qkv_b 96 | ln1_w 32 | ln1_b 32 | proj_b 32 | fc1_b 64 | ln2_w 32 | ln2_b 32 | fc2_b 32
+    // the epilogue vectors of a block (c | sc | scalars, written by mpl_spt_pack behind the fragments), one float4 per thread
     auto load_par = [&](const mpl_block_weights& b) -> float4 {
         if (tid >= SPT3_NPAR / 4) return float4{0.f, 0.f, 0.f, 0.f};
-        const int i = tid;
-        gfp src = i < 24 ? G(b.qkv_b) + 4 * i
-                         : i < 32 ? G(b.ln1_w) + 4 * (i - 24)
-                         : i < 40 ? G(b.ln1_b) + 4 * (i - 32)
-                         : i < 48 ? G(b.proj_b) + 4 * (i - 40)
-                         : i < 64 ? G(b.fc1_b) + 4 * (i - 48)
-                         : i < 72 ? G(b.ln2_w) + 4 * (i - 64)
-                         : i < 80 ? G(b.ln2_b) + 4 * (i - 72)
-                                  : G(b.fc2_b) + 4 * (i - 80);
-        return ld4(src);
+        return ld4(G(reinterpret_cast<const float*>(reinterpret_cast<const char*>(b.qkv_w3) + SPT_PACK_VEC)) + 4 * tid);
     };
     auto store_par = [&](int app_of, const float4& v) {
         if (tid < SPT3_NPAR / 4) st4(S_PAR + (app_of & 1) * SPT3_NPAR + 4 * tid, v);
@@ -641,7 +714,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     mpl_block_weights bw;
     if (p.n_apps > 0) {                            // application 0: its qkv weights and parameters, under the embedding
         bw = set.blocks[p.sched[0] & 0x7f];
-        stage_w(R_Q, bw.qkv_w3, SPT_PACK_QKV, 18);
+        stage_w(R_Q, bw.qkv_w3, SPT_PACK_QKV, 12);
     }
     const float4 par0 = p.n_apps > 0 ? load_par(bw) : float4{0.f, 0.f, 0.f, 0.f};
     spt_embed<true>(p, set, X, tid, b0, pose, ray, cen);
@@ -649,15 +722,14 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     phase_sync();
 
     const int nj = part == 0 ? 5 : 4;              // joints part, part + 4, ... of this wave
-    auto load_w = [&](const char* region, int unit, sbf16x8 (&w)[3]) {      // from the staged section in LDS
-        const sbf16x8* g = reinterpret_cast<const sbf16x8*>(region) + (size_t)unit * 3 * 64 + lane;
+    auto load_w = [&](const char* region, int unit, sf16x8 (&w)[2]) {      // from the staged section in LDS
+        const sf16x8* g = reinterpret_cast<const sf16x8*>(region) + (size_t)unit * 2 * 64 + lane;
         w[0] = g[0];
         w[1] = g[64];
-        w[2] = g[128];
     };
-    // LayerNorm-ed, split A fragment of row tile m (K = 32): lane (s, kq) holds k = 8 kq .. 8 kq + 7 of row 16 m + s
-    auto ln_frag = [&](int m, const float4& g0, const float4& g1, const float4& e0, const float4& e1, sbf16x8& ah, sbf16x8& am,
-                       sbf16x8& al) {
+    // normalised, split A fragment of row tile m (K = 32): lane (s, kq) holds k = 8 kq .. 8 kq + 7 of row 16 m + s;
+    // z = (x - mean) rstd 2^10 (gamma / beta live in the packed weights / c)
+    auto ln_frag = [&](int m, sf16x8& ah, sf16x8& al) {
         const float* xr = X + (m * 16 + li) * XS + 8 * kq;
         float4 x0 = ::mpl::ld4(xr), x1 = ::mpl::ld4(xr + 4);
         float sm = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
@@ -668,15 +740,15 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) +
                    ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
         ss = ::mpl::xor32_add(::mpl::xor16_add(ss));
-        const float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / 32.0f) + 1e-6f);   // v_rsq_f32 (1 ulp): not the ~20-instruction IEEE 1 / sqrt
-        const float y[8] = {x0.x * rstd * g0.x + e0.x, x0.y * rstd * g0.y + e0.y, x0.z * rstd * g0.z + e0.z, x0.w * rstd * g0.w + e0.w,
-                            x1.x * rstd * g1.x + e1.x, x1.y * rstd * g1.y + e1.y, x1.z * rstd * g1.z + e1.z, x1.w * rstd * g1.w + e1.w};
-        spt_split3(y, ah, am, al);
+        const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / 32.0f) + 1e-6f) * SPT_SA;   // v_rsq_f32 (1 ulp)
+        const float y[8] = {x0.x * rs, x0.y * rs, x0.z * rs, x0.w * rs, x1.x * rs, x1.y * rs, x1.z * rs, x1.w * rs};
+        spt_split2(y, ah, al);
     };
-    auto raw_frag = [&](const float* rowp, sbf16x8& ah, sbf16x8& am, sbf16x8& al) {
+    // plain A fragment: the producer already applied the static scale of the operand (attention output, GELU output)
+    auto raw_frag = [&](const float* rowp, sf16x8& ah, sf16x8& al) {
         const float4 x0 = ::mpl::ld4(rowp), x1 = ::mpl::ld4(rowp + 4);
         const float y[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        spt_split3(y, ah, am, al);
+        spt_split2(y, ah, al);
     };
 
     for (int app = 0; app < p.n_apps; ++app) {
@@ -684,44 +756,44 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         bw = set.blocks[p.sched[app] & 0x7f];
         const unsigned short* pack = bw.qkv_w3;
         const float* par = S_PAR + (app & 1) * SPT3_NPAR;
-        stage_w(S_W, pack, SPT_PACK_PROJ, 6);      // proj weights: land during qkv + attention
+        stage_w(S_W, pack, SPT_PACK_PROJ, 4);      // proj weights: land during qkv + attention
         // ---------------- qkv: this wave's q, k, v tiles (head group hg) of its joints
         {
-            sbf16x8 wq[3][3];
-            float4 bq[3];
+            sf16x8 wq[3][2];
+            float4 bq[3], sq[3];                   // c_n and sc_n of this lane's q, k, v columns (q: times hd^-0.5 log2 e)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 load_w(R_Q, 2 * c + hg, wq[c]);
-                bq[c] = ::mpl::ld4(par + 32 * c + 16 * hg + 4 * kq);
+                bq[c] = ::mpl::ld4(par + SPT_C_QKV + 32 * c + 16 * hg + 4 * kq);
+                sq[c] = ::mpl::ld4(par + SPT_NCOL + SPT_C_QKV + 32 * c + 16 * hg + 4 * kq);
             }
-            const float4 g0 = ::mpl::ld4(par + 96 + 8 * kq), g1 = ::mpl::ld4(par + 96 + 8 * kq + 4);
-            const float4 e0 = ::mpl::ld4(par + 128 + 8 * kq), e1 = ::mpl::ld4(par + 128 + 8 * kq + 4);
             float4 q[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 q[t] = float4{0.f, 0.f, 0.f, 0.f};
                 if (t < nj) {
                     const int j = part + 4 * t;
-                    sbf16x8 ah, am, al;
-                    ln_frag(j, g0, g1, e0, e1, ah, am, al);
+                    sf16x8 ah, al;
+                    ln_frag(j, ah, al);
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 cq = mfma6(wq[0], ah, am, al, z), ck = mfma6(wq[1], ah, am, al, z), cv = mfma6(wq[2], ah, am, al, z);
-                    q[t] = float4{cq[0] + bq[0].x, cq[1] + bq[0].y, cq[2] + bq[0].z, cq[3] + bq[0].w};
+                    const f32x4 cq = mfma3(wq[0], ah, al, z), ck = mfma3(wq[1], ah, al, z), cv = mfma3(wq[2], ah, al, z);
+                    q[t] = float4{fmaf(cq[0], sq[0].x, bq[0].x), fmaf(cq[1], sq[0].y, bq[0].y), fmaf(cq[2], sq[0].z, bq[0].z),
+                                  fmaf(cq[3], sq[0].w, bq[0].w)};
                     const int h = 4 * hg + kq;
-                    st4(Kb + ((j * SH + h) * SEQ + li) * 4, float4{ck[0] + bq[1].x, ck[1] + bq[1].y, ck[2] + bq[1].z, ck[3] + bq[1].w});
-                    st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{cv[0] + bq[2].x, cv[1] + bq[2].y, cv[2] + bq[2].z, cv[3] + bq[2].w});
+                    st4(Kb + ((j * SH + h) * SEQ + li) * 4, float4{fmaf(ck[0], sq[1].x, bq[1].x), fmaf(ck[1], sq[1].y, bq[1].y),
+                                                                    fmaf(ck[2], sq[1].z, bq[1].z), fmaf(ck[3], sq[1].w, bq[1].w)});
+                    st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{fmaf(cv[0], sq[2].x, bq[2].x), fmaf(cv[1], sq[2].y, bq[2].y),
+                                                                    fmaf(cv[2], sq[2].z, bq[2].z), fmaf(cv[3], sq[2].w, bq[2].w)});
                 }
             }
             phase_sync();
             // ---------------- attention (:55-64): lane = (sequence li, head h), its <= 5 query joints against all 17 keys.
-            // Scores in the exp2 domain (q carries hd^-0.5 log2 e = 0.5 log2 e), the probabilities stay unnormalised until
-            // the output row is complete (one multiplication per output instead of one per probability).
+            // Scores in the exp2 domain (the q columns carry hd^-0.5 log2 e = 0.5 log2 e from their epilogue multiplier), the
+            // probabilities stay unnormalised until the output row is complete; the output leaves with the static scale of the
+            // proj operand (par[448], a power of two).
             {
                 const int h = 4 * hg + kq;
                 float sc[5][SJ];
-                constexpr float QS = 0.5f * 1.4426950408889634f;
-#pragma unroll
-                for (int t = 0; t < 5; ++t) q[t] = float4{q[t].x * QS, q[t].y * QS, q[t].z * QS, q[t].w * QS};
 #pragma unroll
                 for (int j = 0; j < SJ; ++j) {
                     const float4 k = ::mpl::ld4(Kb + ((j * SH + h) * SEQ + li) * 4);
@@ -729,6 +801,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     for (int t = 0; t < 5; ++t)
                         sc[t][j] = fmaf(q[t].w, k.w, fmaf(q[t].z, k.z, fmaf(q[t].y, k.y, q[t].x * k.x)));
                 }
+                const float s_att = par[2 * SPT_NCOL];
                 float inv[5];
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
@@ -741,7 +814,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                         sc[t][j] = __builtin_amdgcn_exp2f(sc[t][j] - mx);
                         l += sc[t][j];
                     }
-                    inv[t] = __builtin_amdgcn_rcpf(l);                      // v_rcp_f32 (1 ulp)
+                    inv[t] = __builtin_amdgcn_rcpf(l) * s_att;              // v_rcp_f32 (1 ulp)
                     if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales the query row
                         const int b = b0 + li;
                         inv[t] *= (b < p.B && t < nj) ? pose[((size_t)b * SJ + (part + 4 * t)) * 3 + 2] : 0.f;
@@ -763,7 +836,13 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 5; ++t) o[t] = float4{o[t].x * inv[t], o[t].y * inv[t], o[t].z * inv[t], o[t].w * inv[t]};
+                for (int t = 0; t < 5; ++t) {
+                    o[t] = float4{o[t].x * inv[t], o[t].y * inv[t], o[t].z * inv[t], o[t].w * inv[t]};
+                    // the confidence weights are data: only with them can the operand leave the window its static scale assumes
+                    if (weighted)
+                        o[t] = float4{__builtin_amdgcn_fmed3f(o[t].x, -65000.f, 65000.f), __builtin_amdgcn_fmed3f(o[t].y, -65000.f, 65000.f),
+                                      __builtin_amdgcn_fmed3f(o[t].z, -65000.f, 65000.f), __builtin_amdgcn_fmed3f(o[t].w, -65000.f, 65000.f)};
+                }
 #pragma unroll
                 for (int t = 0; t < 5; ++t)
                     if (t < nj) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
@@ -772,53 +851,56 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         phase_sync();
         // ---------------- X += attn_out . Wproj^T + b : 17 x 2 tiles, dealt as contiguous ranges of the (m, n) list
         {
-            stage_w(R_F1, pack, SPT_PACK_FC1, 12);      // fc1 weights into the dead K tile
-            sbf16x8 wp[2][3];
-            float4 bp[2];
+            stage_w(R_F1, pack, SPT_PACK_FC1, 8);       // fc1 weights into the dead K tile
+            sf16x8 wp[2][2];
+            float4 bp[2], sp[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 load_w(S_W, n, wp[n]);
-                bp[n] = ::mpl::ld4(par + 160 + 16 * n + 4 * kq);
+                bp[n] = ::mpl::ld4(par + SPT_C_PROJ + 16 * n + 4 * kq);
+                sp[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_PROJ + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
-                sbf16x8 ah, am, al;
-                raw_frag(ATT + (m * 16 + li) * ATS + 8 * kq, ah, am, al);
+                sf16x8 ah, al;
+                raw_frag(ATT + (m * 16 + li) * ATS + 8 * kq, ah, al);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int u = 2 * m + n;
                     if (u < lo || u >= hi) continue;
-                    const f32x4 c = mfma6(wp[n], ah, am, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 c = mfma3(wp[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
                     float* xd = X + (m * 16 + li) * XS + 16 * n + 4 * kq;
                     const float4 x = ::mpl::ld4(xd);
-                    st4(xd, float4{x.x + (c[0] + bp[n].x), x.y + (c[1] + bp[n].y), x.z + (c[2] + bp[n].z), x.w + (c[3] + bp[n].w)});
+                    st4(xd, float4{x.x + fmaf(c[0], sp[n].x, bp[n].x), x.y + fmaf(c[1], sp[n].y, bp[n].y),
+                                   x.z + fmaf(c[2], sp[n].z, bp[n].z), x.w + fmaf(c[3], sp[n].w, bp[n].w)});
                 }
             }
         }
         phase_sync();
         // ---------------- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles
         {
-            stage_w(S_W, pack, SPT_PACK_FC2, 12);       // fc2 weights (the proj weights in S_W were read a phase ago)
-            sbf16x8 w1[4][3];
-            float4 b1[4];
+            stage_w(S_W, pack, SPT_PACK_FC2, 8);        // fc2 weights (the proj weights in S_W were read a phase ago)
+            sf16x8 w1[4][2];
+            float4 b1[4], s1[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 load_w(R_F1, n, w1[n]);
-                b1[n] = ::mpl::ld4(par + 192 + 16 * n + 4 * kq);
+                b1[n] = ::mpl::ld4(par + SPT_C_FC1 + 16 * n + 4 * kq);
+                s1[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_FC1 + 16 * n + 4 * kq);
             }
-            const float4 g0 = ::mpl::ld4(par + 256 + 8 * kq), g1 = ::mpl::ld4(par + 256 + 8 * kq + 4);
-            const float4 e0 = ::mpl::ld4(par + 288 + 8 * kq), e1 = ::mpl::ld4(par + 288 + 8 * kq + 4);
+            const float hs = par[2 * SPT_NCOL + 1];     // half the static scale of the fc2 operand (a power of two)
             const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
             for (int m = lo >> 2; m <= ((hi - 1) >> 2); ++m) {
-                sbf16x8 ah, am, al;
-                ln_frag(m, g0, g1, e0, e1, ah, am, al);
+                sf16x8 ah, al;
+                ln_frag(m, ah, al);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const int u = 4 * m + n;
                     if (u < lo || u >= hi) continue;
-                    const f32x4 c = mfma6(w1[n], ah, am, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 c = mfma3(w1[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
                     st4(HID + (m * 16 + li) * HS + 16 * n + 4 * kq,
-                        float4{gelu_as(c[0] + b1[n].x), gelu_as(c[1] + b1[n].y), gelu_as(c[2] + b1[n].z), gelu_as(c[3] + b1[n].w)});
+                        float4{gelu_as_scaled(fmaf(c[0], s1[n].x, b1[n].x), hs), gelu_as_scaled(fmaf(c[1], s1[n].y, b1[n].y), hs),
+                               gelu_as_scaled(fmaf(c[2], s1[n].z, b1[n].z), hs), gelu_as_scaled(fmaf(c[3], s1[n].w, b1[n].w), hs)});
                 }
             }
         }
@@ -829,31 +911,33 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
             float4 parn = float4{0.f, 0.f, 0.f, 0.f};
             if (app + 1 < p.n_apps) {
                 const mpl_block_weights bn = set.blocks[p.sched[app + 1] & 0x7f];
-                stage_w(R_Q, bn.qkv_w3, SPT_PACK_QKV, 18);
+                stage_w(R_Q, bn.qkv_w3, SPT_PACK_QKV, 12);
                 parn = load_par(bn);
             }
-            sbf16x8 w2[2][2][3];
-            float4 b2[2];
+            sf16x8 w2[2][2][2];
+            float4 b2[2], s2[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 load_w(S_W, 2 * n, w2[n][0]);
                 load_w(S_W, 2 * n + 1, w2[n][1]);
-                b2[n] = ::mpl::ld4(par + 320 + 16 * n + 4 * kq);
+                b2[n] = ::mpl::ld4(par + SPT_C_FC2 + 16 * n + 4 * kq);
+                s2[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_FC2 + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
-                sbf16x8 ah0, am0, al0, ah1, am1, al1;
-                raw_frag(HID + (m * 16 + li) * HS + 8 * kq, ah0, am0, al0);
-                raw_frag(HID + (m * 16 + li) * HS + 32 + 8 * kq, ah1, am1, al1);
+                sf16x8 ah0, al0, ah1, al1;
+                raw_frag(HID + (m * 16 + li) * HS + 8 * kq, ah0, al0);
+                raw_frag(HID + (m * 16 + li) * HS + 32 + 8 * kq, ah1, al1);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int u = 2 * m + n;
                     if (u < lo || u >= hi) continue;
-                    f32x4 c = mfma6(w2[n][0], ah0, am0, al0, f32x4{0.f, 0.f, 0.f, 0.f});
-                    c = mfma6(w2[n][1], ah1, am1, al1, c);
+                    f32x4 c = mfma3(w2[n][0], ah0, al0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    c = mfma3(w2[n][1], ah1, al1, c);
                     float* xd = X + (m * 16 + li) * XS + 16 * n + 4 * kq;
                     const float4 x = ::mpl::ld4(xd);
-                    st4(xd, float4{x.x + (c[0] + b2[n].x), x.y + (c[1] + b2[n].y), x.z + (c[2] + b2[n].z), x.w + (c[3] + b2[n].w)});
+                    st4(xd, float4{x.x + fmaf(c[0], s2[n].x, b2[n].x), x.y + fmaf(c[1], s2[n].y, b2[n].y),
+                                   x.z + fmaf(c[2], s2[n].z, b2[n].z), x.w + fmaf(c[3], s2[n].w, b2[n].w)});
                 }
             }
             if (app + 1 < p.n_apps) store_par(app + 1, parn);

@@ -359,7 +359,7 @@ class MultiView_MPL(nn.Module):
         # 2x faster than on the fp32 matrix instructions -- worth it for "fp32"; the 6 B / element operands of the older
         # engines are not rebuilt per forward (replicas of those precisions run the native fp32 MFMA kernels)
         h2 = self.matmul_precision == "fp32" and self._x3_supported()
-        # the SPT Linear layers also run from split operands (fp32 arithmetic on the bf16 matrix cores) unless the native
+        # the SPT Linear layers also run from split operands (fp32 arithmetic on the fp16 matrix cores) unless the native
         # fp32 matrix instructions were asked for (or this is a replica of one of the older engines)
         spt3 = self.matmul_precision != "fp32_mfma" and not (self._dp_replica and self.matmul_precision != "fp32") \
             and not self.no_transformer_spt
@@ -367,7 +367,8 @@ class MultiView_MPL(nn.Module):
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
         if spt3:
             stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
-            key = key + ("spt3",) + tuple(t._version for st in stacks for b in st for t in self._block_ptrs(b)[2:12:2])
+            # every tensor of a block: the packed SPT operand folds norm1 / norm2 into the weights and the biases into c
+            key = key + ("spt3",) + tuple(t._version for st in stacks for b in st for t in self._block_ptrs(b))
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent

@@ -552,6 +552,8 @@ def test_split_operands_follow_in_place_weight_updates():
         m.blocks[1].norm2.weight.mul_(0.9)                       # folded into the fc1 operand
         m.Spatial_blocks[0].mlp.fc1.weight.mul_(1.1)             # SPT operands (mpl_spt_pack) are derived data too
         m.Spatial_blocks[1].attn.proj.weight.add_(0.02)
+        m.Spatial_blocks[0].norm1.bias.add_(0.05)                # folded into c of the packed qkv operand
+        m.Spatial_blocks[1].mlp.fc1.bias.mul_(1.2)
         upd = m(P, rays=R, centers=Cn)
     assert not torch.allclose(base, upd)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
