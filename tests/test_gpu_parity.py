@@ -352,6 +352,29 @@ def test_bf16_matmul_path(name, B):
     _assert_close(out32, ref, name + " back to fp32")
 
 
+@pytest.mark.parametrize("scales", [dict(qkv=64.0, proj=1 / 64.0, fc1=1e-3, fc2=1e3, g1=30.0, g2=0.02),
+                                    dict(qkv=1e-4, proj=1e4, fc1=300.0, fc2=1 / 300.0, g1=0.01, g2=50.0)])
+def test_spt_split_operands_follow_the_weight_magnitudes(scales):
+    """The packed SPT operand (mpl_spt_pack) carries one power-of-two scale per output column and static scales for the
+    attention / GELU outputs from data-free bounds: weights and LayerNorm gains far from the usual magnitudes (the products
+    qkv x proj and fc1 x fc2 kept near one so that the residual stream stays finite) must give the same parity."""
+    m, g = _model("chosen_v4_b8_l2")
+    P, R, Cn = golden_inputs(g, DEV)
+    with torch.no_grad():
+        for blk in m.Spatial_blocks:
+            blk.attn.qkv.weight.mul_(scales["qkv"]); blk.attn.qkv.bias.mul_(scales["qkv"])
+            blk.attn.proj.weight.mul_(scales["proj"])
+            blk.mlp.fc1.weight.mul_(scales["fc1"]); blk.mlp.fc1.bias.mul_(scales["fc1"])
+            blk.mlp.fc2.weight.mul_(scales["fc2"])
+            blk.norm1.weight.mul_(scales["g1"]); blk.norm1.bias.mul_(scales["g1"])
+            blk.norm2.weight.mul_(scales["g2"]); blk.norm2.bias.mul_(scales["g2"])
+        out = m(P, rays=R, centers=Cn)
+    assert torch.isfinite(out).all()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cp, cr, cc = golden_inputs(g, "cpu")
+    _assert_close(out, mpl_oracle.forward(sd, g["flags"], cp, cr, cc, dtype=torch.float64), "SPT weights at unusual magnitudes")
+
+
 # ----------------------------------------------------------------------------- fp32 on the bf16 matrix cores (split operands)
 def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
     a = A.double()
