@@ -530,6 +530,7 @@ constexpr float SPT_SA = 1024.0f;                   // scale of a normalised Lay
 constexpr float SPT_QS = 0.5f * 1.4426950408889634f;   // hd^-0.5 log2 e, folded into the q columns (scores in the exp2 domain)
 
 typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept): h2_gemm.hip
 __device__ __forceinline__ void spt_split2(const float (&x)[8], sf16x8& hi, sf16x8& lo) {
@@ -780,8 +781,20 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     q[t] = float4{fmaf(cq[0], sq[0].x, bq[0].x), fmaf(cq[1], sq[0].y, bq[0].y), fmaf(cq[2], sq[0].z, bq[0].z),
                                   fmaf(cq[3], sq[0].w, bq[0].w)};
                     const int h = 4 * hg + kq;
-                    st4(Kb + ((j * SH + h) * SEQ + li) * 4, float4{fmaf(ck[0], sq[1].x, bq[1].x), fmaf(ck[1], sq[1].y, bq[1].y),
-                                                                    fmaf(ck[2], sq[1].z, bq[1].z), fmaf(ck[3], sq[1].w, bq[1].w)});
+                    // K tile: keys in PAIRS, components interleaved -- [pair][plane][h][seq]{c_j, c_j+1, c'_j, c'_j+1} with plane 0
+                    // = (x, y), plane 1 = (z, w) -- so that two scores come out of one packed multiply-add; the 17th key stays
+                    // a plain [h][seq]{x, y, z, w} record behind the 8 pairs
+                    const float kx = fmaf(ck[0], sq[1].x, bq[1].x), ky = fmaf(ck[1], sq[1].y, bq[1].y);
+                    const float kz = fmaf(ck[2], sq[1].z, bq[1].z), kw = fmaf(ck[3], sq[1].w, bq[1].w);
+                    if (j < SJ - 1) {
+                        float* kp = Kb + ((((j >> 1) * 2) * SH + h) * SEQ + li) * 4 + (j & 1);
+                        kp[0] = kx;
+                        kp[2] = ky;
+                        kp[SH * SEQ * 4] = kz;
+                        kp[SH * SEQ * 4 + 2] = kw;
+                    } else {
+                        st4(Kb + (SJ - 1) * SH * SEQ * 4 + (h * SEQ + li) * 4, float4{kx, ky, kz, kw});
+                    }
                     st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{fmaf(cv[0], sq[2].x, bq[2].x), fmaf(cv[1], sq[2].y, bq[2].y),
                                                                     fmaf(cv[2], sq[2].z, bq[2].z), fmaf(cv[3], sq[2].w, bq[2].w)});
                 }
@@ -795,11 +808,26 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 const int h = 4 * hg + kq;
                 float sc[5][SJ];
 #pragma unroll
-                for (int j = 0; j < SJ; ++j) {
-                    const float4 k = ::mpl::ld4(Kb + ((j * SH + h) * SEQ + li) * 4);
+                for (int jp = 0; jp < SJ / 2; ++jp) {
+                    const float4 k01 = ::mpl::ld4(Kb + (((jp * 2) * SH + h) * SEQ + li) * 4);        // x_j x_j+1 y_j y_j+1
+                    const float4 k23 = ::mpl::ld4(Kb + (((jp * 2 + 1) * SH + h) * SEQ + li) * 4);    // z_j z_j+1 w_j w_j+1
+                    const f32x2 kx = {k01.x, k01.y}, ky = {k01.z, k01.w}, kz = {k23.x, k23.y}, kw = {k23.z, k23.w};
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) {
+                        const f32x2 qx = {q[t].x, q[t].x}, qy = {q[t].y, q[t].y}, qz = {q[t].z, q[t].z}, qw = {q[t].w, q[t].w};
+                        f32x2 s2 = qx * kx;
+                        s2 = __builtin_elementwise_fma(qy, ky, s2);
+                        s2 = __builtin_elementwise_fma(qz, kz, s2);
+                        s2 = __builtin_elementwise_fma(qw, kw, s2);
+                        sc[t][2 * jp] = s2[0];
+                        sc[t][2 * jp + 1] = s2[1];
+                    }
+                }
+                {
+                    const float4 k = ::mpl::ld4(Kb + (SJ - 1) * SH * SEQ * 4 + (h * SEQ + li) * 4);
 #pragma unroll
                     for (int t = 0; t < 5; ++t)
-                        sc[t][j] = fmaf(q[t].w, k.w, fmaf(q[t].z, k.z, fmaf(q[t].y, k.y, q[t].x * k.x)));
+                        sc[t][SJ - 1] = fmaf(q[t].w, k.w, fmaf(q[t].z, k.z, fmaf(q[t].y, k.y, q[t].x * k.x)));
                 }
                 const float s_att = par[2 * SPT_NCOL];
                 float inv[5];
