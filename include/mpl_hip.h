@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 8
+#define MPL_HIP_ABI_VERSION 9
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -201,6 +201,11 @@ int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const 
  * repack when any tensor of the block changes. */
 size_t mpl_spt_pack_bytes(void);
 int mpl_spt_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
+/* The same operand for a D = 32 FPT block (keypoint-token variant, multiview_mpl.py:261-266): identical layout, the q columns
+ * NOT pre-scaled (the token attention kernel scales q itself).  A block whose qkv_w3 field carries it (proj_w3 / fc1_w3 /
+ * fc2_w3 NULL) runs in mpl_block_stack as d32_qkv_kernel -> token attention -> d32_mlp_kernel: two row-local launches per
+ * block application instead of four GEMMs and two LayerNorm-statistics passes. */
+int mpl_d32_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
 
 /* The same for the bf16 engine: ONE bf16 per weight (round to nearest even of gamma o W), K padded with zero k-tiles to a
  * multiple of 96, the same fold vectors (s summed over the ROUNDED weights).  mpl_ln_linear_bf16: operands rounded to bf16

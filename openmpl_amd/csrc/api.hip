@@ -306,6 +306,22 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     // qkv projection and attention run as one kernel when a 64-row tile holds whole sequences and a 136-column
     // slice whole heads (V in {1,2,4,8,16,32,64}; hd in {68,136}); otherwise as two kernels through `qkv`
     const bool fusable = qkv_attention_fusable(n_tok, D, H);
+    // D = 32 blocks (keypoint-token FPT) that carry the operand of mpl_d32_pack in qkv_w3: everything but the attention is
+    // row-local and runs as two launches from split fp16 operands (spt.hip: d32_qkv_kernel, d32_mlp_kernel)
+    bool d32 = D == 32;
+    for (int a = 0; a < n_apps && d32; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        d32 = b.qkv_w3 && !b.proj_w3 && !b.fc1_w3 && !b.fc2_w3 && !b.qkv_w16 && !b.qkv_h2;
+    }
+    if (d32) {
+        for (int a = 0; a < n_apps; ++a) {
+            const mpl_block_weights& b = blocks[schedule[a]];
+            if ((rc = launch_d32_qkv(x, M, b.qkv_w3, w.qkv, s))) return rc;
+            if ((rc = launch_token_attention(w.qkv, n_seq, n_tok, D, H, w.att, s))) return rc;
+            if ((rc = launch_d32_mlp(x, w.att, M, b.qkv_w3, s))) return rc;
+        }
+        return MPL_OK;
+    }
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
             // packed operands (split fp32 / bf16) take the block_stack_x3 route above; here they cannot be used
@@ -475,7 +491,12 @@ size_t mpl_spt_pack_bytes(void) { return spt_pack_bytes(); }
 
 int mpl_spt_pack(const mpl_block_weights* block, uint16_t* dst, void* stream) {
     clear_stale_hip_error();
-    return launch_spt_pack(block, dst, (hipStream_t)stream);
+    return launch_spt_pack(block, dst, 1, (hipStream_t)stream);
+}
+
+int mpl_d32_pack(const mpl_block_weights* block, uint16_t* dst, void* stream) {
+    clear_stale_hip_error();
+    return launch_spt_pack(block, dst, 0, (hipStream_t)stream);
 }
 
 size_t mpl_pack_bf16_bytes(int N, int K) { return x3_operand_bytes(N, K, 1); }

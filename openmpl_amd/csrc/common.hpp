@@ -181,7 +181,9 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
 // matrix cores); else the fp32-MFMA kernel reads the nn.Linear weights in place
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, int use_packed, hipStream_t s);
 size_t spt_pack_bytes();
-int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s);
+int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, int fold_q, hipStream_t s);
+int launch_d32_qkv(const float* x, int M, const unsigned short* pack, float* qkv, hipStream_t s);
+int launch_d32_mlp(float* x, const float* att, int M, const unsigned short* pack, hipStream_t s);
 // y_out != nullptr: stop after the Conv1d weighted mean and write the (B, J*d) feature instead of running head[0..1]
 // err_ws (optional): the error word of this call's block stack (see device_error_word); set -> the output is NaN
 int launch_fuse_head(const mpl_config* cfg, const mpl_weights* w, const float* x, int batch, float* out, float* y_out,

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__
                                                         const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
                                                         const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
                                                         const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
-                                                        char* __restrict__ dst) {
+                                                        char* __restrict__ dst, int fold_q) {
     __shared__ float Wf[8192];                  // qkv' [96][32] | proj [32][32] | fc1' [64][32] | fc2 [32][64]
     __shared__ float cn[SPT_NCOL], sw[SPT_NCOL], bnd[SPT_NCOL], scal[2];
     const int tid = threadIdx.x;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__
         else if (n < 128) sc = 1.0f / (scal[0] * sw[n]);
         else if (n < 192) sc = 1.0f / (SPT_SA * sw[n]);
         else sc = 1.0f / (scal[1] * sw[n]);
-        if (n < 32) { c *= SPT_QS; sc *= SPT_QS; }
+        if (n < 32 && fold_q) { c *= SPT_QS; sc *= SPT_QS; }
         vec[n] = c;
         vec[SPT_NCOL + n] = sc;
     }
@@ -647,13 +647,15 @@ __global__ __launch_bounds__(256) void spt_pack_kernel(const float* __restrict__
     }
 }
 
-int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, hipStream_t s) {
+// fold_q: the q columns carry hd^-0.5 log2 e (the SPT kernel's exp2-domain attention); 0 for the D = 32 FPT blocks, whose
+// attention kernel scales q itself
+int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, int fold_q, hipStream_t s) {
     const mpl_block_weights* b = bw_host;
     if (!b || !dst || !b->qkv_w || !b->proj_w || !b->fc1_w || !b->fc2_w || !b->qkv_b || !b->proj_b || !b->fc1_b || !b->fc2_b ||
         !b->ln1_w || !b->ln1_b || !b->ln2_w || !b->ln2_b)
         return MPL_E_INVALID;
     hipLaunchKernelGGL(spt_pack_kernel, dim3(1), dim3(256), 0, s, b->qkv_w, b->qkv_b, b->ln1_w, b->ln1_b, b->proj_w, b->proj_b, b->fc1_w,
-                       b->fc1_b, b->ln2_w, b->ln2_b, b->fc2_w, b->fc2_b, reinterpret_cast<char*>(dst));
+                       b->fc1_b, b->ln2_w, b->ln2_b, b->fc2_w, b->fc2_b, reinterpret_cast<char*>(dst), fold_q);
     return hip_check_launch();
 }
 
@@ -973,6 +975,171 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         phase_sync();
     }
     spt_epilogue<true>(p, X, tid, view, b0, pose, ray, cen);
+}
+
+// ---------------------------------------------------------------------------------------------- D = 32 FPT blocks
+// The FPT blocks of the keypoint-token variant (FPT_blocks_view_keypoint_tokens: 17 V tokens of width 32, :261-266, :436-437)
+// have the SPT block's Linear shapes, so they run from the same packed operand (mpl_spt_pack format, q columns unscaled) with
+// the same arithmetic.  Everything except the attention is ROW-LOCAL at this width: a wave takes a 16-row tile through a
+// whole chain of GEMMs by itself -- weights in registers for all its tiles, the accumulator layout (lane = row i, 4 columns)
+// turned into the next A fragment (lane = row i, 8 consecutive k) through a 16-row scratch tile of its own in LDS, no
+// workgroup barrier anywhere:
+//   d32_qkv_kernel:  qkv = LN1(x) . Wqkv^T + b                                         (-> token attention kernel)
+//   d32_mlp_kernel:  x += att . Wproj^T + b;  x += fc2(gelu(fc1(LN2(x))))              (Block.forward :84-92, Mlp :31-37)
+// Two launches per block application besides the attention instead of four GEMMs and two statistics passes.
+__device__ __forceinline__ void d32_ln_split(const float4& a0, const float4& a1, sf16x8& ah, sf16x8& al) {
+    float4 x0 = a0, x1 = a1;
+    float sm = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
+    sm = xor32_add(xor16_add(sm));
+    const float mean = sm * (1.0f / 32.0f);
+    x0.x -= mean; x0.y -= mean; x0.z -= mean; x0.w -= mean;
+    x1.x -= mean; x1.y -= mean; x1.z -= mean; x1.w -= mean;
+    float ss = ((x0.x * x0.x + x0.y * x0.y) + (x0.z * x0.z + x0.w * x0.w)) + ((x1.x * x1.x + x1.y * x1.y) + (x1.z * x1.z + x1.w * x1.w));
+    ss = xor32_add(xor16_add(ss));
+    const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / 32.0f) + 1e-6f) * SPT_SA;
+    const float y[8] = {x0.x * rs, x0.y * rs, x0.z * rs, x0.w * rs, x1.x * rs, x1.y * rs, x1.z * rs, x1.w * rs};
+    spt_split2(y, ah, al);
+}
+__device__ __forceinline__ void d32_load_w(const char* pack, int unit, int lane, sf16x8 (&w)[2]) {
+    const sf16x8* g = reinterpret_cast<const sf16x8*>(pack) + (size_t)unit * 2 * 64 + lane;
+    w[0] = g[0];
+    w[1] = g[64];
+}
+
+__global__ __launch_bounds__(512) void d32_qkv_kernel(const float* __restrict__ x, int M, const char* __restrict__ pack,
+                                                       float* __restrict__ qkv) {
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int gw = blockIdx.x * 8 + (threadIdx.x >> 6), nw = gridDim.x * 8;
+    const float* vec = reinterpret_cast<const float*>(pack + SPT_PACK_VEC);
+    sf16x8 wq[6][2];
+    float4 cq[6], sq[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        d32_load_w(pack, n, lane, wq[n]);
+        cq[n] = ld4(vec + SPT_C_QKV + 16 * n + 4 * kq);
+        sq[n] = ld4(vec + SPT_NCOL + SPT_C_QKV + 16 * n + 4 * kq);
+    }
+    const int n_tiles = (M + 15) / 16;
+    for (int tile = gw; tile < n_tiles; tile += nw) {
+        const int row = tile * 16 + li;
+        const bool ok = row < M;
+        const float* xr = x + (size_t)(ok ? row : M - 1) * SD + 8 * kq;
+        sf16x8 ah, al;
+        d32_ln_split(ld4(xr), ld4(xr + 4), ah, al);
+        float* o = qkv + (size_t)row * (3 * SD) + 4 * kq;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const f32x4 c = mfma3(wq[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (ok) st4(o + 16 * n, float4{fmaf(c[0], sq[n].x, cq[n].x), fmaf(c[1], sq[n].y, cq[n].y), fmaf(c[2], sq[n].z, cq[n].z),
+                                           fmaf(c[3], sq[n].w, cq[n].w)});
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void d32_mlp_kernel(float* __restrict__ x, const float* __restrict__ att, int M,
+                                                       const char* __restrict__ pack) {
+    __shared__ __attribute__((aligned(16))) float scratch[8][16 * XS + 16 * HS];
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+    float* XT = scratch[wave];              // [16][36]: x after the attention half, in A-fragment order for norm2
+    float* HT = XT + 16 * XS;               // [16][68]: the hidden layer (already times the static scale of the fc2 operand)
+    const float* vec = reinterpret_cast<const float*>(pack + SPT_PACK_VEC);
+    sf16x8 wp[2][2], w1[4][2], w2[2][2][2];
+    float4 bp[2], sp[2], b1[4], s1[4], b2[2], s2[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        d32_load_w(pack, 6 + n, lane, wp[n]);
+        d32_load_w(pack, 12 + 2 * n, lane, w2[n][0]);
+        d32_load_w(pack, 12 + 2 * n + 1, lane, w2[n][1]);
+        bp[n] = ld4(vec + SPT_C_PROJ + 16 * n + 4 * kq);
+        sp[n] = ld4(vec + SPT_NCOL + SPT_C_PROJ + 16 * n + 4 * kq);
+        b2[n] = ld4(vec + SPT_C_FC2 + 16 * n + 4 * kq);
+        s2[n] = ld4(vec + SPT_NCOL + SPT_C_FC2 + 16 * n + 4 * kq);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        d32_load_w(pack, 8 + n, lane, w1[n]);
+        b1[n] = ld4(vec + SPT_C_FC1 + 16 * n + 4 * kq);
+        s1[n] = ld4(vec + SPT_NCOL + SPT_C_FC1 + 16 * n + 4 * kq);
+    }
+    const float s_att = vec[2 * SPT_NCOL], hs = vec[2 * SPT_NCOL + 1];
+    const int n_tiles = (M + 15) / 16;
+    for (int tile = gw; tile < n_tiles; tile += nw) {
+        const int row = tile * 16 + li;
+        const bool ok = row < M;
+        const size_t rc = (size_t)(ok ? row : M - 1);
+        // ---- x += att . Wproj^T + b
+        float4 xn[2];
+        {
+            const float* ar = att + rc * SD + 8 * kq;
+            const float4 a0 = ld4(ar), a1 = ld4(ar + 4);
+            const float y[8] = {a0.x * s_att, a0.y * s_att, a0.z * s_att, a0.w * s_att, a1.x * s_att, a1.y * s_att, a1.z * s_att, a1.w * s_att};
+            sf16x8 ah, al;
+            spt_split2(y, ah, al);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 c = mfma3(wp[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                const float4 xo = ld4(x + rc * SD + 16 * n + 4 * kq);
+                xn[n] = float4{xo.x + fmaf(c[0], sp[n].x, bp[n].x), xo.y + fmaf(c[1], sp[n].y, bp[n].y), xo.z + fmaf(c[2], sp[n].z, bp[n].z),
+                               xo.w + fmaf(c[3], sp[n].w, bp[n].w)};
+                st4(XT + li * XS + 16 * n + 4 * kq, xn[n]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS stores, read back in another lane order
+        // ---- hidden = gelu(LN2(x) . W1^T + b)
+        {
+            sf16x8 ah, al;
+            d32_ln_split(ld4(XT + li * XS + 8 * kq), ld4(XT + li * XS + 8 * kq + 4), ah, al);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 c = mfma3(w1[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
+                st4(HT + li * HS + 16 * n + 4 * kq,
+                    float4{gelu_as_scaled(fmaf(c[0], s1[n].x, b1[n].x), hs), gelu_as_scaled(fmaf(c[1], s1[n].y, b1[n].y), hs),
+                           gelu_as_scaled(fmaf(c[2], s1[n].z, b1[n].z), hs), gelu_as_scaled(fmaf(c[3], s1[n].w, b1[n].w), hs)});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- x += hidden . W2^T + b   (K = 64: two k steps)
+        {
+            sf16x8 ah0, al0, ah1, al1;
+            {
+                const float4 h0 = ld4(HT + li * HS + 8 * kq), h1 = ld4(HT + li * HS + 8 * kq + 4);
+                const float y[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                spt_split2(y, ah0, al0);
+            }
+            {
+                const float4 h0 = ld4(HT + li * HS + 32 + 8 * kq), h1 = ld4(HT + li * HS + 32 + 8 * kq + 4);
+                const float y[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                spt_split2(y, ah1, al1);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 c = mfma3(w2[n][0], ah0, al0, f32x4{0.f, 0.f, 0.f, 0.f});
+                c = mfma3(w2[n][1], ah1, al1, c);
+                if (ok) st4(x + (size_t)row * SD + 16 * n + 4 * kq,
+                            float4{xn[n].x + fmaf(c[0], s2[n].x, b2[n].x), xn[n].y + fmaf(c[1], s2[n].y, b2[n].y),
+                                   xn[n].z + fmaf(c[2], s2[n].z, b2[n].z), xn[n].w + fmaf(c[3], s2[n].w, b2[n].w)});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the scratch tiles are rewritten by the next tile
+    }
+}
+
+static int d32_grid(int M) {
+    const int need = ((M + 15) / 16 + 7) / 8;
+    return need < 512 ? (need > 0 ? need : 1) : 512;
+}
+int launch_d32_qkv(const float* x, int M, const unsigned short* pack, float* qkv, hipStream_t s) {
+    if (!x || !pack || !qkv || M <= 0) return MPL_E_INVALID;
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL(d32_qkv_kernel, dim3(d32_grid(M)), dim3(512), 0, s, x, M, reinterpret_cast<const char*>(pack), qkv);
+    return hip_check_launch();
+}
+int launch_d32_mlp(float* x, const float* att, int M, const unsigned short* pack, hipStream_t s) {
+    if (!x || !pack || !att || M <= 0) return MPL_E_INVALID;
+    ProfScope prof(MPL_K_GEMM, s);
+    hipLaunchKernelGGL(d32_mlp_kernel, dim3(d32_grid(M)), dim3(512), 0, s, x, att, M, reinterpret_cast<const char*>(pack));
+    return hip_check_launch();
 }
 
 int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in, float* xs, int use_packed, hipStream_t s) {

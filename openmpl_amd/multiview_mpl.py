@@ -365,6 +365,11 @@ class MultiView_MPL(nn.Module):
             and not self.no_transformer_spt
         if bf16 or x3 or h2:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
             key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
+        # keypoint-token FPT blocks (width 32 = the SPT block's shapes) run from the same kind of split operand (mpl_d32_pack)
+        d32 = self.matmul_precision == "fp32" and not self._dp_replica and self.FPT_blocks_view_keypoint_tokens \
+            and not self.no_transformer_fpt and len(self.blocks) > 0 and tuple(self.blocks[0].attn.qkv.weight.shape) == (96, 32)
+        if d32:
+            key = key + ("d32",) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
         if spt3:
             stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
             # every tensor of a block: the packed SPT operand folds norm1 / norm2 into the weights and the biases into c
@@ -429,6 +434,13 @@ class MultiView_MPL(nn.Module):
                     w16_keep.append(c3)
                     ptrs.append(c3.data_ptr())
             fpt[l] = cabi.BlockWeights(*ptrs)
+            if d32:
+                lib = cabi.load()
+                pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
+                cabi.check(lib.mpl_d32_pack(C.byref(fpt[l]), pk.data_ptr(), torch.cuda.current_stream(device).cuda_stream),
+                           "mpl_d32_pack")
+                w16_keep.append(pk)
+                fpt[l].qkv_w3 = pk.data_ptr()
         w = cabi.Weights()
         w.spt_sets = base
         w.spt_packed = 1 if (spt3 and L > 0) else 0

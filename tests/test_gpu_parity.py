@@ -514,7 +514,8 @@ def test_native_fp32_mfma_path_matches_golden(name):
     with torch.no_grad():
         out3 = m(P, rays=R, centers=Cn)
     _assert_close(out3, torch.from_numpy(g["out"]), name + " fp32 (split operands where supported)")
-    assert bool(m._hip_cache[0]["keep"][4]) == m._x3_supported()
+    # packed FPT operands: the 544 / 1088-wide engines, or the D = 32 row-local kernels of the keypoint-token variant
+    assert bool(m._hip_cache[0]["keep"][4]) == (m._x3_supported() or bool(m.FPT_blocks_view_keypoint_tokens))
 
 
 def test_fp32_paths_agree_and_are_both_batch_invariant():
