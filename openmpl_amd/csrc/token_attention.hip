@@ -296,6 +296,139 @@ __global__ __launch_bounds__(256) void token_attention_long_kernel(const float* 
     }
 }
 
+// ---- head dim 4, keys in PAIRS: the kernel above spends 12 VALU instructions per score (4 for q.k, subtract, exp, max,
+// sum, 4 for p.v) at one instruction per 4 cycles and wave -- it is VALU-issue bound.  Here two keys share every multiply-add:
+// K and V live in LDS as [pair]{x_j, x_j+1, y_j, y_j+1, z_j, z_j+1, w_j, w_j+1}, the scores, the exponent arguments, the row
+// sum and the output accumulate as 2-vectors (packed fp32 instructions); the two halves of the output / row sum (even and odd
+// keys) are added once at the end.
+typedef float taf2 __attribute__((ext_vector_type(2)));
+template <int NR, bool FULL>
+__device__ __forceinline__ void attend_chunk_p4(const float4 (&q)[NR], taf2 (&o)[NR][4], float (&m)[NR], taf2 (&l)[NR],
+                                                const float* Kp, const float* Vp, int n_tok, int j0) {
+    constexpr int CP = 8;                       // pairs per chunk (16 keys)
+    taf2 sc[NR][CP];
+#pragma unroll
+    for (int pp = 0; pp < CP; ++pp) {
+        const int jp = (FULL || j0 + 2 * pp < n_tok) ? (j0 >> 1) + pp : (n_tok - 1) >> 1;
+        const float4 k01 = ld4(Kp + jp * 8), k23 = ld4(Kp + jp * 8 + 4);
+        const taf2 kx = {k01.x, k01.y}, ky = {k01.z, k01.w}, kz = {k23.x, k23.y}, kw = {k23.z, k23.w};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const taf2 qx = {q[r].x, q[r].x}, qy = {q[r].y, q[r].y}, qz = {q[r].z, q[r].z}, qw = {q[r].w, q[r].w};
+            taf2 s2 = qx * kx;
+            s2 = __builtin_elementwise_fma(qy, ky, s2);
+            s2 = __builtin_elementwise_fma(qz, kz, s2);
+            s2 = __builtin_elementwise_fma(qw, kw, s2);
+            if (!FULL) {
+                if (j0 + 2 * pp >= n_tok) s2[0] = -INFINITY;
+                if (j0 + 2 * pp + 1 >= n_tok) s2[1] = -INFINITY;
+            }
+            sc[r][pp] = s2;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float mc = fmaxf(sc[r][0][0], sc[r][0][1]);
+#pragma unroll
+        for (int pp = 1; pp < CP; ++pp) mc = fmaxf(mc, fmaxf(sc[r][pp][0], sc[r][pp][1]));
+        const float mn = fmaxf(m[r], mc);
+        const float f = __builtin_amdgcn_exp2f(m[r] - mn);
+        const taf2 f2 = {f, f};
+        l[r] *= f2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[r][c] *= f2;
+        m[r] = mn;
+        const taf2 mn2 = {mn, mn};
+#pragma unroll
+        for (int pp = 0; pp < CP; ++pp) {
+            const taf2 d = sc[r][pp] - mn2;
+            sc[r][pp] = taf2{__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < CP; ++pp) {
+        const int jp = (FULL || j0 + 2 * pp < n_tok) ? (j0 >> 1) + pp : (n_tok - 1) >> 1;
+        const float4 v01 = ld4(Vp + jp * 8), v23 = ld4(Vp + jp * 8 + 4);
+        const taf2 vx = {v01.x, v01.y}, vy = {v01.z, v01.w}, vz = {v23.x, v23.y}, vw = {v23.z, v23.w};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const taf2 e = sc[r][pp];
+            l[r] += e;
+            o[r][0] = __builtin_elementwise_fma(e, vx, o[r][0]);
+            o[r][1] = __builtin_elementwise_fma(e, vy, o[r][1]);
+            o[r][2] = __builtin_elementwise_fma(e, vz, o[r][2]);
+            o[r][3] = __builtin_elementwise_fma(e, vw, o[r][3]);
+        }
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void attend_rows_p4(const float* __restrict__ base, size_t ld, const float* Kp, const float* Vp,
+                                               int n_tok, int i0, int stride, float scale, float* __restrict__ out_row0,
+                                               size_t out_ld) {
+    constexpr int CH = 16;
+    float4 q[NR];
+    taf2 o[NR][4], l[NR];
+    float m[NR];
+    const float qs = scale * 1.4426950408889634f;        // scores in the exp2 domain
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = i0 + stride * r;
+        const int ic = i < n_tok ? i : n_tok - 1;
+        q[r] = ld4(base + ic * ld);
+        q[r].x *= qs; q[r].y *= qs; q[r].z *= qs; q[r].w *= qs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[r][c] = taf2{0.f, 0.f};
+        m[r] = -INFINITY;
+        l[r] = taf2{0.f, 0.f};
+    }
+    int j0 = 0;
+    for (; j0 + CH <= n_tok; j0 += CH) attend_chunk_p4<NR, true>(q, o, m, l, Kp, Vp, n_tok, j0);
+    if (j0 < n_tok) attend_chunk_p4<NR, false>(q, o, m, l, Kp, Vp, n_tok, j0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = i0 + stride * r;
+        if (i >= n_tok) continue;
+        const float inv = 1.0f / (l[r][0] + l[r][1]);
+        st4(out_row0 + (size_t)i * out_ld, float4{(o[r][0][0] + o[r][0][1]) * inv, (o[r][1][0] + o[r][1][1]) * inv,
+                                                  (o[r][2][0] + o[r][2][1]) * inv, (o[r][3][0] + o[r][3][1]) * inv});
+    }
+}
+
+__global__ __launch_bounds__(256) void token_attention_long_p4_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                       int n_tok, int D, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int R = 3;
+    const int nthr = blockDim.x;
+    const int sq = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)sq * n_tok * ld + (size_t)h * 4;
+    const int n_pair = (n_tok + 1) >> 1;
+    float* Kp = sm;
+    float* Vp = sm + (size_t)n_pair * 8;
+    for (int j = threadIdx.x; j < 2 * n_pair; j += nthr) {
+        float4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};      // the missing partner of an odd last key
+        if (j < n_tok) {
+            k = ld4(base + j * ld + D);
+            v = ld4(base + j * ld + 2 * D);
+        }
+        float* kp = Kp + (j >> 1) * 8 + (j & 1);
+        float* vp = Vp + (j >> 1) * 8 + (j & 1);
+        kp[0] = k.x; kp[2] = k.y; kp[4] = k.z; kp[6] = k.w;
+        vp[0] = v.x; vp[2] = v.y; vp[4] = v.z; vp[6] = v.w;
+    }
+    __syncthreads();
+    float* orow = out + (size_t)sq * n_tok * D + (size_t)h * 4;
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));     // first query row of this wave
+    for (int w0 = wbase; w0 < n_tok; w0 += nthr * R) {
+        const int ns = (n_tok - w0 + nthr - 1) / nthr;
+        const int i0 = w0 + (int)(threadIdx.x & 63u);
+        if (ns >= 3) attend_rows_p4<3>(base, ld, Kp, Vp, n_tok, i0, nthr, scale, orow, (size_t)D);
+        else if (ns == 2) attend_rows_p4<2>(base, ld, Kp, Vp, n_tok, i0, nthr, scale, orow, (size_t)D);
+        else attend_rows_p4<1>(base, ld, Kp, Vp, n_tok, i0, nthr, scale, orow, (size_t)D);
+    }
+}
+
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s) {
     if (n_seq <= 0 || n_tok <= 0 || heads <= 0 || dim % heads) return MPL_E_INVALID;
     const int hd = dim / heads;
@@ -307,7 +440,11 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
         const size_t lds = (size_t)n_tok * hd * 8;
         int waves = (n_tok + 191) / 192;             // three row slots per wave
         waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
-        if (hd == 4)
+        static const bool no_pairs = getenv("MPL_ATT_NOPAIRS") != nullptr;      // bench-only A/B switch
+        if (hd == 4 && !no_pairs)
+            hipLaunchKernelGGL(token_attention_long_p4_kernel, dim3(n_seq * heads), dim3(64 * waves), (size_t)((n_tok + 1) / 2) * 64, s,
+                               qkv, out, n_tok, dim, heads, sc);
+        else if (hd == 4)
             hipLaunchKernelGGL((token_attention_long_kernel<1>), dim3(n_seq * heads), dim3(64 * waves), lds, s, qkv, out, n_tok,
                                dim, heads, sc);
         else
