@@ -70,7 +70,7 @@ constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of
 constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
 constexpr int H2_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the generic attention epilogue
-constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (K <= 2048)
+constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (|z| <= sqrt(K): fine up to K = 2048)
 #ifndef H2_DBG
 #define H2_DBG 0
 #endif
@@ -486,7 +486,7 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
 // CHAIN = false: the GEMM is a launch of its own.  CHAIN = true: one phase of h2_stack_kernel (see there): `chain` counts
 // the arrivals of the team, the A operand (and the LayerNorm partials) may be read once it reaches `chain_need`, and this
 // workgroup arrives when its outputs are written.  Returns false when the wait timed out (error words set, nothing computed).
-// WC = W pieces this wave requests per stage (1 for the waves 0..3, 4 for the waves 4, 5, 3 for the waves 6, 7): a template
+// WC = W pieces this wave requests per stage (2 for the waves 0..3, 3 for the waves 4, 5, 2 for the waves 6, 7): a template
 // parameter, so that neither the requests nor the counted waits need a branch in the k loop.
 template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
@@ -517,9 +517,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const bool row_ok = row_l < a.rpt && m0 + row_l < M;
     const int row = row_ok ? m0 + row_l : (M - 1);
 
-    // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..3 / 4..7, waves 6, 7 pieces 8..10 / 11..13, wave
-    // w < 4 piece 14 + w.  A (8 per A stage): waves 0..3 the two pieces of row group `wave`.  (Moving the W pieces of the waves
-    // 0..3 to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm operand in place, -3 %; it costs 1-3 % now.)
+    // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..2 / 3..5, waves 6, 7 pieces 6, 7 / 8, 9, wave
+    // w < 4 pieces 10 + 2 w, 11 + 2 w (H2_WSPLIT 0: 4 / 4 / 3 / 3 and one each).  A (8 per A stage): waves 0..3 the two pieces
+    // of row group `wave`.  (Moving ALL W pieces to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm
+    // operand in place, -3 %; it costs 1-5 % now.)
 #if H2_WSPLIT == 1
     const int w_first = HAS_A ? 10 + 2 * wave : (wave < 6 ? 3 * (wave - 4) : 6 + 2 * (wave - 6));
     static_assert(HAS_A ? WC == 2 : (WC == 3 || WC == 2), "W pieces per wave");
