@@ -774,7 +774,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 q[t] = float4{0.f, 0.f, 0.f, 0.f};
-                if (t < nj) {
+                if (t < nj && !(p.abl & 8)) {
                     const int j = part + 4 * t;
                     sf16x8 ah, al;
                     ln_frag(j, ah, al);
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
             // Scores in the exp2 domain (the q columns carry hd^-0.5 log2 e = 0.5 log2 e from their epilogue multiplier), the
             // probabilities stay unnormalised until the output row is complete; the output leaves with the static scale of the
             // proj operand (par[448], a power of two).
-            {
+            if (!(p.abl & 1)) {
                 const int h = 4 * hg + kq;
                 float sc[5][SJ];
 #pragma unroll
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 sp[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_PROJ + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 32); ++m) {
                 sf16x8 ah, al;
                 raw_frag(ATT + (m * 16 + li) * ATS + 8 * kq, ah, al);
 #pragma unroll
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
             }
             const float hs = par[2 * SPT_NCOL + 1];     // half the static scale of the fc2 operand (a power of two)
             const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
-            for (int m = lo >> 2; m <= ((hi - 1) >> 2); ++m) {
+            for (int m = lo >> 2; m <= ((hi - 1) >> 2) && !(p.abl & 64); ++m) {
                 sf16x8 ah, al;
                 ln_frag(m, ah, al);
 #pragma unroll
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 s2[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_FC2 + 16 * n + 4 * kq);
             }
             const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
-            for (int m = lo >> 1; m <= ((hi - 1) >> 1); ++m) {
+            for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 128); ++m) {
                 sf16x8 ah0, al0, ah1, al1;
                 raw_frag(HID + (m * 16 + li) * HS + 8 * kq, ah0, al0);
                 raw_frag(HID + (m * 16 + li) * HS + 32 + 8 * kq, ah1, al1);
