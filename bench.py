@@ -405,14 +405,14 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     spt_fl = spt_flops_per_forward(flags, a.batch)
     spt_us = spt_ms / max(1, spt_n) * 1e3
     spt_t = spt_fl / (spt_us * 1e-6) / 1e12
-    # the SPT Linear layers run from split operands on the bf16 pipe (spt3_kernel) unless fp32_mfma was asked for: the
-    # executed matrix work is then 6 bf16 products per product of the four Linear layers (272 = 17 x 16 rows per
-    # workgroup, no padding); the 17 x 17 x hd 4 attention is VALU work and not part of `achieved`
+    # the SPT Linear layers run from two-part fp16 operands (spt3_kernel, the arithmetic of the h2 engine) unless fp32_mfma was
+    # asked for: the executed matrix work is then 3 fp16 products per product of the four Linear layers (272 = 17 x 16 rows
+    # per workgroup, no padding); the 17 x 17 x hd 4 attention is VALU work and not part of `achieved`
     spt_packed = a.precision != "fp32_mfma"
     spt_lin = (flags["depth"] + 1) * 16.0 * 17 * 32 * 32 * flags["num_views"] * a.batch
     if spt_packed:
-        spt_ex = spt_lin * 6.0 / (spt_us * 1e-6) / 1e12
-        spt_roof = dict(kernel="spt3_kernel", instruction="v_mfma_f32_16x16x32_bf16 (split operands) + VALU attention",
+        spt_ex = spt_lin * 3.0 / (spt_us * 1e-6) / 1e12
+        spt_roof = dict(kernel="spt3_kernel", instruction="v_mfma_f32_16x16x32_f16 (two-part operands, 3 products) + VALU attention",
                         achieved=round(spt_ex, 2), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(spt_ex / PEAK_BF16_MFMA_TFLOPS, 4), algorithmic_tflops=round(spt_t, 2))
     else:
