@@ -1020,12 +1020,23 @@ __global__ __launch_bounds__(512) void d32_qkv_kernel(const float* __restrict__ 
         sq[n] = ld4(vec + SPT_NCOL + SPT_C_QKV + 16 * n + 4 * kq);
     }
     const int n_tiles = (M + 15) / 16;
+    // the rows of the NEXT tile of this wave are requested before the current one is multiplied (a wave walks ~4 tiles; one
+    // memory round trip per tile in the open was most of the kernel's time)
+    auto rows_of = [&](int tile, float4& a0, float4& a1) {
+        const int r = tile * 16 + li;
+        const float* xr = x + (size_t)(r < M ? r : M - 1) * SD + 8 * kq;
+        a0 = ld4(xr);
+        a1 = ld4(xr + 4);
+    };
+    float4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
+    if (gw < n_tiles) rows_of(gw, n0, n1);
     for (int tile = gw; tile < n_tiles; tile += nw) {
         const int row = tile * 16 + li;
         const bool ok = row < M;
-        const float* xr = x + (size_t)(ok ? row : M - 1) * SD + 8 * kq;
+        const float4 c0 = n0, c1 = n1;
+        if (tile + nw < n_tiles) rows_of(tile + nw, n0, n1);
         sf16x8 ah, al;
-        d32_ln_split(ld4(xr), ld4(xr + 4), ah, al);
+        d32_ln_split(c0, c1, ah, al);
         float* o = qkv + (size_t)row * (3 * SD) + 4 * kq;
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
@@ -1064,22 +1075,33 @@ __global__ __launch_bounds__(512) void d32_mlp_kernel(float* __restrict__ x, con
     }
     const float s_att = vec[2 * SPT_NCOL], hs = vec[2 * SPT_NCOL + 1];
     const int n_tiles = (M + 15) / 16;
+    // operands of the NEXT tile of this wave (attention rows as A fragment, x in accumulator layout) are requested up front
+    auto rows_of = [&](int tile, float4& a0, float4& a1, float4 (&xo)[2]) {
+        const int r = tile * 16 + li;
+        const size_t rcl = (size_t)(r < M ? r : M - 1);
+        a0 = ld4(att + rcl * SD + 8 * kq);
+        a1 = ld4(att + rcl * SD + 8 * kq + 4);
+        xo[0] = ld4(x + rcl * SD + 4 * kq);
+        xo[1] = ld4(x + rcl * SD + 16 + 4 * kq);
+    };
+    float4 na0 = {0.f, 0.f, 0.f, 0.f}, na1 = na0, nx[2] = {na0, na0};
+    if (gw < n_tiles) rows_of(gw, na0, na1, nx);
     for (int tile = gw; tile < n_tiles; tile += nw) {
         const int row = tile * 16 + li;
         const bool ok = row < M;
-        const size_t rc = (size_t)(ok ? row : M - 1);
         // ---- x += att . Wproj^T + b
         float4 xn[2];
         {
-            const float* ar = att + rc * SD + 8 * kq;
-            const float4 a0 = ld4(ar), a1 = ld4(ar + 4);
+            const float4 a0 = na0, a1 = na1;
+            const float4 xc[2] = {nx[0], nx[1]};
+            if (tile + nw < n_tiles) rows_of(tile + nw, na0, na1, nx);
             const float y[8] = {a0.x * s_att, a0.y * s_att, a0.z * s_att, a0.w * s_att, a1.x * s_att, a1.y * s_att, a1.z * s_att, a1.w * s_att};
             sf16x8 ah, al;
             spt_split2(y, ah, al);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const f32x4 c = mfma3(wp[n], ah, al, f32x4{0.f, 0.f, 0.f, 0.f});
-                const float4 xo = ld4(x + rc * SD + 16 * n + 4 * kq);
+                const float4 xo = xc[n];
                 xn[n] = float4{xo.x + fmaf(c[0], sp[n].x, bp[n].x), xo.y + fmaf(c[1], sp[n].y, bp[n].y), xo.z + fmaf(c[2], sp[n].z, bp[n].z),
                                xo.w + fmaf(c[3], sp[n].w, bp[n].w)};
                 st4(XT + li * XS + 16 * n + 4 * kq, xn[n]);
