@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 9
+#define MPL_HIP_ABI_VERSION 10
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -92,10 +92,14 @@ typedef struct mpl_block_weights {
     const uint16_t *qkv_w3, *proj_w3, *fc1_w3, *fc2_w3;
     /* Optional fp16x2 operands (mpl_pack_h2) of the four Linear layers, same folding as above: the DEFAULT fp32 engine of the
      * FPT block stack (csrc/h2_gemm.hip).  Every fp32 operand is split in two fp16 parts under an exact power-of-two scale
-     * (per weight column; static per layer for the activations, from a data-free bound), each product is accumulated in fp32
+     * (per weight column; static per activation column, from a data-free bound), each product is accumulated in fp32
      * from three partial products ("3xTF32" on the fp16 matrix cores): as accurate as an fp32 GEMM, half the matrix
      * instructions and two thirds of the operand bytes of the *_w3 engine.  Used when all four are non-NULL (and *_w16,
-     * *_w3 are NULL) in every block; shapes must satisfy mpl_pack_h2_bytes() != 0. */
+     * *_w3 are NULL) in every block; shapes must satisfy mpl_pack_h2_bytes() != 0.  qkv_h2 / fc1_h2 come from mpl_pack_h2 (norm1 /
+     * norm2 folded); proj_h2 / fc2_h2 from mpl_pack_h2_scaled against the static output scales of the layer that produces their
+     * input: in_scale = mpl_pack_h2_out_scale(qkv_h2, 3D, D) + 2D (the v columns) for proj, mpl_pack_h2_out_scale(fc1_h2, 2D, D)
+     * for fc2.  The stack verifies that pairing on the device (fingerprints inside the operands) and poisons the call's output
+     * (NaN poses, MPL_E_DEVICE) on a mismatch. */
     const uint16_t *qkv_h2, *proj_h2, *fc1_h2, *fc2_h2;
 } mpl_block_weights;
 
@@ -293,6 +297,15 @@ int mpl_pose_metrics_ex(const float *output, const float *target, const float *w
 size_t mpl_pack_h2_bytes(int N, int K);
 int mpl_pack_h2(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
                 void *stream);
+/* Static activation scales.  A LayerNorm operand stores, per output column n, the power of two so_n that brings the data-free
+ * bound of |out_n| (sqrt(K) |gamma o W_n|_2 + |bias_n + beta . W_n|) to the top of the fp16 window; the GEMM epilogue that hands
+ * column n on as a packed operand (attention output: a convex combination of v rows; GELU output: |gelu(t)| <= |t|) multiplies
+ * by so_n.  mpl_pack_h2_out_scale returns the DEVICE address of so[N] inside such an operand.  The Linear that consumes those
+ * columns (proj after qkv's v columns, fc2 after fc1: multiview_mpl.py:65, :35) is packed with mpl_pack_h2_scaled: W_nk is stored
+ * as W_nk / in_scale_k (exact), so operands are equilibrated per channel and one outlier channel costs no other channel
+ * resolution.  in_scale: K powers of two on the device. */
+int mpl_pack_h2_scaled(const float *W, const float *bias, const float *in_scale, int N, int K, uint16_t *dst, void *stream);
+const float *mpl_pack_h2_out_scale(const uint16_t *operand, int N, int K);
 size_t mpl_ln_linear_h2_workspace_bytes(int M, int K);
 int mpl_ln_linear_h2(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W2, int N, int epilogue,
                      const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
@@ -321,7 +334,8 @@ int mpl_x3_spin_limit(int log2_polls);
 #define MPL_K_GEMM 2
 #define MPL_K_ATTENTION 3
 #define MPL_K_FUSE_HEAD 4
-#define MPL_K_COUNT 5
+#define MPL_K_PACK 5 /* derived-operand builders: mpl_pack_h2*, mpl_spt_pack, mpl_d32_pack, mpl_pack_bf16, mpl_split_bf16x3 */
+#define MPL_K_COUNT 6
 int mpl_profile_start(void);
 int mpl_profile_stop(float *kind_ms, int *kind_launches, int n_kinds);
 

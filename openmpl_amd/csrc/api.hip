@@ -71,6 +71,20 @@ void mpl::device_error_clear(int dev) {
 }
 
 namespace {
+std::atomic<int> g_fault_phase{0};
+}  // namespace
+void mpl::set_fault_injection(int phase) { g_fault_phase.store(phase); }
+int mpl::take_fault_injection() { return g_fault_phase.exchange(0); }
+int mpl::refuse_stream_capture(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return MPL_OK;                       // the legacy default stream cannot be queried while another stream captures
+    }
+    return st == hipStreamCaptureStatusNone ? MPL_OK : MPL_E_UNSUPPORTED;
+}
+
+namespace {
 std::mutex g_chain_mu[64];
 hipEvent_t g_chain_ev[64];
 std::mutex g_chain_create_mu;
@@ -183,9 +197,6 @@ H2Ws carve_h2_ws(void* base, size_t M, size_t D, int rpt) {
     w.bytes = off;
     return w;
 }
-inline const float* h2_meta(const uint16_t* op, int N, int K) {
-    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(op) + h2_operand_bytes(N, K)) - 8;
-}
 int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
                    int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s);
 
@@ -249,33 +260,31 @@ int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     const int n_tiles = (M + rpt - 1) / rpt;
     if (err_ws) *err_ws = w.counters + n_tiles;
     int rc;
-    // entry of the stack, one launch: LayerNorm slice partials of the incoming rows, zeroed arrival counters + error word
-    if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, n_tiles + 1, s))) return rc;
-    if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
-        const unsigned short* ops[MPL_MAX_APPS * 4];
-        for (int a = 0; a < n_apps; ++a) {
-            const mpl_block_weights& b = blocks[schedule[a]];
-            for (int i = 0; i < 4; ++i) ops[4 * a + i] = (&b.qkv_h2)[i];
-        }
-        return launch_h2_stack(x, M, D, n_tok, H, ops, n_apps, w.att2, w.hid2, w.stats, w.counters, eps, g_x3_stop.load(), s);
+    const unsigned short* ops[MPL_MAX_APPS * 4];
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        for (int i = 0; i < 4; ++i) ops[4 * a + i] = (&b.qkv_h2)[i];
     }
+    // entry of the stack, one launch: LayerNorm slice partials of the incoming rows, zeroed arrival counters + error word, and
+    // the check that proj / fc2 were packed against the static scales of their producers (mpl_pack_h2_scaled)
+    if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, n_tiles + 1, ops, n_apps, s))) return rc;
+    if (!g_x3_per_gemm.load(std::memory_order_relaxed))
+        return launch_h2_stack(x, M, D, n_tok, H, ops, n_apps, w.att2, w.hid2, w.stats, w.counters, eps, g_x3_stop.load(), s);
     // A/B switch (mpl_x3_stack_mode): the same phases as one launch per GEMM
     const int stop = g_x3_stop.load();
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        const float* m_qkv = h2_meta(b.qkv_h2, 3 * D, D);
-        const float* m_fc1 = h2_meta(b.fc1_h2, 2 * D, D);
         if ((rc = launch_h2_qkv_attention(x, b.qkv_h2, w.stats, eps, M, D, n_tok, H, w.att2, s))) return rc;
         if (stop && 4 * a + 1 >= stop) return MPL_OK;
-        if ((rc = launch_h2_gemm(nullptr, w.att2, m_qkv + 3, b.proj_h2, false, nullptr, 0.f, x, D, x, D, nullptr, nullptr, w.stats, M, D, D,
+        if ((rc = launch_h2_gemm(nullptr, w.att2, nullptr, b.proj_h2, false, nullptr, 0.f, x, D, x, D, nullptr, w.stats, M, D, D,
                                  rpt, MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
         if (stop && 4 * a + 2 >= stop) return MPL_OK;
-        if ((rc = launch_h2_gemm(x, nullptr, nullptr, b.fc1_h2, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid2, m_fc1, nullptr, M, 2 * D,
+        if ((rc = launch_h2_gemm(x, nullptr, nullptr, b.fc1_h2, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid2, nullptr, M, 2 * D,
                                  D, rpt, MPL_EPI_BIAS_GELU, s)))
             return rc;
         if (stop && 4 * a + 3 >= stop) return MPL_OK;
-        if ((rc = launch_h2_gemm(nullptr, w.hid2, m_fc1 + 2, b.fc2_h2, false, nullptr, 0.f, x, D, x, D, nullptr, nullptr, w.stats, M, D,
+        if ((rc = launch_h2_gemm(nullptr, w.hid2, nullptr, b.fc2_h2, false, nullptr, 0.f, x, D, x, D, nullptr, w.stats, M, D,
                                  2 * D, rpt, MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
     }
@@ -513,8 +522,16 @@ size_t mpl_pack_h2_bytes(int N, int K) { return h2_operand_bytes(N, K); }
 int mpl_pack_h2(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst, void* stream) {
     clear_stale_hip_error();
     if (mpl_pack_h2_bytes(N, K) == 0) return MPL_E_INVALID;
-    return launch_pack_h2(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
+    return launch_pack_h2(W, N, K, ln_w, ln_b, bias, nullptr, dst, (hipStream_t)stream);
 }
+
+int mpl_pack_h2_scaled(const float* W, const float* bias, const float* in_scale, int N, int K, uint16_t* dst, void* stream) {
+    clear_stale_hip_error();
+    if (mpl_pack_h2_bytes(N, K) == 0 || !in_scale) return MPL_E_INVALID;
+    return launch_pack_h2(W, N, K, nullptr, nullptr, bias, in_scale, dst, (hipStream_t)stream);
+}
+
+const float* mpl_pack_h2_out_scale(const uint16_t* operand, int N, int K) { return h2_out_scale(operand, N, K); }
 
 size_t mpl_ln_linear_h2_workspace_bytes(int M, int K) {
     const size_t a = h2_act_bytes(M, K, 64);
@@ -530,14 +547,14 @@ int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const 
     if (has_ln) {
         if (!stats) return MPL_E_INVALID;
         if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
-        return launch_h2_gemm(x, nullptr, nullptr, W2, true, stats, eps, residual, N, y, N, nullptr, nullptr, nullptr, M, N, K, 64, epilogue, s);
+        return launch_h2_gemm(x, nullptr, nullptr, W2, true, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
     }
     const size_t need = mpl_ln_linear_h2_workspace_bytes(M, K);
     if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
     float* sc = reinterpret_cast<float*>(workspace);
     unsigned short* a2 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + 256);
     if ((rc = launch_h2_pack_rows(x, M, K, K, 64, a2, sc, s))) return rc;
-    return launch_h2_gemm(nullptr, a2, sc + 2, W2, false, nullptr, 0.f, residual, N, y, N, nullptr, nullptr, nullptr, M, N, K, 64, epilogue, s);
+    return launch_h2_gemm(nullptr, a2, sc + 2, W2, false, nullptr, 0.f, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
 }
 
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
@@ -559,8 +576,14 @@ int mpl_device_error_clear(int device) {
 
 int mpl_x3_spin_limit(int log2_polls) {
     if ((log2_polls & 0xff) < 1 || (log2_polls & 0xff) > 30 || log2_polls < 0) return MPL_E_INVALID;
-    x3_set_spin_log2(log2_polls);
-    h2_set_spin_log2(log2_polls);
+    // the fault injection (bits 8..) is compiled into the product library but inert unless the process opted in
+    // (MPL_FAULT_INJECT=1 in the environment when the library was loaded), and it is ONE-SHOT: the first stack launch that
+    // consumes it clears it, so a test that dies between set and reset cannot leave the process deserting workgroups
+    static const bool inject_ok = getenv("MPL_FAULT_INJECT") != nullptr && atoi(getenv("MPL_FAULT_INJECT")) != 0;
+    if ((log2_polls >> 8) != 0 && !inject_ok) return MPL_E_UNSUPPORTED;
+    x3_set_spin_log2(log2_polls & 0xff);
+    h2_set_spin_log2(log2_polls & 0xff);
+    set_fault_injection(log2_polls >> 8);
     return MPL_OK;
 }
 
@@ -658,12 +681,14 @@ int mpl_pose_metrics_size(int joints) { return 4 + 2 * (joints + 1) + 3 * joints
 int mpl_pose_metrics(const float* output, const float* target, const float* weight, int batch, int joints,
                      const float* scale3, const float* offset3, float* result, void* stream) {
     clear_stale_hip_error();
+    if (int rc = earlier_device_failure()) return rc;
     return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, 0u, result, (hipStream_t)stream);
 }
 
 int mpl_pose_metrics_ex(const float* output, const float* target, const float* weight, int batch, int joints,
                         const float* scale3, const float* offset3, uint32_t not_consider_mask, float* result, void* stream) {
     clear_stale_hip_error();
+    if (int rc = earlier_device_failure()) return rc;
     return launch_pose_metrics(output, target, weight, batch, joints, scale3, offset3, not_consider_mask, result, (hipStream_t)stream);
 }
 

@@ -147,6 +147,14 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
 unsigned* device_error_word(int dev);      // device-usable address; nullptr if the allocation failed
 int device_error_pending(int dev);         // 1 when a kernel reported a failure since the last clear
 void device_error_clear(int dev);
+// test hook (mpl_x3_spin_limit): the phase before which one workgroup of the NEXT persistent launch deserts its team; taking it
+// clears it (one-shot, shared by both engines)
+void set_fault_injection(int phase);
+int take_fault_injection();
+// 0 when `s` is not being captured into a graph; MPL_E_UNSUPPORTED when it is: the persistent launches are serialised per
+// device through a process-global event, which a capture would turn into a captured event (later eager launches on other
+// streams would then depend on a graph-internal node) and a graph replay would bypass altogether
+int refuse_stream_capture(hipStream_t s);
 void x3_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
 void h2_set_spin_log2(int log2_polls);
 // The persistent block-stack kernels (x3_stack_kernel, h2_stack_kernel) need every workgroup resident: the library
@@ -159,17 +167,19 @@ int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, 
 // fp32 GEMMs on the fp16 matrix cores from operands split in TWO fp16 parts (three partial products), h2_gemm.hip: the
 // default engine of the FPT block stack
 bool h2_shape_ok(int N, int K);
-size_t h2_operand_bytes(int N, int K);                    // packed weights + {c, sc, sw, bound}[N] + meta[8]; 0 = no layout
+size_t h2_operand_bytes(int N, int K);                    // packed weights + {c, sc, sw, bound, so}[N] + meta[8]; 0 = no layout
+const float* h2_out_scale(const unsigned short* op, int N, int K);   // so[N] inside an operand: static per-column scales of its outputs
 size_t h2_act_bytes(int M, int K, int rpt);
 int h2_rows_per_tile(int n_tok);
 bool h2_attention_fusable(int n_tok, int dim, int heads);
 void h2_set_debug_buffer(unsigned long long* p);
-int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
-                   hipStream_t s);
-int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters, hipStream_t s);
+int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, const float* in_scale,
+                   unsigned short* dst, hipStream_t s);
+int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters,
+                    const unsigned short* const* ops, int n_apps, hipStream_t s);
 int launch_h2_pack_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, float* sc, hipStream_t s);
 int launch_h2_gemm(const float* X, const unsigned short* A2, const float* a_inv, const unsigned short* W2, bool ln, const float* stats,
-                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, const float* o_scale, float* stats_out,
+                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, float* stats_out,
                    int M, int N, int K, int rpt, int epi, hipStream_t s);
 int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const float* stats, float eps, int M, int D, int n_tok,
                             int heads, unsigned short* att2, hipStream_t s);

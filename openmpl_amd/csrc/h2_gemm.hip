@@ -22,11 +22,16 @@
 //   * the input of a LayerNorm GEMM (qkv, fc1) is normalised BEFORE it is split: z = (x - mean) rstd 2^10, |z| <= sqrt(K)
 //     2^10 < 65504 for every K <= 2048 -- the gain gamma is folded into W, beta and the bias into c:
 //         LN(x) . W^T + b  =  2^-10 sw_n^-1 ( z . (sw_n gamma o W_n) ) + c_n,     c_n = b_n + sum_k beta_k W_nk ;
-//   * the inputs of proj and fc2 (attention output, GELU output) use one STATIC scale per layer from a bound that needs no
-//     data: |LN(x) . W_n + b_n| <= sqrt(K) |gamma o W_n|_2 + |c_n| (Cauchy-Schwarz, |LN(x)|_2 <= sqrt(K)); the attention
-//     output is a convex combination of v rows and |gelu(t)| <= |t|, so the bound of the producing Linear holds for both.
-//     Typical values sit sqrt(K) below the bound, i.e. at >= 2^10 of a 2^15 window; fp16 subnormals are honoured by the
-//     MFMA and by v_cvt (tools/h2_probe.hip), so the absolute resolution is 2^-24 2^-11 of the window.
+//   * the inputs of proj and fc2 (attention output, GELU output) use one STATIC scale PER COLUMN (= per k of the consumer)
+//     from a bound that needs no data: |LN(x) . W_n + b_n| <= bound_n = sqrt(K) |gamma o W_n|_2 + |c_n| (Cauchy-Schwarz,
+//     |LN(x)|_2 <= sqrt(K)); the attention output is a convex combination of v rows (column by column) and |gelu(t)| <= |t|,
+//     so the bound of the producing column holds for both.  so_n = the largest power of two with so_n bound_n <= 2^15 is
+//     stored behind the producer's fragments; the producing epilogue multiplies column n by so_n, and the CONSUMER's weights
+//     are packed as W_mk / so_k (exact), their column scale sw_m taken afterwards -- the operands are column-equilibrated, so
+//     one outlier channel (a huge v bias, one fc1 row 1e4 x the others) costs no other channel anything (round 3 used one
+//     scale per layer: the outlier set the window of every column; tests/test_robust_gpu.py).  Typical values sit sqrt(K)
+//     below their bound, i.e. at >= 2^10 of a 2^15 window; fp16 subnormals are honoured by the MFMA and by v_cvt
+//     (tools/h2_probe.hip), so the absolute resolution is 2^-24 2^-11 of the window.
 // Nothing overflows for ANY input; the unit-test entry (mpl_ln_linear_h2) scales a plain A operand by its measured amax.
 //
 // Data flow of a block application (x = fp32 residual stream, the ONLY activation kept in fp32):
@@ -41,8 +46,8 @@
 //   k-tile t < 4G:  lane (i, kq) element j <-> column 136 (t/4) + 32 (t%4) + 16 (j/4) + 4 kq + (j%4);  t = 4G + u: 136 (4u + kq) + 128 + j
 //   A2[row tile][4 row groups][KT][2 parts][64 lanes][8 fp16]     lane = 16 kq + i, i = row in the 16-row group
 //   W2[N/136][KT][9 slots][2 parts][64 lanes][8 fp16]             slot s = column tile {0,1,2,3,8,4,5,6,7}[s]
-//       followed by fp32 vectors c[N], sc[N] (epilogue multiplier), sw[N], bound[N] and meta[8] = {scale of the packed
-//       output (all columns), the same for the last third of the columns (v), their reciprocals, ...}
+//       followed by fp32 vectors c[N], sc[N] (epilogue multiplier), sw[N], bound[N], so[N] (static scale of output column n
+//       when it travels on as a packed operand) and meta[8] = {.., fingerprints of so / of the input scales, see h2_meta_kernel}
 // Workgroup = one row tile x 136 columns (x NPASS column groups), 8 waves: wave w owns row group w & 3 and slots 0..4
 // (w < 4) or 5..8.  Stage = A 8 KiB + W 18 KiB = 26 KiB, ring of 6 (156 KiB, one workgroup per CU).
 // The k order of every output element is fixed: results do not depend on batch size or launch geometry.
@@ -71,6 +76,7 @@ constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
 constexpr int H2_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the generic attention epilogue
 constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (|z| <= sqrt(K): fine up to K = 2048)
+constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind the fragments: c | sc | sw | bound | so
 #ifndef H2_DBG
 #define H2_DBG 0
 #endif
@@ -103,7 +109,7 @@ bool h2_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 
 
 size_t h2_operand_bytes(int N, int K) {
     if (!h2_shape_ok(N, K)) return 0;
-    return (size_t)(N / BN) * (K / BK) * H2_W + ((size_t)4 * N + 8) * sizeof(float);
+    return (size_t)(N / BN) * (K / BK) * H2_W + ((size_t)H2_TRV * N + 8) * sizeof(float);
 }
 size_t h2_act_bytes(int M, int K, int rpt) {
     if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
@@ -136,20 +142,24 @@ __host__ __device__ inline float h2_window_scale(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------- weight operand
-// trailer floats behind the fragments: c[N] | sc[N] | sw[N] | bound[N] | meta[8]
-// One wave per output column n: the column scale sw_n (max |gamma o W_n| sw_n in [2^13, 2^14)), c_n = b_n + sum_k beta_k W_nk
-// (fp64 sum), the epilogue multiplier sc_n = 1 / (sa sw_n) (sa = the static scale of a normalised LayerNorm input, or 1) and
-// the data-free bound of |out_n| (LayerNorm GEMMs only; see the head of the file).
+// trailer floats behind the fragments: c[N] | sc[N] | sw[N] | bound[N] | so[N] | meta[8]
+// One wave per output column n: the column scale sw_n (max |f o W_n| sw_n in [2^13, 2^14); f = the LayerNorm gain, or the
+// reciprocal of the static scales the A operand arrives with, or 1), c_n = b_n + sum_k beta_k W_nk (fp64 sum), the epilogue
+// multiplier sc_n = 1 / (sa sw_n) (sa = the static scale of a normalised LayerNorm input, or 1), the data-free bound of
+// |out_n| and the static scale so_n it implies for column n as an operand (LayerNorm GEMMs only; see the head of the file).
+__device__ __forceinline__ float h2_in_factor(const float* gamma, const float* in_scale, int k) {
+    return gamma ? gamma[k] : (in_scale ? 1.0f / in_scale[k] : 1.0f);      // in_scale: powers of two, the reciprocal is exact
+}
 __global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
-                                                       float* __restrict__ tr) {
+                                                       const float* __restrict__ beta, const float* __restrict__ bias,
+                                                       const float* __restrict__ in_scale, int N, int K, float* __restrict__ tr) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
     double ss = 0.0, c = 0.0;
     float amax = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const float wg = gamma ? w * gamma[k] : w;
+        const float wg = (gamma || in_scale) ? w * h2_in_factor(gamma, in_scale, k) : w;
         amax = fmaxf(amax, fabsf(wg));
         ss += (double)wg * (double)wg;
         if (gamma) c += (double)w * (double)beta[k];
@@ -174,36 +184,59 @@ __global__ __launch_bounds__(256) void h2_fold_kernel(const float* __restrict__ 
         tr[n] = cn;
         tr[N + n] = 1.0f / (sa * sw);
         tr[2 * N + n] = sw;
-        tr[3 * N + n] = gamma ? (float)(sqrt((double)K) * sqrt(ss)) + fabsf(cn) : 0.f;
+        const float bound = gamma ? (float)(sqrt((double)K) * sqrt(ss)) + fabsf(cn) : 0.f;
+        tr[3 * N + n] = bound;
+        tr[4 * N + n] = gamma ? h2_window_scale(bound) : 1.0f;
     }
 }
-// meta: the static scales of what a LayerNorm GEMM hands on (all columns: GELU output of fc1; last third: v of qkv)
-__global__ __launch_bounds__(256) void h2_meta_kernel(int N, float* __restrict__ tr) {
-    __shared__ float red[2][256];
-    float ball = 0.f, bv = 0.f;
+// meta[0..5]: the largest bound over all columns / over the last third of the columns (v of qkv), the window scales they
+// imply and their reciprocals (informational since the scales went per column).  meta[6], meta[7]: FINGERPRINTS that let the
+// stack check that a consumer operand was packed against the scales its producer applies -- 0.5 + the sum of the binary
+// exponents (exact in fp32) of so over all columns [6] and over the last third [7] for a LayerNorm operand; for a plain
+// operand [6] = the same sum over the in_scale vector it was packed with (0 without one) and [7] = 0.
+__global__ __launch_bounds__(256) void h2_meta_kernel(int N, int K, int has_ln, const float* __restrict__ in_scale, float* __restrict__ tr) {
+    __shared__ float red[4][256];
+    float ball = 0.f, bv = 0.f, fall = 0.f, fv = 0.f;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float b = tr[3 * N + n];
+        const float e = (float)ilogbf(tr[4 * N + n]);
         ball = fmaxf(ball, b);
-        if (3 * n >= 2 * N) bv = fmaxf(bv, b);
+        fall += e;
+        if (3 * n >= 2 * N) {
+            bv = fmaxf(bv, b);
+            fv += e;
+        }
+    }
+    if (!has_ln) {
+        fall = fv = 0.f;
+        if (in_scale)
+            for (int k = threadIdx.x; k < K; k += 256) fall += (float)ilogbf(in_scale[k]);
     }
     red[0][threadIdx.x] = ball;
     red[1][threadIdx.x] = bv;
+    red[2][threadIdx.x] = fall;
+    red[3][threadIdx.x] = fv;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             red[0][threadIdx.x] = fmaxf(red[0][threadIdx.x], red[0][threadIdx.x + s]);
             red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+            red[2][threadIdx.x] += red[2][threadIdx.x + s];          // integers far below 2^24: exact in any order
+            red[3][threadIdx.x] += red[3][threadIdx.x + s];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        float* m = tr + 4 * N;
+        float* m = tr + H2_TRV * N;
         const float sa = h2_window_scale(red[0][0]), sv = h2_window_scale(red[1][0]);
         m[0] = sa; m[1] = sv; m[2] = 1.0f / sa; m[3] = 1.0f / sv;
-        m[4] = red[0][0]; m[5] = red[1][0]; m[6] = 0.f; m[7] = 0.f;
+        m[4] = red[0][0]; m[5] = red[1][0];
+        m[6] = (has_ln || in_scale) ? red[2][0] + 0.5f : 0.f;
+        m[7] = has_ln ? red[3][0] + 0.5f : 0.f;
     }
 }
-__global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict__ W, const float* __restrict__ gamma, int N, int K,
+__global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                         const float* __restrict__ in_scale, int N, int K,
                                                          const float* __restrict__ tr, f16x8* __restrict__ dst, size_t total) {
     const int G = K / BN, KT = K / BK;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -220,7 +253,8 @@ __global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict_
             if (c < BN) {
                 const int k = h2_col(kt, kq, j, G);
                 const float w = W[(size_t)(g * BN + c) * K + k];
-                x[j] = (gamma ? w * gamma[k] : w) * tr[2 * N + g * BN + c];    // gain folded (one fp32 rounding), then the exact column scale
+                // gain folded (one fp32 rounding; the reciprocal input scale is exact), then the exact column scale
+                x[j] = ((gamma || in_scale) ? w * h2_in_factor(gamma, in_scale, k) : w) * tr[2 * N + g * BN + c];
             }
         }
         f16x8 hi, lo;
@@ -231,26 +265,56 @@ __global__ __launch_bounds__(256) void h2_pack_w_kernel(const float* __restrict_
     }
 }
 
-int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
-                   hipStream_t s) {
+// in_scale (optional, plain operands only): device vector of K powers of two, the static scales the A operand's columns
+// arrive with (the so vector of the producing layer, h2_out_scale): the weights are packed as W_nk / in_scale_k
+const float* h2_out_scale(const unsigned short* op, int N, int K) {
+    if (!op || !h2_shape_ok(N, K)) return nullptr;
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(op) + (size_t)(N / BN) * (K / BK) * H2_W) + 4 * (size_t)N;
+}
+int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, const float* in_scale,
+                   unsigned short* dst, hipStream_t s) {
     if (!W || !dst || !bias || !h2_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr))) return MPL_E_INVALID;
+    if (ln_w && in_scale) return MPL_E_INVALID;          // a LayerNorm input is normalised in the k loop: it has no static scale
     if (ln_w && K > 1088) return MPL_E_UNSUPPORTED;      // the kernel combines at most 8 slice partials per row (K = 136 x 8)
     float* tr = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (size_t)(N / BN) * (K / BK) * H2_W);
-    hipLaunchKernelGGL(h2_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, N, K, tr);
-    hipLaunchKernelGGL(h2_meta_kernel, dim3(1), dim3(256), 0, s, N, tr);
+    ProfScope prof(MPL_K_PACK, s);
+    hipLaunchKernelGGL(h2_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ln_w, ln_b, bias, in_scale, N, K, tr);
+    hipLaunchKernelGGL(h2_meta_kernel, dim3(1), dim3(256), 0, s, N, K, ln_w ? 1 : 0, in_scale, tr);
     const size_t total = (size_t)(N / BN) * (K / BK) * NT * 64;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(h2_pack_w_kernel, dim3(grid), dim3(256), 0, s, W, ln_w, N, K, tr, reinterpret_cast<f16x8*>(dst), total);
+    hipLaunchKernelGGL(h2_pack_w_kernel, dim3(grid), dim3(256), 0, s, W, ln_w, in_scale, N, K, tr, reinterpret_cast<f16x8*>(dst), total);
     return hip_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------- entry of a stack
 // One launch in front of the persistent kernel: the LayerNorm slice partials {mean, M2} of the incoming rows (one wave per
 // row, two-pass per 136-column slice) and -- block 0 -- the zeroed arrival counters + error word of the call.
+// With `ops` (the stack's operands) block 0 also checks that every proj / fc2 operand was packed against the static scales its
+// producer applies (fingerprints in meta[6], meta[7], h2_meta_kernel): a mismatch sets the error words of the call -- the
+// poses come out NaN and the device reports MPL_E_DEVICE -- instead of multiplying under the wrong scales.
+struct H2Ops {
+    int n_apps, D;
+    unsigned* err_host;
+    const char* w[MPL_MAX_APPS][4];
+};
 __global__ __launch_bounds__(256) void h2_entry_kernel(const float* __restrict__ X, int M, int K, int ldx, float* __restrict__ stats,
-                                                        unsigned* __restrict__ counters, int n_counters) {
-    if (blockIdx.x == 0 && counters)
+                                                        unsigned* __restrict__ counters, int n_counters, const H2Ops ops) {
+    if (blockIdx.x == 0 && counters) {
         for (int i = threadIdx.x; i < n_counters; i += 256) counters[i] = 0u;
+        __syncthreads();
+        const int D = ops.D;
+        for (int i = threadIdx.x; i < ops.n_apps; i += 256) {
+            auto meta = [&](const char* w2, int N, int Kw) -> const float* {
+                return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (Kw / BK) * H2_W) + H2_TRV * N;
+            };
+            const bool ok = meta(ops.w[i][1], D, D)[6] == meta(ops.w[i][0], 3 * D, D)[7] &&
+                            meta(ops.w[i][3], D, 2 * D)[6] == meta(ops.w[i][2], 2 * D, D)[6];
+            if (!ok) {
+                __hip_atomic_store(counters + n_counters - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ops.err_host) __hip_atomic_store(ops.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -277,10 +341,24 @@ __global__ __launch_bounds__(256) void h2_entry_kernel(const float* __restrict__
         }
     }
 }
-int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters, hipStream_t s) {
-    if (!X || !stats || M <= 0 || K % BN || (ldx & 3)) return MPL_E_INVALID;
+// ops (optional): n_apps x {qkv, proj, fc1, fc2} operands of the stack that follows (width K), checked as described above;
+// the error word of the call is counters[n_counters - 1]
+int launch_h2_entry(const float* X, int M, int K, int ldx, float* stats, unsigned* counters, int n_counters,
+                    const unsigned short* const* ops, int n_apps, hipStream_t s) {
+    if (!X || !stats || M <= 0 || K % BN || (ldx & 3) || n_apps < 0 || n_apps > MPL_MAX_APPS || (ops && !counters)) return MPL_E_INVALID;
+    H2Ops o;
+    o.n_apps = ops ? n_apps : 0;
+    o.D = K;
+    o.err_host = nullptr;
+    int dev = 0;
+    if (ops && hipGetDevice(&dev) == hipSuccess) o.err_host = device_error_word(dev);
+    for (int i = 0; i < o.n_apps; ++i)
+        for (int j = 0; j < 4; ++j) {
+            if (!ops[4 * i + j]) return MPL_E_INVALID;
+            o.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
+        }
     ProfScope prof(MPL_K_ROW_STATS, s);
-    hipLaunchKernelGGL(h2_entry_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, M, K, ldx, stats, counters, n_counters);
+    hipLaunchKernelGGL(h2_entry_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, M, K, ldx, stats, counters, n_counters, o);
     return hip_check_launch();
 }
 
@@ -350,7 +428,7 @@ struct H2Args {
     const float* svec;       // sc per output column: 1 / (sa sw)
     const float* stats;      // LNF: per-row slice partials of the K-wide input rows
     const float* a_inv;      // !LNF: device scalar, reciprocal of the scale of A2 (NULL = 1)
-    const float* o_scale;    // C2 != NULL: device scalar, scale of the packed output
+    const float* ovec;       // C2 != NULL: so per output column (absolute column index), the static scales of the packed output
     const float* R;          // residual (fp32), EPI_RES
     int ldr;
     float* C;                // fp32 output (optional)
@@ -370,11 +448,7 @@ struct H2Args {
 static std::atomic<unsigned long long*> g_h2_dbg{nullptr};
 void h2_set_debug_buffer(unsigned long long* p) { g_h2_dbg.store(p); }
 static std::atomic<int> g_h2_spin_log2{23};
-static std::atomic<int> g_h2_inject{0};
-void h2_set_spin_log2(int v) {
-    g_h2_spin_log2.store(v & 0xff);
-    g_h2_inject.store(v >> 8);
-}
+void h2_set_spin_log2(int v) { g_h2_spin_log2.store(v & 0xff); }
 
 enum { H2_EPI_BIAS = 0, H2_EPI_GELU = 1, H2_EPI_RES = 2, H2_EPI_ATT = 3 };
 
@@ -410,9 +484,9 @@ __device__ __forceinline__ void h2_emit_tail(bool wt, char* base, int t, unsigne
 
 // Attention.forward :55-64 on the q | k | v tile T[64][H2_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
 // channels, generic form (any n_tok <= 32, any head width that divides 136): S whole sequences of nt tokens; the output
-// is written as packed A2 of width Dq (scaled by osc) for proj.  The 4-token shapes never come here (registers).
+// is written as packed A2 of width Dq (column c scaled by so[c], the static scales of this workgroup's 136 v columns) for proj.  The 4-token shapes never come here (registers).
 __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C2, int tile_m,
-                                             int g_out, int Dq, float osc) {
+                                             int g_out, int Dq, const float* so) {
     const int hd4 = hd >> 2;
     const int HP = BN / hd, nn = nt * nt;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -470,14 +544,16 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
         const int li = t & 15, kq = (t >> 4) & 3, rg = (t >> 6) & 3, p = t >> 8;
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
-        const float x[8] = {a.x * osc, a.y * osc, a.z * osc, a.w * osc, b.x * osc, b.y * osc, b.z * osc, b.w * osc};
+        const float4 sa = ld4(so + 32 * p + 4 * kq), sb = ld4(so + 32 * p + 16 + 4 * kq);       // static scale per column
+        const float x[8] = {a.x * sa.x, a.y * sa.y, a.z * sa.z, a.w * sa.w, b.x * sb.x, b.y * sb.y, b.z * sb.z, b.w * sb.w};
         h2_emit_frag(WT, cbase, 4 * g_out + p, (unsigned)(rg * strip + (kq * 16 + li) * 16), x);
     }
     for (int t = tid; t < BM * 2; t += 512) {
         const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 128 + 4 * kq);
-        const float x[8] = {a.x * osc, a.y * osc, a.z * osc, a.w * osc, 0.f, 0.f, 0.f, 0.f};
+        const float4 sa = ld4(so + 128 + 4 * kq);
+        const float x[8] = {a.x * sa.x, a.y * sa.y, a.z * sa.z, a.w * sa.w, 0.f, 0.f, 0.f, 0.f};
         h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(rg * strip + ((g_out & 3) * 16 + li) * 16 + kq * 8), x);
     }
 }
@@ -623,14 +699,21 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     };
     static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
 
-    // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue)
+    // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue), and behind
+    // them the static scales so of the columns that leave as a packed operand (attention: the v pass; else every pass)
+    constexpr int NSO = EPI == H2_EPI_ATT ? 1 : (EPI == H2_EPI_RES ? 0 : NPASS);
+    constexpr int VSO = NPASS * 2 * BN;                            // float offset of the so block inside the vector region
+    static_assert((NPASS * 2 + NSO) * BN * 4 <= 4092, "epilogue vectors overflow the spare LDS");
     if (HAS_A) {
         constexpr int NV = NPASS * 2 * (BN / 4);                   // float4s: [pass][c | sc][34]
         int idx = wave * 64 + lane;
-        const bool on = idx < NV;
-        idx = on ? idx : 0;
+        const bool vec = idx < NV;
+        const bool on = vec || (idx < NV + NSO * (BN / 4) && a.ovec != nullptr);
+        const int q = idx - NV;                                    // so block: [pass (attention: the v pass only)][34]
+        idx = vec ? idx : 0;
         const int vp = idx / (2 * (BN / 4)), which = (idx / (BN / 4)) & 1, c4 = idx % (BN / 4);
         const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
+        if (!vec && on) src = a.ovec + colbase(EPI == H2_EPI_ATT ? 2 : q / (BN / 4)) + 4 * (q % (BN / 4));
         if (on) dma16(src, lds0 + (unsigned)(H2_VEC + wave * 1024));
     }
     // ---- prologue.  Chain mode: W(0) does not depend on the other workgroups and is requested BEFORE the wait for them;
@@ -702,7 +785,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         issue_a();
     }
     const float ainv = (!LNF && a.a_inv) ? a.a_inv[0] : 1.0f;
-    const float osc = a.o_scale ? a.o_scale[0] : 1.0f;
 
     // residual of this lane's outputs (fp32 rows this workgroup wrote itself two phases ago, or a previous launch wrote)
     float4 rv[NTW];
@@ -978,6 +1060,12 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             v[r] = ok ? t : 0.f;
         }
     };
+    // static scales of the 4 columns of tile n as they leave packed (so block p of the vector region)
+    auto oscale4 = [&](int p, int n, float (&o)[4]) {
+        const int cl = 16 * tile_of(n) + 4 * kq;
+        const float4 sv = ld4(reinterpret_cast<const float*>(smem + H2_VEC) + VSO + p * BN + (cl + 3 < BN ? cl : 0));
+        o[0] = sv.x; o[1] = sv.y; o[2] = sv.z; o[3] = sv.w;
+    };
     unsigned long long t_st = 0;
 
     if constexpr (EPI == H2_EPI_ATT) {
@@ -1052,13 +1140,15 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         for (int n = 0; n < NTW; ++n) {
             const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
             const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
+            float so4[4];
+            oscale4(0, n, so4);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float o = pj[0] * quad(vv[n][c], 0);
                 o = fmaf(pj[1], quad(vv[n][c], 1), o);
                 o = fmaf(pj[2], quad(vv[n][c], 2), o);
                 o = fmaf(pj[3], quad(vv[n][c], 3), o);
-                ov[n][c] = o * osc;
+                ov[n][c] = o * so4[c];
             }
         }
         const int Go = Dq / BN, g_out = n0 / BN;
@@ -1089,7 +1179,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 }
             }
         __syncthreads();
-        h2_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm, n0 / BN, Dq, osc);
+        h2_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm, n0 / BN, Dq,
+                     reinterpret_cast<const float*>(smem + H2_VEC) + VSO);
       }
     } else {
         const int Go = N / BN;
@@ -1114,17 +1205,26 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                             __builtin_bit_cast(u32x4, o4));
                 }
             }
-            if (a.C2) {
+            if constexpr (NSO > 0) {
+              if (a.C2) {
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    float so4[4];
+                    oscale4(p, n, so4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vals[n][r] *= so4[r];
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const float x[8] = {vals[2 * q][0] * osc, vals[2 * q][1] * osc, vals[2 * q][2] * osc, vals[2 * q][3] * osc,
-                                        vals[2 * q + 1][0] * osc, vals[2 * q + 1][1] * osc, vals[2 * q + 1][2] * osc, vals[2 * q + 1][3] * osc};
+                    const float x[8] = {vals[2 * q][0], vals[2 * q][1], vals[2 * q][2], vals[2 * q][3],
+                                        vals[2 * q + 1][0], vals[2 * q + 1][1], vals[2 * q + 1][2], vals[2 * q + 1][3]};
                     h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
                 }
                 if (NTW == H2_T0 && kq < 2) {
-                    const float x[8] = {vals[NTW - 1][0] * osc, vals[NTW - 1][1] * osc, vals[NTW - 1][2] * osc, vals[NTW - 1][3] * osc, 0.f, 0.f, 0.f, 0.f};
+                    const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
                     h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
                 }
+              }
             }
         }
         if (H2_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
@@ -1255,7 +1355,7 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
             switch (ph & 3) {
                 case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
                     const float* v = vecs(w[0], 3 * D, D);
-                    const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D + 1, nullptr, 0, nullptr, 0, s.att2,
+                    const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D, nullptr, 0, nullptr, 0, s.att2,
                                    nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
                                    s.spin_log2};
                     if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
@@ -1277,9 +1377,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                     const int K = fc2 ? 2 * D : D;
                     const char* w2 = fc2 ? w[3] : w[1];
                     const float* v = vecs(w2, D, K);
-                    // reciprocal of the scale the producer packed the operand with: meta[3] (v columns) of qkv / meta[2] of fc1
-                    const float* ainv = fc2 ? vecs(w[2], 2 * D, D) + 8 * D + 2 : vecs(w[0], 3 * D, D) + 12 * D + 3;
-                    const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, ainv, nullptr, s.x, D, s.x, D, nullptr, s.stats,
+                    // the operand arrives under the producer's per-column static scales, which these weights were packed
+                    // against (mpl_pack_h2_scaled; h2_entry_kernel checks the fingerprints): nothing to take out here
+                    const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, nullptr, s.stats,
                                    s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
                     if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
@@ -1310,18 +1410,19 @@ static int launch_h2(const H2Args& a, hipStream_t s) {
 }
 
 // One GEMM as a launch of its own.  ln: A = fp32 rows X (ld = K) normalised with `stats`; else A = packed A2 whose scale
-// reciprocal sits at a_inv (device).  Outputs: C fp32 (optional) and / or C2 packed with the device scalar o_scale.
+// reciprocal sits at a_inv (device; NULL = the operand carries the per-column static scales W2 was packed against).
+// Outputs: C fp32 (optional) and / or C2 packed under the static scales of W2's own columns (its so vector).
 int launch_h2_gemm(const float* X, const unsigned short* A2, const float* a_inv, const unsigned short* W2, bool ln, const float* stats,
-                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, const float* o_scale, float* stats_out,
+                   float eps, const float* R, int ldr, float* C, int ldc, unsigned short* C2, float* stats_out,
                    int M, int N, int K, int rpt, int epi, hipStream_t s) {
     if (M <= 0 || !W2 || (!C && !C2) || !h2_shape_ok(N, K) || rpt <= 0 || rpt > BM) return MPL_E_INVALID;
     if (ln ? (!X || !stats || K > 1088) : !A2) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
     if (stats_out && epi != MPL_EPI_BIAS_RESIDUAL) return MPL_E_INVALID;
-    if (C2 && (N % (4 * BN) || !o_scale)) return MPL_E_INVALID;
+    if (C2 && (N % (4 * BN) || !ln || epi == MPL_EPI_BIAS_RESIDUAL)) return MPL_E_INVALID;     // static scales exist for LayerNorm GEMMs only
     const char* w2 = reinterpret_cast<const char*>(W2);
     const float* vec = reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
-    H2Args a{reinterpret_cast<const char*>(A2), X, K, w2, vec, vec + N, stats, a_inv, o_scale, R, ldr, C, ldc, reinterpret_cast<char*>(C2),
+    H2Args a{reinterpret_cast<const char*>(A2), X, K, w2, vec, vec + N, stats, a_inv, C2 ? vec + 4 * N : nullptr, R, ldr, C, ldc, reinterpret_cast<char*>(C2),
              stats_out, M, N, K, rpt, (M + rpt - 1) / rpt, N / BN, eps, 0, 0, g_h2_dbg.load(), nullptr, nullptr, 0};
     const bool pair = epi != MPL_EPI_BIAS_RESIDUAL && (a.grid_n & 1) == 0;     // by the SHAPE only (batch invariance)
     if (pair) a.grid_n /= 2;
@@ -1346,7 +1447,7 @@ int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const floa
     const int N = 3 * D, rpt = h2_rows_per_tile(n_tok);
     const char* w2 = reinterpret_cast<const char*>(W2);
     const float* vec = reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (D / BK) * H2_W);
-    H2Args a{nullptr, X, D, w2, vec, vec + N, stats, nullptr, vec + 4 * N + 1, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att2),
+    H2Args a{nullptr, X, D, w2, vec, vec + N, stats, nullptr, vec + 4 * N, nullptr, 0, nullptr, 0, reinterpret_cast<char*>(att2),
              nullptr, M, N, D, rpt, (M + rpt - 1) / rpt, D / BN, eps, n_tok, D / heads, g_h2_dbg.load(), nullptr, nullptr, 0};
     return launch_h2<H2_EPI_ATT, true, 3>(a, s);
 }
@@ -1392,13 +1493,14 @@ int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     a.err_ws = counters + a.n_tiles;
     a.err_host = device_error_word(dev);
     a.spin_log2 = g_h2_spin_log2.load();
-    a.inject = g_h2_inject.load();
+    a.inject = take_fault_injection();
     for (int i = 0; i < n_apps; ++i)
         for (int j = 0; j < 4; ++j) {
             if (!ops[4 * i + j]) return MPL_E_INVALID;
             a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
         }
-    // the library serialises ITS OWN persistent launches per device (see x3_gemm.hip launch_stack_np)
+    // the library serialises ITS OWN persistent launches per device (see x3_gemm.hip launch_stack_np); not under graph capture
+    if (int rc = refuse_stream_capture(s)) return rc;
     hipEvent_t ev = stack_chain_event(dev);
     if (!ev) return MPL_E_LAUNCH;
     std::lock_guard<std::mutex> g(stack_chain_mutex(dev));

@@ -18,9 +18,16 @@ constexpr int MACC = 12;
 __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                             const float* __restrict__ wgt, int B, int J, float sx, float sy,
                                                             float sz, float ox, float oy, float oz, unsigned skip_mask,
-                                                            float* __restrict__ res) {
+                                                            const unsigned* __restrict__ dev_err, float* __restrict__ res) {
     __shared__ double acc[MS][MJ][MACC];
     const int tid = threadIdx.x;
+    // A forward that lost a hand-off writes NaN poses, and nansum / nanmean semantics would score those as ZERO error: while
+    // the device's error word is set (the failing forward ran before this kernel on the stream) every result is NaN instead.
+    if (dev_err && __hip_atomic_load(dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        const int n = 4 + 2 * (J + 1) + 3 * J + 3;
+        for (int i = tid; i < n; i += 256) res[i] = __builtin_nanf("");
+        return;
+    }
     const int j = tid % MJ, s = tid / MJ;
     const float sc[3] = {sx, sy, sz}, of[3] = {ox, oy, oz};
     double a[MACC] = {};   // 0 loss, 1-3 |e| raw, 4 pjpe_abs, 5 pjpe_rel, 6-8 dist sum, 9-11 dist count
@@ -101,8 +108,10 @@ int launch_pose_metrics(const float* out, const float* tgt, const float* wgt, in
     if (!out || !tgt || !res || B <= 0 || J <= 0 || J > MJ) return MPL_E_INVALID;
     const float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
     const float ox = offset3 ? offset3[0] : 0.f, oy = offset3 ? offset3[1] : 0.f, oz = offset3 ? offset3[2] : 0.f;
+    int dev = 0;
+    const unsigned* dev_err = hipGetDevice(&dev) == hipSuccess ? device_error_word(dev) : nullptr;
     ProfScope prof(MPL_K_FUSE_HEAD, s);
-    hipLaunchKernelGGL(pose_metrics_kernel, dim3(1), dim3(256), 0, s, out, tgt, wgt, B, J, sx, sy, sz, ox, oy, oz, skip_mask, res);
+    hipLaunchKernelGGL(pose_metrics_kernel, dim3(1), dim3(256), 0, s, out, tgt, wgt, B, J, sx, sy, sz, ox, oy, oz, skip_mask, dev_err, res);
     return hip_check_launch();
 }
 

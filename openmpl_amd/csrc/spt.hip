@@ -654,6 +654,7 @@ int launch_spt_pack(const mpl_block_weights* bw_host, unsigned short* dst, int f
     if (!b || !dst || !b->qkv_w || !b->proj_w || !b->fc1_w || !b->fc2_w || !b->qkv_b || !b->proj_b || !b->fc1_b || !b->fc2_b ||
         !b->ln1_w || !b->ln1_b || !b->ln2_w || !b->ln2_b)
         return MPL_E_INVALID;
+    ProfScope prof(MPL_K_PACK, s);
     hipLaunchKernelGGL(spt_pack_kernel, dim3(1), dim3(256), 0, s, b->qkv_w, b->qkv_b, b->ln1_w, b->ln1_b, b->proj_w, b->proj_b, b->fc1_w,
                        b->fc1_b, b->ln2_w, b->ln2_b, b->fc2_w, b->fc2_b, reinterpret_cast<char*>(dst), fold_q);
     return hip_check_launch();

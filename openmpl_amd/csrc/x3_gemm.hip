@@ -206,6 +206,7 @@ int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const f
                         unsigned short* dst, int np, hipStream_t s) {
     if (!W || !dst || !bias || !x3_shape_ok(N, K) || ((ln_w != nullptr) != (ln_b != nullptr)) || (np != 1 && np != 3))
         return MPL_E_INVALID;
+    ProfScope prof(MPL_K_PACK, s);
     return np == 3 ? launch_pack<3>(W, N, K, ln_w, ln_b, bias, dst, s) : launch_pack<1>(W, N, K, ln_w, ln_b, bias, dst, s);
 }
 
@@ -319,11 +320,7 @@ static std::atomic<unsigned long long*> g_x3_dbg{nullptr};
 void x3_set_debug_buffer(unsigned long long* p) { g_x3_dbg.store(p); }
 // polls (s_sleep 2 + one L2 round trip each, ~1 us) before a wait of x3_stack_kernel counts as lost: 2^23 ~ 10 s
 static std::atomic<int> g_x3_spin_log2{23};
-static std::atomic<int> g_x3_inject{0};
-void x3_set_spin_log2(int v) {         // bits 0..7 the bound, bits 8.. the phase of the injected desertion (0 = none)
-    g_x3_spin_log2.store(v & 0xff);
-    g_x3_inject.store(v >> 8);
-}
+void x3_set_spin_log2(int v) { g_x3_spin_log2.store(v & 0xff); }
 
 enum { X3_EPI_BIAS = 0, X3_EPI_GELU = 1, X3_EPI_RES = 2, X3_EPI_ATT = 3 };
 
@@ -1383,6 +1380,7 @@ static int launch_stack_np(const X3StackArgs& a, int dev, hipStream_t s) {
     // stack launches per device: each one waits for the event recorded behind the previous one, whatever stream that was
     // on (a no-op on the same stream).  Other processes on the same GPU are not covered: single tenant;
     // a wait that runs out anyway is reported, never ignored (X3Args::err_*).
+    if (int rcc = refuse_stream_capture(s)) return rcc;     // the cross-stream event chain cannot be captured into a graph
     hipEvent_t ev = stack_chain_event(dev);
     if (!ev) return MPL_E_LAUNCH;
     std::lock_guard<std::mutex> g(stack_chain_mutex(dev));
@@ -1437,7 +1435,7 @@ int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     a.err_ws = counters + a.n_tiles;
     a.err_host = device_error_word(dev);
     a.spin_log2 = g_x3_spin_log2.load();
-    a.inject = g_x3_inject.load();
+    a.inject = take_fault_injection();       // one-shot test hook (mpl_x3_spin_limit)
     for (int i = 0; i < n_apps; ++i)
         for (int j = 0; j < 4; ++j) {
             if (!ops[4 * i + j]) return MPL_E_INVALID;

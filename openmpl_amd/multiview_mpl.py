@@ -221,6 +221,7 @@ class MultiView_MPL(nn.Module):
         self._unsupported = self._find_unsupported()
         self._hip_cache = {}
         self._dp_replica = False
+        self._dp_src = None
         self.matmul_precision = "fp32"
 
     # ------------------------------------------------------------------ support matrix
@@ -279,19 +280,14 @@ class MultiView_MPL(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _replicate_for_data_parallel(self):
-        """DataParallel replicas (valid_mpl.py:177-178) get fresh broadcast copies of every parameter on every forward,
-        so derived operand copies can never be reused: a replica re-packs the operands of the default engine on every
-        forward (cheap next to what the engine saves, see _marshal); the persistent one-process-per-GPU path
-        (openmpl_amd/dist.py) packs once."""
+        """DataParallel replicas (valid_mpl.py:177-178) are shallow copies that torch re-creates on EVERY forward with freshly
+        broadcast parameter storage.  The packed operands are derived from the parameter VALUES, which are the source module's:
+        a replica shares the source's per-device cache (the shallow copy of __dict__ already aliases the dict) and keys the
+        derived copies on the SOURCE parameters' storage + version, so a device packs once and every later forward only
+        rebuilds the small struct of addresses (_marshal).  Round 3 re-packed everything per forward (1.2 ms of GPU time)."""
         r = super()._replicate_for_data_parallel()
-        r._hip_cache = {}
         r._dp_replica = True
-        if self.matmul_precision == "bf16":
-            # a replica cannot honour the request (no packed bf16 operands): say so instead of silently running fp32
-            import warnings
-            warnings.warn("MultiView_MPL (HIP): DataParallel replicas run the fp32 matrix instructions; the requested "
-                          "matmul precision 'bf16' applies to the one-process-per-GPU path (openmpl_amd.dist) only",
-                          RuntimeWarning, stacklevel=2)
+        r._dp_src = self._dp_src if self._dp_replica else self
         return r
 
     # ------------------------------------------------------------------ C-ABI argument marshalling
@@ -347,33 +343,34 @@ class MultiView_MPL(nn.Module):
         out += [b for n, b in self.head.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
         return out
 
+    def _derived_key(self, h2, x3, bf16, spt3, d32):
+        """What the packed operands were built from: engine selection + storage and version of every SOURCE tensor they fold
+        (norm1 / norm2, weights and biases of each block).  A replica looks at the module it was replicated from."""
+        src = self._dp_src if self._dp_replica else self
+        ts = []
+        if h2 or x3 or bf16 or d32:
+            ts += [t for b in src.blocks for t in src._block_ptrs(b)]
+        if spt3:
+            stacks = src.Spatial_blocks if src.multiple_spatial_blocks else [src.Spatial_blocks]
+            ts += [t for st in stacks for b in st for t in src._block_ptrs(b)]
+        return (self.matmul_precision, h2, x3, bf16, spt3, d32) + tuple((t.data_ptr(), t._version) for t in ts)
+
     def _marshal(self, device: torch.device):
-        """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the
-        cache stays valid under in-place updates; it is rebuilt whenever any storage address changes."""
+        """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the struct stays valid
+        under in-place updates; it is rebuilt whenever any storage address changes.  The derived (packed) operands are kept
+        as long as the tensors they were built from keep their storage and version (_derived_key)."""
         plist = self._param_list()
-        key = tuple(map(torch.Tensor.data_ptr, plist))
-        bf16 = self.matmul_precision == "bf16" and not self._dp_replica and self._x3_supported()
-        x3 = self.matmul_precision == "fp32x3" and not self._dp_replica and self._x3_supported()
-        # DataParallel replicas get fresh parameter storage every forward, so their derived operands are rebuilt every
-        # forward: ~60 us of packing kernels for the default engine (114 MB read, 120 MB written) against a forward that is
-        # 2x faster than on the fp32 matrix instructions -- worth it for "fp32"; the 6 B / element operands of the older
-        # engines are not rebuilt per forward (replicas of those precisions run the native fp32 MFMA kernels)
+        bf16 = self.matmul_precision == "bf16" and self._x3_supported()
+        x3 = self.matmul_precision == "fp32x3" and self._x3_supported()
         h2 = self.matmul_precision == "fp32" and self._x3_supported()
         # the SPT Linear layers also run from split operands (fp32 arithmetic on the fp16 matrix cores) unless the native
-        # fp32 matrix instructions were asked for (or this is a replica of one of the older engines)
-        spt3 = self.matmul_precision != "fp32_mfma" and not (self._dp_replica and self.matmul_precision != "fp32") \
-            and not self.no_transformer_spt
-        if bf16 or x3 or h2:    # derived copies go stale on in-place updates too (the split operands fold norm1 / norm2 and the biases)
-            key = key + (self.matmul_precision,) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
+        # fp32 matrix instructions were asked for
+        spt3 = self.matmul_precision != "fp32_mfma" and not self.no_transformer_spt
         # keypoint-token FPT blocks (width 32 = the SPT block's shapes) run from the same kind of split operand (mpl_d32_pack)
-        d32 = self.matmul_precision == "fp32" and not self._dp_replica and self.FPT_blocks_view_keypoint_tokens \
+        d32 = self.matmul_precision == "fp32" and self.FPT_blocks_view_keypoint_tokens \
             and not self.no_transformer_fpt and len(self.blocks) > 0 and tuple(self.blocks[0].attn.qkv.weight.shape) == (96, 32)
-        if d32:
-            key = key + ("d32",) + tuple(t._version for b in self.blocks for t in self._block_ptrs(b))
-        if spt3:
-            stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
-            # every tensor of a block: the packed SPT operand folds norm1 / norm2 into the weights and the biases into c
-            key = key + ("spt3",) + tuple(t._version for st in stacks for b in st for t in self._block_ptrs(b))
+        dkey = self._derived_key(h2, x3, bf16, spt3, d32)
+        key = tuple(map(torch.Tensor.data_ptr, plist)) + dkey
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent
@@ -381,6 +378,13 @@ class MultiView_MPL(nn.Module):
             if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("MultiView_MPL (HIP): every parameter must be a contiguous float32 tensor on %s "
                                    "(found %s %s)" % (device, t.device, t.dtype))
+        lib = cabi.load()
+        st = torch.cuda.current_stream(device).cuda_stream
+        # derived operands of this device: reused when only addresses changed (every DataParallel forward), else rebuilt
+        derived = ent["derived"] if (ent is not None and ent["dkey"] == dkey) else None
+        fresh = derived is None
+        if fresh:
+            derived = dict(spt={}, fpt={}, d32={})
         n_sets = self.num_views if self.multiple_spatial_blocks else 1
         L = 0 if self.no_transformer_spt else self.depth
         # device blob: [n_sets x mpl_spt_set][n_sets x L x mpl_block_weights]
@@ -388,7 +392,6 @@ class MultiView_MPL(nn.Module):
         blob = torch.empty(n_sets * set_sz + max(1, n_sets * L) * blk_sz, dtype=torch.uint8, device=device)
         base = blob.data_ptr()
         sets = (cabi.SptSet * n_sets)()
-        spt_keep = []
         blks = (cabi.BlockWeights * max(1, n_sets * L))()
         for s in range(n_sets):
             multi = self.multiple_spatial_blocks
@@ -404,42 +407,35 @@ class MultiView_MPL(nn.Module):
                 for l, b in enumerate(stack):
                     bwl = cabi.BlockWeights(*[_ptr(t) for t in self._block_ptrs(b)])
                     if spt3:
-                        lib = cabi.load()
-                        pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
-                        cabi.check(lib.mpl_spt_pack(C.byref(bwl), pk.data_ptr(), torch.cuda.current_stream(device).cuda_stream),
-                                   "mpl_spt_pack")
-                        spt_keep.append(pk)
+                        pk = derived["spt"].get((s, l))
+                        if pk is None:
+                            pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
+                            cabi.check(lib.mpl_spt_pack(C.byref(bwl), pk.data_ptr(), st), "mpl_spt_pack")
+                            derived["spt"][(s, l)] = pk
                         bwl.qkv_w3 = pk.data_ptr()
                     blks[s * L + l] = bwl
         host = bytes(sets) + bytes(blks)
         blob.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
         fpt = (cabi.BlockWeights * max(1, len(self.blocks)))()
-        w16_keep = []
         for l, b in enumerate(self.blocks):
             ptrs = [_ptr(t) for t in self._block_ptrs(b)]
             if bf16 or x3 or h2:
-                lib = cabi.load()
-                nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else \
-                    ((lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3) if x3 else (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2))
+                ops = derived["fpt"].get(l)
+                if ops is None:
+                    ops = self._pack_block(lib, b, device, st, bf16, x3, h2)
+                    derived["fpt"][l] = ops
                 if x3:
                     ptrs += [0, 0, 0, 0]
                 if h2:
                     ptrs += [0] * 8
-                for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
-                    n, k = lin.weight.shape
-                    c3 = torch.empty(nbytes(n, k), dtype=torch.uint8, device=device)
-                    cabi.check(pack(lin.weight.data_ptr(), lin.bias.data_ptr(), _ptr(ln.weight if ln else None),
-                                    _ptr(ln.bias if ln else None), n, k, c3.data_ptr(),
-                                    torch.cuda.current_stream(device).cuda_stream), "pack operand")
-                    w16_keep.append(c3)
-                    ptrs.append(c3.data_ptr())
+                ptrs += [c3.data_ptr() for c3 in ops]
             fpt[l] = cabi.BlockWeights(*ptrs)
             if d32:
-                lib = cabi.load()
-                pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
-                cabi.check(lib.mpl_d32_pack(C.byref(fpt[l]), pk.data_ptr(), torch.cuda.current_stream(device).cuda_stream),
-                           "mpl_d32_pack")
-                w16_keep.append(pk)
+                pk = derived["d32"].get(l)
+                if pk is None:
+                    pk = torch.empty(lib.mpl_spt_pack_bytes(), dtype=torch.uint8, device=device)
+                    cabi.check(lib.mpl_d32_pack(C.byref(fpt[l]), pk.data_ptr(), st), "mpl_d32_pack")
+                    derived["d32"][l] = pk
                 fpt[l].qkv_w3 = pk.data_ptr()
         w = cabi.Weights()
         w.spt_sets = base
@@ -458,14 +454,38 @@ class MultiView_MPL(nn.Module):
         if not (self.deep_head or self.head_kadkhod):
             w.head_ln_w, w.head_ln_b = _ptr(self.head[0].weight), _ptr(self.head[0].bias)
             w.head_w, w.head_b = _ptr(self.head[1].weight), _ptr(self.head[1].bias)
-        ent = dict(key=key, weights=w, keep=(blob, fpt, sets, blks, w16_keep, spt_keep), cfg=self._config(), fpt_blocks=fpt)
+        new = dict(key=key, dkey=dkey, derived=derived, weights=w, keep=(blob, fpt, sets, blks), cfg=self._config(), fpt_blocks=fpt,
+                   packed_now=fresh)
         # the struct blob and the derived copies were enqueued on the stream current NOW: a later forward on another
         # stream must not read them before that work has finished
-        ent["ready"] = torch.cuda.Event()
-        ent["ready"].record(torch.cuda.current_stream(device))
-        ent["ready_stream"] = torch.cuda.current_stream(device).cuda_stream
-        self._hip_cache[device.index] = ent
-        return ent
+        new["ready"] = torch.cuda.Event()
+        new["ready"].record(torch.cuda.current_stream(device))
+        new["ready_stream"] = st
+        self._hip_cache[device.index] = new
+        return new
+
+    @staticmethod
+    def _pack_block(lib, b, device, st, bf16, x3, h2):
+        """The four packed Linear operands {qkv (norm1 folded), proj, fc1 (norm2 folded), fc2} of one FPT block."""
+        nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else \
+            ((lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3) if x3 else (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2))
+        ops = []
+        in_scale = 0        # h2: static scales (device vector) of the columns the NEXT plain Linear consumes
+        for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
+            n, k = lin.weight.shape
+            c3 = torch.empty(nbytes(n, k), dtype=torch.uint8, device=device)
+            if h2 and ln is None:
+                # proj / fc2: packed against the per-column static scales their producer (qkv's v columns / fc1) applies
+                cabi.check(lib.mpl_pack_h2_scaled(lin.weight.data_ptr(), lin.bias.data_ptr(), in_scale, n, k,
+                                                  c3.data_ptr(), st), "pack operand")
+            else:
+                cabi.check(pack(lin.weight.data_ptr(), lin.bias.data_ptr(), _ptr(ln.weight if ln else None),
+                                _ptr(ln.bias if ln else None), n, k, c3.data_ptr(), st), "pack operand")
+                if h2:
+                    so = lib.mpl_pack_h2_out_scale(c3.data_ptr(), n, k)
+                    in_scale = so + 4 * (n - k) if lin is b.attn.qkv else so      # qkv: the last third of the columns (v)
+            ops.append(c3)
+        return ops
 
     def _check_inputs(self, poses, rays, centers):
         if len(poses) != self.num_views:

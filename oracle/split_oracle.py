@@ -115,11 +115,13 @@ def six_product_matmul(A: np.ndarray, W: np.ndarray) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------------------------------
 # fp16x2 engine (openmpl_amd/csrc/h2_gemm.hip): two fp16 parts per operand under exact power-of-two scales, three
 # partial products.  Same k permutation, 2 parts instead of 3:
-#     W2[N/136][KT][9 slots][2 parts][64 lanes][8 fp16], then fp32 c[N], sc[N], sw[N], bound[N], meta[8]
+#     W2[N/136][KT][9 slots][2 parts][64 lanes][8 fp16], then fp32 c[N], sc[N], sw[N], bound[N], so[N], meta[8]
 #     sw_n = 2^(14 - e), max_k |gamma_k W_nk| = m 2^e with m in [0.5, 1)      (the scaled column maximum is in [2^13, 2^14))
 #     sc_n = 1 / (sa sw_n), sa = 1024 for an operand with LayerNorm folded in, else 1
 #     bound_n = sqrt(K) |gamma o W_n|_2 + |c_n|  (LayerNorm operands; 0 otherwise);
-#     meta = {scale(max bound), scale(max bound of the last third of the columns), their reciprocals, the two maxima, 0, 0},
+#     so_n = scale(bound_n): static scale of output column n as an operand of the next GEMM (round 4: per column; round 3 used
+#     one per layer); a consumer packed against them stores W_nk / so_k;
+#     meta = {scale(max bound), scale(max bound of the last third of the columns), their reciprocals, the two maxima, two fingerprints},
 #     scale(v) = largest power of two p with p v <= 2^15.
 H2_SA = 1024.0
 
@@ -143,11 +145,25 @@ def h2_window_scale(v: float) -> float:
     return float(np.ldexp(np.float32(1.0), int(min(120, max(-120, e - 1)))))
 
 
-def h2_trailer(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None):
-    """(c, sc, sw, bound, meta) fp32 arrays stored behind the fragments of an fp16x2 weight operand."""
+def _h2_factor(W, gamma, in_scale):
+    """Per-k factor folded into the weights before their column scale: the LayerNorm gain, or the reciprocal of the static scales
+    the A operand's columns arrive with (powers of two: exact)."""
+    W = np.asarray(W, dtype=np.float32)
+    if gamma is not None:
+        return (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    if in_scale is not None:
+        return (W * (np.float32(1.0) / np.asarray(in_scale, dtype=np.float32))[None, :]).astype(np.float32)
+    return W
+
+
+def h2_trailer(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None, in_scale: np.ndarray = None):
+    """(c, sc, sw, bound, so, meta) fp32 arrays stored behind the fragments of an fp16x2 weight operand.
+    so_n = scale(bound_n): the static scale of output column n when it travels on as a packed operand (LayerNorm operands; 1
+    otherwise).  meta[6], meta[7] = 0.5 + sum of the binary exponents of so over all columns / over the last third (LayerNorm
+    operands); meta[6] = the same over in_scale for a plain operand packed against one (0 without)."""
     W = np.asarray(W, dtype=np.float32)
     N, K = W.shape
-    Wg = W if gamma is None else (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    Wg = _h2_factor(W, gamma, in_scale)
     amax = np.abs(Wg).max(1)
     m, e = np.frexp(amax)
     sw = np.where(amax > 0, np.ldexp(np.float32(1.0), 14 - e), np.float32(1.0)).astype(np.float32)
@@ -160,22 +176,31 @@ def h2_trailer(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: 
     if gamma is not None:
         nrm = np.sqrt((Wg.astype(np.float64) ** 2).sum(1))
         bound = ((np.sqrt(np.float64(K)) * nrm).astype(np.float32) + np.abs(c)).astype(np.float32)
+        so = np.array([h2_window_scale(float(b)) for b in bound], dtype=np.float32)
     else:
         bound = np.zeros(N, dtype=np.float32)
+        so = np.ones(N, dtype=np.float32)
     ball = float(bound.max())
-    bv = float(bound[(3 * np.arange(N) >= 2 * N)].max())
+    last = 3 * np.arange(N) >= 2 * N
+    bv = float(bound[last].max())
     s_all, s_v = h2_window_scale(ball), h2_window_scale(bv)
-    meta = np.array([s_all, s_v, 1.0 / s_all, 1.0 / s_v, ball, bv, 0.0, 0.0], dtype=np.float32)
-    return c, sc, sw, bound, meta
+    ex = lambda v: float(np.frexp(np.asarray(v, dtype=np.float32))[1].astype(np.int64).sum() - np.asarray(v).size)   # ilogb = frexp exponent - 1
+    if gamma is not None:
+        f6, f7 = ex(so) + 0.5, ex(so[last]) + 0.5
+    else:
+        f6, f7 = (ex(in_scale) + 0.5 if in_scale is not None else 0.0), 0.0
+    meta = np.array([s_all, s_v, 1.0 / s_all, 1.0 / s_v, ball, bv, f6, f7], dtype=np.float32)
+    return c, sc, sw, bound, so, meta
 
 
-def h2_operand(W: np.ndarray, gamma: np.ndarray = None) -> np.ndarray:
-    """uint16 array [N/136][KT][9][2][64][8] of the fragment bytes mpl_pack_h2 must produce for W[N][K] (gamma folded)."""
+def h2_operand(W: np.ndarray, gamma: np.ndarray = None, in_scale: np.ndarray = None) -> np.ndarray:
+    """uint16 array [N/136][KT][9][2][64][8] of the fragment bytes mpl_pack_h2 (gamma folded) / mpl_pack_h2_scaled (W_nk /
+    in_scale_k) must produce for W[N][K]."""
     W = np.asarray(W, dtype=np.float32)
     N, K = W.shape
     assert N % 136 == 0 and K % 544 == 0
     Gn, KT = N // 136, K // 32
-    Wg = W if gamma is None else (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
+    Wg = _h2_factor(W, gamma, in_scale)
     amax = np.abs(Wg).max(1)
     m, e = np.frexp(amax)
     sw = np.where(amax > 0, np.ldexp(np.float32(1.0), 14 - e), np.float32(1.0)).astype(np.float32)

@@ -7,9 +7,13 @@ Here the whole FPT block stack is ONE launch whose workgroups hand operands to e
   * two forwards enqueued on two streams of one device are serialised by the library and both equal the serial result
     bit for bit;
   * unrelated work that occupies the CUs on another stream only delays the forward."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+os.environ.setdefault("MPL_FAULT_INJECT", "1")      # the injection hook of mpl_x3_spin_limit is inert unless the process opts in
 
 from openmpl_amd import cabi, detrng
 from openmpl_amd.multiview_mpl import MultiView_MPL

@@ -509,13 +509,15 @@ def test_native_fp32_mfma_path_matches_golden(name):
     with torch.no_grad():
         out = m(P, rays=R, centers=Cn)
     _assert_close(out, torch.from_numpy(g["out"]), name + " fp32_mfma")
-    assert not m._hip_cache[0]["keep"][4], "native path must not build split operands"
+    d = m._hip_cache[0]["derived"]
+    assert not d["fpt"] and not d["d32"] and not d["spt"], "native path must not build split operands"
     m.set_matmul_precision("fp32")
     with torch.no_grad():
         out3 = m(P, rays=R, centers=Cn)
     _assert_close(out3, torch.from_numpy(g["out"]), name + " fp32 (split operands where supported)")
     # packed FPT operands: the 544 / 1088-wide engines, or the D = 32 row-local kernels of the keypoint-token variant
-    assert bool(m._hip_cache[0]["keep"][4]) == (m._x3_supported() or bool(m.FPT_blocks_view_keypoint_tokens))
+    d = m._hip_cache[0]["derived"]
+    assert bool(d["fpt"] or d["d32"]) == (m._x3_supported() or bool(m.FPT_blocks_view_keypoint_tokens))
 
 
 def test_fp32_paths_agree_and_are_both_batch_invariant():
@@ -607,7 +609,7 @@ def test_spt_engines_agree_and_packs_are_used():
             m.set_matmul_precision(prec)
             ent = m._marshal(dev)
             assert bool(ent["weights"].spt_packed) == (prec == "fp32")
-            assert bool(ent["keep"][5]) == (prec == "fp32")
+            assert bool(ent["derived"]["spt"]) == (prec == "fp32")
             inp = cabi.Inputs()
             inp.batch = B
             for v in range(m.num_views):

@@ -44,7 +44,7 @@ def test_scales_are_exact_powers_of_two_and_keep_every_operand_in_the_window():
         b = rng.standard_normal(272).astype(np.float32)
         g = (rng.random(544) + 0.5).astype(np.float32)
         e = (rng.standard_normal(544) * 0.1).astype(np.float32)
-        c, sc, sw, bound, meta = so.h2_trailer(W, b, g, e)
+        c, sc, sw, bound, oscale, meta = so.h2_trailer(W, b, g, e)
         m, ex = np.frexp(sw)
         assert np.all(m == 0.5), "column scales must be powers of two"
         amax = np.abs(W * g[None, :]).max(1) * sw
@@ -58,6 +58,10 @@ def test_scales_are_exact_powers_of_two_and_keep_every_operand_in_the_window():
         z = z / np.sqrt((z ** 2).mean())                       # a LayerNorm output (gain 1, mean 0, variance 1)
         out = z @ Wg.T + c.astype(np.float64)
         assert np.all(np.abs(out) <= bound.astype(np.float64) * (1 + 1e-6))
+        # one static scale per output column: a power of two that brings the column's bound to the top of the fp16 window
+        mo, _ = np.frexp(oscale)
+        assert np.all(mo == 0.5) and np.all(oscale * bound <= 2.0 ** 15) and np.all(oscale * bound * 2 > 2.0 ** 15)
+        assert meta[6] == np.float32(np.log2(oscale.astype(np.float64)).sum() + 0.5)
         for k, rng_cols in ((0, slice(None)), (1, slice(2 * 272 // 3 + (1 if (2 * 272) % 3 else 0), None))):
             bm = float(bound[rng_cols].max())
             mm, _ = np.frexp(np.float32(meta[k]))
@@ -71,7 +75,7 @@ def test_fragment_layout_of_the_fp16x2_operand():
     gam = (rng.random(544) + 0.5).astype(np.float32)
     w2 = so.h2_operand(W, gam)
     assert w2.shape == (2, 17, 9, 2, 64, 8) and w2.nbytes == 2 * 17 * 18 * 1024
-    _, _, sw, _, _ = so.h2_trailer(W, np.zeros(272, np.float32), gam, np.zeros(544, np.float32))
+    _, _, sw, _, _, _ = so.h2_trailer(W, np.zeros(272, np.float32), gam, np.zeros(544, np.float32))
     hi, lo = so.split2(((W * gam[None, :]).astype(np.float32) * sw[:, None]).astype(np.float32))
     for g, kt, slot, lane, j in ((1, 6, 3, 37, 5), (0, 16, 4, 23, 2), (1, 16, 7, 60, 7), (0, 0, 0, 0, 0)):
         li, kq = lane & 15, lane >> 4
@@ -98,3 +102,49 @@ def test_normalised_layernorm_input_fits_the_fp16_window():
         mu, var = x.mean(1, keepdims=True), x.var(1, keepdims=True)
         z = (x - mu) / np.sqrt(var + 1e-6) * so.H2_SA
         assert np.abs(z).max() <= np.sqrt(K) * so.H2_SA * (1 + 1e-9) < 65504.0
+
+
+def test_per_column_static_scales_equilibrate_an_outlier_channel():
+    """The operand pair (A_k so_k, W_nk / so_k): one producer column 1e5 x the others (a huge v bias, one fc1 row far outside
+    the rest) must not cost the OTHER channels resolution.  With one scale per layer (round 3) the outlier set the fp16 window
+    of every column; per column the three-product sum stays at the accuracy of the benign case."""
+    rng = np.random.default_rng(7)
+    K, N, M = 544, 136, 64
+    bound = np.full(K, 14.0, np.float32)                       # sqrt(K) |gamma o W_k|_2 + |c_k| of ordinary producer columns
+    bound[37] = 3e6                                            # the outlier's bound
+    A = (rng.standard_normal((M, K)) * 0.6).astype(np.float32)  # typical activations sit sqrt(K) below their bound
+    A[:, 37] = 1e5
+    W = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)
+    W[:, 37] *= 1e-5                                           # the consumer's column for it keeps the output finite
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    so_k = np.array([so.h2_window_scale(float(b)) for b in bound], np.float32)
+
+    def three(a_scale, w_factor):
+        amax = np.abs(W * w_factor[None, :]).max(1)
+        _, e = np.frexp(amax)
+        sw = np.ldexp(np.float32(1.0), 14 - e).astype(np.float32)
+        ah, al = (t.astype(np.float64) for t in so.split2((A * a_scale[None, :]).astype(np.float32)))
+        wh, wl = (t.astype(np.float64) for t in so.split2((W * w_factor[None, :] * sw[:, None]).astype(np.float32)))
+        return (al @ wh.T + ah @ wl.T + ah @ wh.T) / sw.astype(np.float64)[None, :]
+
+    per_col = three(so_k, (np.float32(1.0) / so_k))
+    layer = np.float32(so.h2_window_scale(float(bound.max())))
+    per_layer = three(np.full(K, layer, np.float32), np.ones(K, np.float32)) / np.float64(layer)
+    scale = np.abs(ref).max()
+    e_col, e_layer = np.abs(per_col - ref).max() / scale, np.abs(per_layer - ref).max() / scale
+    assert e_col < 2e-7, e_col
+    assert e_layer > 10 * e_col, (e_layer, e_col)              # what the per-layer scale lost
+
+
+def test_consumer_operand_packed_against_input_scales():
+    rng = np.random.default_rng(8)
+    W = rng.standard_normal((136, 544)).astype(np.float32)
+    ins = np.ldexp(np.float32(1.0), rng.integers(-6, 12, 544)).astype(np.float32)
+    c, sc, sw, bound, oscale, meta = so.h2_trailer(W, np.zeros(136, np.float32), None, None, ins)
+    amax = np.abs(W / ins[None, :]).max(1) * sw
+    assert np.all(amax >= 2.0 ** 13) and np.all(amax < 2.0 ** 14) and np.all(oscale == 1.0) and np.all(bound == 0.0)
+    assert np.array_equal(sc, (np.float32(1.0) / sw).astype(np.float32))
+    assert meta[6] == np.float32(np.log2(ins.astype(np.float64)).sum() + 0.5) and meta[7] == 0.0
+    w2 = so.h2_operand(W, None, ins)
+    hi, _ = so.split2(((W / ins[None, :]).astype(np.float32) * sw[:, None]).astype(np.float32))
+    assert w2[0, 3, 2, 0, 21, 4] == so.f16_bits(hi[2 * 16 + 5:2 * 16 + 6, so.x3_col(3, 1, 4, 4):so.x3_col(3, 1, 4, 4) + 1])[0, 0]

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from openmpl_amd import cabi
+from openmpl_amd import cabi, detrng
 from oracle import mpl_oracle, split_oracle
 from tests.test_gpu_parity import DEV, _assert_close, _big_inputs, _fp64_linear, _model, _stream, _x3_linear
 
@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _h2_pack(lib, Wd, bd, gd, bed, N, K, ln):
     nbytes = lib.mpl_pack_h2_bytes(N, K)
-    assert nbytes == (N // 136) * (K // 32) * 18 * 1024 + (4 * N + 8) * 4
+    assert nbytes == (N // 136) * (K // 32) * 18 * 1024 + (5 * N + 8) * 4
     W2 = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
     cabi.check(lib.mpl_pack_h2(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None, bed.data_ptr() if ln else None,
                                N, K, W2.data_ptr(), _stream()), "mpl_pack_h2")
@@ -147,12 +147,35 @@ def test_h2_operand_bytes_match_the_definition():
         want = split_oracle.h2_operand(W.numpy(), gam.numpy() if ln else None).reshape(-1)
         assert got.shape == want.shape
         assert np.array_equal(got, want), "N=%d K=%d: %d of %d fp16 words differ" % (N, K, int((got != want).sum()), want.size)
-        c, sc, sw, bound, meta = split_oracle.h2_trailer(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
+        c, sc, sw, bound, oscale, meta = split_oracle.h2_trailer(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
         vec = raw[nfr:].view(np.float32)
         assert np.array_equal(vec[:N], c) and np.array_equal(vec[N:2 * N], sc) and np.array_equal(vec[2 * N:3 * N], sw)
         assert np.allclose(vec[3 * N:4 * N], bound, rtol=2e-6, atol=0)
+        # the static per-column scales: identical unless a bound sits within rounding of a power of two
+        assert (vec[4 * N:5 * N] != oscale).sum() <= 1 and np.all(np.frexp(vec[4 * N:5 * N])[0] == 0.5)
         if ln:
-            assert np.array_equal(vec[4 * N:4 * N + 4], meta[:4]), (vec[4 * N:4 * N + 8], meta)
+            assert np.array_equal(vec[5 * N:5 * N + 4], meta[:4]), (vec[5 * N:5 * N + 8], meta)
+            if np.array_equal(vec[4 * N:5 * N], oscale):
+                assert np.array_equal(vec[5 * N + 6:5 * N + 8], meta[6:8])
+            # a consumer of these columns (K2 = N inputs), packed against the scales: W / so, byte for byte, and the fingerprint
+            if N % 544 == 0:
+                N2 = 136
+                Wc = torch.randn(N2, N, generator=g) * N ** -0.5
+                bc = torch.randn(N2, generator=g)
+                so_dev = lib.mpl_pack_h2_out_scale(dst.data_ptr(), N, K)
+                assert so_dev == dst.data_ptr() + nfr + 4 * N * 4
+                dst2 = torch.zeros(lib.mpl_pack_h2_bytes(N2, N), dtype=torch.uint8, device=DEV)
+                cabi.check(lib.mpl_pack_h2_scaled(Wc.to(DEV).data_ptr(), bc.to(DEV).data_ptr(), so_dev, N2, N, dst2.data_ptr(), _stream()),
+                           "mpl_pack_h2_scaled")
+                torch.cuda.synchronize()
+                raw2 = dst2.cpu().numpy()
+                nfr2 = (N2 // 136) * (N // 32) * 18 * 1024
+                ins = vec[4 * N:5 * N].copy()
+                want2 = split_oracle.h2_operand(Wc.numpy(), None, ins).reshape(-1)
+                assert np.array_equal(raw2[:nfr2].view(np.uint16), want2)
+                t2 = split_oracle.h2_trailer(Wc.numpy(), bc.numpy(), None, None, ins)
+                vec2 = raw2[nfr2:].view(np.float32)
+                assert np.array_equal(vec2[N2:2 * N2], t2[1]) and vec2[5 * N2 + 6] == t2[5][6] == vec[5 * N + 6]
 
 
 def test_h2_shapes_are_validated():
@@ -209,44 +232,73 @@ def test_x3_engine_still_matches_goldens(name):
     _assert_close(out, torch.from_numpy(g["out"]), name + " fp32x3")
 
 
-def _replica(m):
-    """What torch.nn.parallel.replicate does for one device: shallow copies of every module (through the module's own
-    _replicate_for_data_parallel) whose parameters are plain tensors sharing the originals' storage."""
-    mods = list(m.modules())
-    copies = {mod: mod._replicate_for_data_parallel() for mod in mods}
-    for mod, rep in copies.items():
-        for k, child in mod._modules.items():
-            rep._modules[k] = copies[child] if child is not None else None
-        for k, p in mod._parameters.items():
-            rep._parameters[k] = None if p is None else p.detach()
-        for k, b in mod._buffers.items():
-            rep._buffers[k] = b
-    return copies[m]
+def _kinds(fn):
+    """Kernel launches of the library (by kind) while fn() runs."""
+    cabi.profile_start()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, {k: n for k, (ms, n) in cabi.profile_stop().items()}
 
 
-def test_data_parallel_replicas_run_the_default_engine():
-    """A DataParallel replica (torch re-creates them on every forward with fresh parameter storage, valid_mpl.py:177-178) packs its
-    own operands and runs the default engine -- not the slower fp32 matrix instructions it fell back to in round 2."""
+def test_data_parallel_replicas_pack_once_per_device():
+    """torch.nn.parallel.replicate (what DataParallel.forward does on every call, valid_mpl.py:177-178) hands each replica
+    fresh parameter tensors.  The replica shares the source module's per-device cache and keys the packed operands on the
+    SOURCE parameters' storage + version: the first forward on a device packs, every later one launches no packing kernel
+    (round 3 re-packed everything on every forward: 1.2 ms of GPU time), and an in-place update of a source parameter re-packs."""
+    from torch.nn.parallel import replicate
     m, g = _model("chosen_v4_b8_l2")
     P, R, Cn = _big_inputs(64, 4, 3)
     with torch.no_grad():
         want = m(P, rays=R, centers=Cn)
-        rep = _replica(m)
-        assert rep._dp_replica and rep._hip_cache == {}
-        got = rep(P, rays=R, centers=Cn)
-    assert torch.equal(got, want)
-    blk = rep._hip_cache[0]["fpt_blocks"][0]
-    assert bool(blk.qkv_h2) and rep._hip_cache[0]["weights"].spt_packed
-    m.set_matmul_precision("bf16")
-    with pytest.warns(RuntimeWarning, match="DataParallel replicas"):
-        rep = _replica(m)
-    with torch.no_grad():
-        out = rep(P, rays=R, centers=Cn)            # replicas of the older engines: native fp32 MFMA kernels
-    assert not rep._hip_cache[0]["keep"][4]
-    mx, nw = mpl_oracle.rel_errors(out.cpu(), want.cpu())
-    assert mx < 5e-6
-    m.set_matmul_precision("fp32")
+        rep = replicate(m, [0], detach=True)[0]
+        assert rep is not m and rep._dp_replica and rep._dp_src is m and rep._hip_cache is m._hip_cache
+        got, k1 = _kinds(lambda: rep(P, rays=R, centers=Cn))
+        assert torch.equal(got, want) and k1["pack"] == 0, k1          # same device, same storage: the source's operands serve
+        # what a second GPU sees: parameters in FRESH storage on every forward (cloned here, broadcast there)
+        def fresh_replica():
+            r = replicate(m, [0], detach=True)[0]
+            for mod in r.modules():                 # replicate() leaves the copies as plain tensor attributes (_former_parameters)
+                for k, p in list(mod._former_parameters.items()):
+                    setattr(mod, k, p.clone())
+            return r
+        outs = []
+        for it in range(3):
+            r = fresh_replica()
+            o, k = _kinds(lambda: r(P, rays=R, centers=Cn))
+            outs.append(o)
+            assert k["pack"] == 0, "forward %d of a replica packed operands again: %s" % (it, k)
+            assert k["gemm"] == 1 and k["spt"] == 1
+            blk = r._hip_cache[0]["fpt_blocks"][0]
+            assert bool(blk.qkv_h2) and r._hip_cache[0]["weights"].spt_packed
+        assert all(torch.equal(o, want) for o in outs)
+        # an optimiser step / load_state_dict on the SOURCE invalidates the derived operands of every replica
+        m.blocks[0].attn.proj.weight.mul_(1.5)
+        r = fresh_replica()
+        o, k = _kinds(lambda: r(P, rays=R, centers=Cn))
+        assert k["pack"] > 0 and not torch.equal(o, want)
+        assert torch.equal(o, m(P, rays=R, centers=Cn))
+        # replicas honour the other engines too (they fell back to the fp32 matrix instructions in round 3)
+        m.set_matmul_precision("bf16")
+        ob = m(P, rays=R, centers=Cn)
+        r = fresh_replica()
+        assert torch.equal(r(P, rays=R, centers=Cn), ob)
+        assert bool(r._hip_cache[0]["fpt_blocks"][0].qkv_w16)
+        m.set_matmul_precision("fp32")
 
+
+def test_data_parallel_module_end_to_end():
+    """nn.DataParallel over every visible GPU with CPU inputs (scatter does the H2D copy), twice: the second forward packs
+    nothing; the result is bitwise the direct one."""
+    m, g = _model("chosen_v4_b8_l2")
+    p, r, c = detrng.make_inputs(96, 4, seed=3)
+    P, R, Cn = ([torch.from_numpy(x) for x in lst] for lst in (p, r, c))
+    with torch.no_grad():
+        want = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn])
+        dp = torch.nn.DataParallel(m).eval()
+        first = dp(P, rays=R, centers=Cn)
+        second, k = _kinds(lambda: dp(P, rays=R, centers=Cn))
+    assert torch.equal(first, want) and torch.equal(second, want)
+    assert k["pack"] == 0, k
 
 
 def test_shipped_call_shape_b256_v2():
