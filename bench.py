@@ -270,6 +270,11 @@ def latest_profile(name):
 
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(a):
+    # rank 0 prints exactly ONE line on stdout, the JSON result: whatever native libraries write to file descriptor 1 meanwhile
+    # (RCCL prints its version banner there when a process group is created) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,7 +317,7 @@ def run_rank(a):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
 
 
 def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used_dist):
@@ -462,7 +467,9 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     mx, nw = mpl_oracle.rel_errors(got, ref)
     parity = dict(max_scaled=float("%.3e" % mx), norm_wise=float("%.3e" % nw),
                   mpjpe_vs_ref=float("%.3e" % mpl_oracle.mpjpe(got, ref)), poses=nb,
-                  tol=None if a.precision == "bf16" else 1e-4)     # bf16: the deviation is reported, not gated
+                  tol=None if a.precision == "bf16" else 1e-4,     # bf16: the deviation is reported, not gated
+                  note="a bounded in-run check (%d poses against the fp32 oracle); the full-size checks (B = 1024 / 8192 against the "
+                       "fp64 oracle, every golden) are tests/test_gpu_parity.py, `pytest -m gpu`" % nb)
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N = 1 only)
     cpu_base = None
@@ -493,8 +500,18 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                         others=others)
 
     extra = {}
+    if world == 1 and not used_dist:
+        # the headline is ONE region of `steps` forwards (26 ms of GPU time at the defaults); the same region repeated gives the
+        # number a distribution, and >= 1 s of GPU-busy time behind it
+        reps = 25
+        ms = sorted(timed_steps(model, batches, a.steps, 0) / a.steps * 1e3 for _ in range(reps))
+        extra["repeat_ms_per_step"] = dict(regions=reps, steps_per_region=a.steps, median=round(ms[reps // 2], 4), min=round(ms[0], 4),
+                                           max=round(ms[-1], 4), p10=round(ms[reps // 10], 4), p90=round(ms[reps - 1 - reps // 10], 4),
+                                           median_poses_per_s=round(a.batch / ms[reps // 2] * 1e3, 1))
     if not a.no_extra and world == 1 and a.flagset == "chosen":
-        extra = extras(a, model, flags, batches, dev, sd, got, ref, nb)
+        extra.update(extras(a, model, flags, batches, dev, sd, got, ref, nb))
+        if not used_dist:
+            extra.update(dist_and_dp_extras(a, model, batches, dev))
 
     return {
         "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) %s" % (a.views, a.batch, "bf16" if a.precision == "bf16" else "fp32"),
@@ -653,7 +670,57 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
         extra[tag + "_poses_per_s"] = round(v5, 1)
         extra[tag + "_tflops"] = round(v5 * mpl_oracle.flop_count(f5) / 1e12, 1)
         del m5
+    # the non-default tails at the reference's default width (TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM = 1024, config.py:98):
+    # step time relative to the default head on the same batches
+    heads = {}
+    base = timed_steps(model, batches, n_o, 3) / n_o * 1e3
+    for tag, fl in (("deep_head", dict(deep_head=True, hidden_dim=1024)), ("head_kadkhod", dict(head_kadkhod=True, hidden_dim=1024)),
+                    ("linear_weighted_mean", dict(linear_weighted_mean=True))):
+        mh = build_model(model_flags("chosen", a.views, a.depth, **fl), dev)
+        t = timed_steps(mh, batches, n_o, 3) / n_o * 1e3
+        heads[tag] = dict(ms_per_step=round(t, 4), vs_default_head=round(t / base, 3))
+        del mh
+    heads["default_head_ms_per_step"] = round(base, 4)
+    extra["heads_hidden_dim_1024"] = heads
     return extra
+
+
+def dist_and_dp_extras(a, model, batches, dev):
+    """The two multi-GPU mechanisms on ONE GPU: the rank path (process group of one rank, the RCCL all-gather issued every
+    step: what --force-dist measures) and the reference's own torch.nn.DataParallel wrapper (valid_mpl.py:177-178) fed CPU
+    tensors, over device 0 alone and over every visible GPU."""
+    import torch
+    import torch.distributed as dist
+    from openmpl_amd.dist import ShardedLifter
+    out = {}
+    n = max(10, a.steps)
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        lifter = ShardedLifter(model)
+        out["force_dist_poses_per_s"] = round(a.batch * n / timed_steps(model, batches, n, 3, lifter, a.batch), 1)
+        dist.destroy_process_group()
+    except Exception as e:            # a box without a working RCCL: say so, the headline does not depend on it
+        out["force_dist_poses_per_s"] = "failed: %r" % (e,)
+    host = [tuple([t.cpu() for t in lst] for lst in b) for b in batches[:2]]
+    ids = {"device0": [0], "all_visible_gpus": list(range(torch.cuda.device_count()))}
+    dp_out = {}
+    for tag, dev_ids in ids.items():
+        dp = torch.nn.DataParallel(model, device_ids=dev_ids).eval()
+        with torch.no_grad():
+            for i in range(3):
+                dp(host[i % 2][0], rays=host[i % 2][1], centers=host[i % 2][2])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                dp(host[i % 2][0], rays=host[i % 2][1], centers=host[i % 2][2])
+            torch.cuda.synchronize()
+        dp_out[tag] = dict(gpus=len(dev_ids), poses_per_s=round(a.batch * n / (time.perf_counter() - t0), 1))
+    dp_out["note"] = ("torch.nn.DataParallel(model) called with CPU tensors as validate() does (function_mpl.py:350): scatter copies "
+                      "the inputs, replicas share the per-device packed operands (packed once, not per forward)")
+    out["data_parallel"] = dp_out
+    return out
 
 
 def main():

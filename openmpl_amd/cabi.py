@@ -236,3 +236,16 @@ def device_error(device: int = -1) -> bool:
 
 def clear_device_error(device: int = -1):
     check(load().mpl_device_error_clear(device), "mpl_device_error_clear")
+
+
+def raise_if_device_error(device: int = -1, synchronize: bool = False):
+    """Surface a lost hand-off WITH the results it poisoned.  The forward is asynchronous: the call that produced NaN poses
+    has long returned when its kernel reports the failure, and without this check the error would only show on the NEXT
+    call into the library -- never, if the failing batch was the last one.  Call it wherever outputs are consumed on the host
+    (GatherHandle.wait() and pose_metrics() do; a validate() loop should after its final batch, with synchronize=True, which
+    waits for the device first so that a failure of work still in flight is seen too)."""
+    if synchronize:
+        import torch
+        torch.cuda.synchronize(None if device < 0 else device)
+    if device_error(device):
+        check(-5, "a forward on this device")

@@ -430,9 +430,10 @@ const char* mpl_hip_error_string(int code) {
         case MPL_E_WORKSPACE: return "workspace missing or too small";
         case MPL_E_LAUNCH: return "HIP runtime error at kernel launch";
         case MPL_E_DEVICE:
-            return "an earlier forward on this device lost a hand-off between the workgroups of its persistent kernel (its "
-                   "poses are NaN): the GPU was shared with other work for longer than the wait bound; clear with "
-                   "mpl_device_error_clear()";
+            return "an earlier forward on this device lost a hand-off between the workgroups of its persistent kernel, or was "
+                   "handed proj / fc2 operands that were not packed against their producers' scales (its poses are NaN): the "
+                   "GPU was shared with other work for longer than the wait bound, or mpl_pack_h2_scaled was skipped; clear "
+                   "with mpl_device_error_clear()";
         default: return "unknown error";
     }
 }

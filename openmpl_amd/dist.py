@@ -75,6 +75,11 @@ class GatherHandle:
             self._work.wait()
             self._work = None
         self._keep = None
+        if self._buf.is_cuda:
+            # a forward of this device that lost a hand-off produced NaN poses: raise here, with the batch it poisoned, not
+            # on whatever call happens to come next (openmpl_amd.cabi.raise_if_device_error)
+            from . import cabi
+            cabi.raise_if_device_error(self._buf.device.index)
         buf, batch, world = self._buf, self._batch, self._world
         if batch % world == 0:
             return buf

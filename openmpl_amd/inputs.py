@@ -53,14 +53,18 @@ def prepare_inputs(joints_px: torch.Tensor, conf: Optional[torch.Tensor], cams: 
 
 class HostStager:
     """One pinned staging buffer + ONE host-to-device copy per batch for callers that hold the inputs on the host (the
-    loop of validate(), function_mpl.py:334-351, hands `model(input, centers=, rays=)` CPU tensors): the V x {(B,J,3) poses,
-    (B,J,3) rays, (B,1,3) centers} are packed back to back into pinned memory and cross PCIe as one transfer instead of
-    3V small ones; the returned lists are views into one device buffer (layouts exactly those the model expects)."""
+    loop of validate(), function_mpl.py:334-351, hands `model(input, centers=, rays=)` CPU tensors): the V x {(b,J,3) poses,
+    (b,J,3) rays, (b,1,3) centers} are packed back to back into pinned memory and cross PCIe as one transfer instead of
+    3V small ones; the returned lists are views into one device buffer (layouts exactly those the model expects).
+
+    `batch` is the LARGEST batch: a shorter one (the ragged last batch of a loader without drop_last) is staged into a
+    prefix.  The returned views ALIAS the stager's device buffer, which the next stage() overwrites: consume them on the
+    stream that was current when stage() ran (the copy is enqueued there, so a forward launched on it afterwards is ordered
+    behind the copy and ahead of the next one), or use two stagers alternately as bench.py does."""
 
     def __init__(self, batch: int, views: int, joints: int, device):
         self.shape = (batch, views, joints)
-        self.sizes = [batch * joints * 3, batch * joints * 3, batch * 3]
-        n = views * sum(self.sizes)
+        n = views * batch * (2 * joints * 3 + 3)
         self.host = torch.empty(n, dtype=torch.float32).pin_memory()
         self.dev = torch.empty(n, dtype=torch.float32, device=device)
         self._copied = None          # event behind the last host-to-device copy out of self.host
@@ -69,16 +73,19 @@ class HostStager:
         B, V, J = self.shape
         if self._copied is not None:
             self._copied.synchronize()      # the previous transfer has read the pinned buffer before it is overwritten
-        if len(poses) != V or poses[0].shape[0] != B:
-            raise RuntimeError("HostStager was built for %d views of batch %d" % (V, B))
+        b = poses[0].shape[0] if len(poses) else 0
+        if len(poses) != V or len(rays) != V or len(centers) != V or not 0 < b <= B:
+            raise RuntimeError("HostStager was built for %d views of at most %d poses" % (V, B))
         off, views = 0, ([], [], [])
-        for k, (lst, n, shp) in enumerate(((poses, self.sizes[0], (B, J, 3)), (rays, self.sizes[1], (B, J, 3)),
-                                           (centers, self.sizes[2], (B, 1, 3)))):
+        for k, (lst, shp) in enumerate(((poses, (b, J, 3)), (rays, (b, J, 3)), (centers, (b, 1, 3)))):
+            n = shp[0] * shp[1] * shp[2]
             for t in lst:
+                if tuple(t.shape) != shp:
+                    raise RuntimeError("HostStager: expected a tensor of shape %s, got %s" % (shp, tuple(t.shape)))
                 self.host[off:off + n].view(shp).copy_(t)
                 views[k].append(self.dev[off:off + n].view(shp))
                 off += n
-        self.dev.copy_(self.host, non_blocking=True)
+        self.dev[:off].copy_(self.host[:off], non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record(torch.cuda.current_stream(self.dev.device))
         return views

@@ -44,6 +44,10 @@ def pose_metrics(output: torch.Tensor, target: torch.Tensor, weight: Optional[to
         rc = lib.mpl_pose_metrics_ex(output.data_ptr(), target.data_ptr(), None if weight is None else weight.data_ptr(), B, J,
                                      sc, of, mask, res.data_ptr(), torch.cuda.current_stream().cuda_stream)
     cabi.check(rc, "mpl_pose_metrics")
+    # NaN poses of a forward that lost a hand-off would be SKIPPED by the nansum / nanmean semantics of the reference's metrics
+    # and score as zero error: the C entry refuses while the device's error word is set, the kernel writes NaN results when
+    # the failing forward is still in flight on this stream, and a failure that has already been reported raises here
+    cabi.raise_if_device_error(output.device.index)
     o = 4
     return dict(loss=res[0], loss_axis=res[1:4], pjpe_abs=res[o:o + J], mpjpe_abs=res[o + J],
                 pjpe_rel=res[o + J + 1:o + 2 * J + 1], mpjpe_rel=res[o + 2 * J + 1],

@@ -50,6 +50,10 @@ CASES = [
     _c("linear_wmean_v3_b3_l2", dict(CHOSEN, linear_weighted_mean=True), 3, 3, 2),
     _c("deep_head_v3_b3_l2", dict(CHOSEN, deep_head=True, hidden_dim=64), 3, 3, 2),
     _c("kadkhod_v3_b3_l2", dict(CHOSEN, head_kadkhod=True, hidden_dim=64), 3, 3, 2),
+    # the same heads at the reference's default width, TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM = 1024 (config.py:98)
+    _c("deep_head_h1024_v3_b5_l2", dict(CHOSEN, deep_head=True, hidden_dim=1024), 3, 5, 2),
+    _c("kadkhod_h1024_v3_b5_l2", dict(CHOSEN, head_kadkhod=True, hidden_dim=1024), 3, 5, 2),
+    _c("linear_wmean_v4_b5_l2", dict(CHOSEN, linear_weighted_mean=True), 4, 5, 2),
     _c("geo3d_v3_b3_l2", dict(pose_3d_emb_learnable=False), 3, 3, 2),
     _c("inspatial_learn_v3_b3_l2", dict(pose_3d_emb_learnable=True, add_3D_pos_encoding_in_Spatial=True), 3, 3, 2),
     _c("inspatial_geo_v3_b3_l2", dict(pose_3d_emb_learnable=False, add_3D_pos_encoding_in_Spatial=True), 3, 3, 2),

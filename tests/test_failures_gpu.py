@@ -111,3 +111,64 @@ def test_foreign_work_on_another_stream_only_delays_the_forward():
     for g in got:
         assert torch.equal(g, want)
     assert torch.isfinite(a).all() or True
+
+
+def test_mismatched_operand_scales_poison_the_call_and_the_metrics():
+    """proj / fc2 operands must be packed against the static scales their producers apply (mpl_pack_h2_scaled); an operand
+    packed without them is detected on the device (fingerprints, h2_entry_kernel): NaN poses + the device error, never poses
+    under the wrong scales.  And the metrics refuse a poisoned device: NaN poses would otherwise be skipped by the nansum
+    semantics of calc_mpjpe (evaluate.py:91-114) and score as zero error."""
+    import openmpl_amd
+    from openmpl_amd.metrics import pose_metrics
+    lib = cabi.load()
+    m = _model()
+    P, R, C = _inputs(64, 5)
+    tgt = torch.randn(64, 17, 3, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    with torch.no_grad():
+        good = m(P, rays=R, centers=C)
+        ok = pose_metrics(good, tgt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ok["mpjpe_abs"])
+        proj = m.blocks[0].attn.proj
+        op = m._hip_cache[0]["derived"]["fpt"][0][1]
+        cabi.check(lib.mpl_pack_h2(proj.weight.data_ptr(), proj.bias.data_ptr(), None, None, 544, 544, op.data_ptr(), st), "mpl_pack_h2")
+        bad = m(P, rays=R, centers=C)
+        try:
+            res = pose_metrics(bad, tgt)             # enqueued behind the failing forward: the KERNEL sees the error word
+            torch.cuda.synchronize()
+            assert torch.isnan(res["mpjpe_abs"]) and torch.isnan(res["loss"]), "a poisoned batch must not score"
+        except RuntimeError:
+            pass                                     # the failure had already reached the host: the call itself refused
+        torch.cuda.synchronize()
+        assert torch.isnan(bad).all() and cabi.device_error()
+        with pytest.raises(RuntimeError):
+            pose_metrics(bad, tgt)
+        with pytest.raises(RuntimeError):
+            openmpl_amd.check_device()
+        cabi.clear_device_error()
+        m.set_matmul_precision("fp32")               # drops the cache: the operands are packed again, correctly
+        again = m(P, rays=R, centers=C)
+        openmpl_amd.check_device()
+    assert torch.equal(again, good)
+
+
+def test_fault_injection_is_one_shot():
+    """The injected desertion is consumed by the first persistent launch: a test that dies between set and reset cannot leave
+    the process poisoned."""
+    lib = cabi.load()
+    m = _model()
+    P, R, C = _inputs(64, 6)
+    with torch.no_grad():
+        good = m(P, rays=R, centers=C)
+        cabi.check(lib.mpl_x3_spin_limit(10 | (1 << 8)), "spin limit")
+        try:
+            bad = m(P, rays=R, centers=C)
+            torch.cuda.synchronize()
+            assert torch.isnan(bad).all()
+            cabi.clear_device_error()
+            again = m(P, rays=R, centers=C)          # no reset of the hook in between
+            torch.cuda.synchronize()
+        finally:
+            cabi.check(lib.mpl_x3_spin_limit(23), "spin limit")
+    assert torch.equal(again, good) and not cabi.device_error()

@@ -221,6 +221,34 @@ def test_full_size_batch_against_oracle(name, B):
     _assert_close(out, ref32, name + " vs fp32 oracle")
 
 
+@pytest.mark.parametrize("name", ["deep_head_h1024_v3_b5_l2", "kadkhod_h1024_v3_b5_l2", "linear_wmean_v4_b5_l2"])
+def test_wide_heads_full_batch_against_oracle(name):
+    """The non-default heads at the reference's default width (TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM = 1024, config.py:98;
+    multiview_mpl.py:287-317, :506-519) and linear_weighted_mean (:441-443) at batch 1024 against the fp64 oracle: their Linear
+    layers run as exact fp32 on the matrix cores (heads.hip linear_mfma_kernel), ragged K = 51 + 544 concat inputs included."""
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    B = 1024
+    p, r, c = detrng.make_inputs(B, V, seed=31)
+    P, R, Cn = ([torch.from_numpy(x) for x in lst] for lst in (p, r, c))
+    with torch.no_grad():
+        out = m([x.to(DEV) for x in P], rays=[x.to(DEV) for x in R], centers=[x.to(DEV) for x in Cn])
+    sd = golden_state_dict(name, g)
+    ref = mpl_oracle.forward(sd, g["flags"], P, R, Cn, dtype=torch.float64)
+    if isinstance(out, tuple):
+        out, inter = out
+        ref, rinter = ref
+        for a_, b_ in zip(inter, rinter):
+            _assert_close(a_, b_, name + " intermediate")
+    mx, nw = _assert_close(out, ref, name + " B=1024 vs fp64 oracle")
+    print("%s B=1024: %.2e / %.2e" % (name, mx, nw))
+    # ragged batch: tiles of 64 rows with a tail
+    with torch.no_grad():
+        part = m([x[:77].to(DEV) for x in P], rays=[x[:77].to(DEV) for x in R], centers=[x[:77].to(DEV) for x in Cn])
+    part = part[0] if isinstance(part, tuple) else part
+    assert torch.equal(part, out[:77]), "head results depend on the batch size"
+
+
 # ----------------------------------------------------------------------------- size-independent properties
 def _big_inputs(B, V, seed):
     p, r, c = detrng.make_inputs(B, V, seed=seed)

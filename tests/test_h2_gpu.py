@@ -165,7 +165,8 @@ def test_h2_operand_bytes_match_the_definition():
                 so_dev = lib.mpl_pack_h2_out_scale(dst.data_ptr(), N, K)
                 assert so_dev == dst.data_ptr() + nfr + 4 * N * 4
                 dst2 = torch.zeros(lib.mpl_pack_h2_bytes(N2, N), dtype=torch.uint8, device=DEV)
-                cabi.check(lib.mpl_pack_h2_scaled(Wc.to(DEV).data_ptr(), bc.to(DEV).data_ptr(), so_dev, N2, N, dst2.data_ptr(), _stream()),
+                Wcd, bcd = Wc.to(DEV), bc.to(DEV)
+                cabi.check(lib.mpl_pack_h2_scaled(Wcd.data_ptr(), bcd.data_ptr(), so_dev, N2, N, dst2.data_ptr(), _stream()),
                            "mpl_pack_h2_scaled")
                 torch.cuda.synchronize()
                 raw2 = dst2.cpu().numpy()

@@ -64,3 +64,31 @@ def test_prepared_inputs_feed_the_model_and_loud_errors():
     assert mx < 1e-4 and nw < 1e-4
     with pytest.raises(RuntimeError, match="no CPU path"):
         prepare_inputs(torch.from_numpy(g["px"]), None, cams, (w, h))
+
+
+@pytest.mark.gpu
+def test_host_stager_reuse_and_short_last_batch():
+    """HostStager (validate()'s host-tensor call shape, function_mpl.py:334-351): one pinned buffer + one copy per batch, reused
+    across batches, a ragged last batch staged into a prefix; the forward on the staged views equals the forward on plain
+    device copies bit for bit."""
+    from openmpl_amd import detrng
+    from openmpl_amd.inputs import HostStager
+    from openmpl_amd.multiview_mpl import MultiView_MPL
+    dev = torch.device("cuda:0")
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=2, num_views=4, pose_3d_emb_learnable=True)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=4)
+    m = m.to(dev).eval()
+    st = HostStager(48, 4, 17, dev)
+    for B, seed in ((48, 1), (48, 2), (7, 3), (48, 4)):
+        p, r, c = detrng.make_inputs(B, 4, seed=seed)
+        P, R, Cn = ([torch.from_numpy(x) for x in lst] for lst in (p, r, c))
+        with torch.no_grad():
+            Pv, Rv, Cv = st.stage(P, R, Cn)
+            assert Pv[0].shape == (B, 17, 3) and Cv[3].shape == (B, 1, 3) and Pv[0].device == dev
+            got = m(Pv, rays=Rv, centers=Cv)
+            want = m([x.to(dev) for x in P], rays=[x.to(dev) for x in R], centers=[x.to(dev) for x in Cn])
+        assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        big = detrng.make_inputs(49, 4, seed=5)
+        st.stage(*([torch.from_numpy(x) for x in lst] for lst in big))
