@@ -561,6 +561,7 @@ int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const 
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);
+    h2_set_row_tiles((one_launch_per_gemm >> 1) & 3);      // bits 1, 2: 0 = by shape, 1 / 2 = force the one- / two-tile stage
     return MPL_OK;
 }
 

@@ -157,6 +157,7 @@ int take_fault_injection();
 int refuse_stream_capture(hipStream_t s);
 void x3_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
 void h2_set_spin_log2(int log2_polls);
+void h2_set_row_tiles(int rt);             // A/B switch of the block stack: 0 by shape, 1 / 2 row tiles per stage
 // The persistent block-stack kernels (x3_stack_kernel, h2_stack_kernel) need every workgroup resident: the library
 // serialises its own launches of them per device, whatever stream they are on -- each launch waits for the event recorded
 // behind the previous one (api.hip).  The event exists from the first call (waiting on a never-recorded event is a no-op).

@@ -89,6 +89,9 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #ifndef H2_WSPLIT
 #define H2_WSPLIT 1    // W pieces per stage and wave: 0 = 1 (waves 0..3) / 4 (waves 4, 5) / 3 (waves 6, 7); 1 = 2 / 3 / 2
 #endif
+#define H2_R2_WC0 1      // W pieces per wave role of the two-tile stage (the waves 0..3 carry four A pieces)
+#define H2_R2_WC1 4
+#define H2_R2_WC2 3
 #define H2_WC0 (H2_WSPLIT == 1 ? 2 : 1)
 #define H2_WC1 (H2_WSPLIT == 1 ? 3 : 4)
 #define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
@@ -113,7 +116,8 @@ size_t h2_operand_bytes(int N, int K) {
 }
 size_t h2_act_bytes(int M, int K, int rpt) {
     if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
-    const size_t tiles = ((size_t)M + rpt - 1) / rpt;
+    // an even number of row tiles: the two-tile stage (h2_stack2_kernel) requests the strips of a pair, also of an absent partner
+    const size_t tiles = ((((size_t)M + rpt - 1) / rpt) + 1) / 2 * 2;
     return tiles * 4 * (K / BK) * H2_RG;
 }
 int h2_rows_per_tile(int n_tok) { return (n_tok >= 1 && n_tok <= BM) ? (BM / n_tok) * n_tok : 0; }
@@ -448,6 +452,8 @@ struct H2Args {
 static std::atomic<unsigned long long*> g_h2_dbg{nullptr};
 void h2_set_debug_buffer(unsigned long long* p) { g_h2_dbg.store(p); }
 static std::atomic<int> g_h2_spin_log2{23};
+static std::atomic<int> g_h2_rt{0};          // 0: by shape; 1 / 2: force the one- / two-tile stage (A/B switch)
+void h2_set_row_tiles(int rt) { g_h2_rt.store(rt); }
 void h2_set_spin_log2(int v) { g_h2_spin_log2.store(v & 0xff); }
 
 enum { H2_EPI_BIAS = 0, H2_EPI_GELU = 1, H2_EPI_RES = 2, H2_EPI_ATT = 3 };
@@ -564,25 +570,37 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
 // workgroup arrives when its outputs are written.  Returns false when the wait timed out (error words set, nothing computed).
 // WC = W pieces this wave requests per stage (2 for the waves 0..3, 3 for the waves 4, 5, 2 for the waves 6, 7): a template
 // parameter, so that neither the requests nor the counted waits need a branch in the k loop.
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC>
+// RT = row tiles per workgroup.  RT = 2 (h2_stack2_kernel: teams that own two or more row tiles): the stage carries the A
+// pieces of TWO row tiles (8 row groups, 16 KiB) against the same 18 KiB of W -- 34 KiB for 54 MFMAs per SIMD instead of 26 KiB
+// for 27, the W fragments are read from LDS once for both tiles -- in a ring of 4 with one barrier per stage (a stage is as long
+// as two of the RT = 1 stages, so that IS the two-stage barrier period).  `tm` then counts pairs of row tiles.  The arithmetic of
+// every output element is the same in both forms (same k order, same product order per accumulator, same epilogue).
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
-                                         unsigned* chain, unsigned chain_need) {
-    constexpr int NST = H2_NST;
+                                         unsigned* chain, unsigned chain_need, bool arrive = true) {
+    constexpr int ABYTES = RT * 4 * H2_RG;       // A bytes per stage
+    constexpr int STAGE = ABYTES + H2_W;
+    constexpr int NST = RT == 1 ? H2_NST : 4;
+    constexpr int APW = 2 * RT;                  // A pieces a wave 0..3 requests per A stage
+    static_assert(NST * STAGE <= H2_VEC, "ring too large");
+    static_assert(RT == 1 || (RT == 2 && EPI != H2_EPI_ATT && NPASS <= 2 && CHAIN), "two row tiles per stage: proj / fc1 / fc2 of a stack");
     // P2: one barrier per TWO stages.  At the barrier in front of an even stage e every wave has its pieces of the stages
     // <= e + 2 landed and has finished reading the fragments of the stages <= e, so stage e may refill the slot of stage e - 1
     // and stage e + 1 the slot of stage e: a refill goes DIST = NST - 1 stages ahead.  Nothing but the DMA landing has to be
     // published: the LayerNorm operand stays RAW in LDS and every wave that multiplies it normalises + splits its lane's eight
     // values in registers (both waves of a row group do the same arithmetic; the in-place conversion by the requesting wave
     // that this replaced needed every barrier and made the waves 0..3 the slow half of the stage).
-    constexpr bool P2 = H2_KPS2 != 0;
+    constexpr bool P2 = H2_KPS2 != 0 && RT == 1;
     constexpr int DIST = P2 ? NST - 1 : NST;
-    constexpr bool HAS_A = NTW == H2_T0;         // waves 0..3 (slots 0..4) bring the A pieces
+    constexpr bool LEAD = NTW == H2_T0;          // waves 0..3 (slots 0..4): multiply first, load afterwards; bring the epilogue vectors
+    constexpr bool HAS_A = LEAD;                 // ... and the A pieces (the second row tile's pieces moved to the waves 4..7, with the
+                                                 // 2 / 3 / 2 W split: measured 0 at M = 8192, tools/ab_rt2.sh, and removed again)
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
     const int M = a.M, N = a.N, K = a.K;
-    const int m0 = tm * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
+    const int m0 = tm * RT * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
     const int Dq = N / 3;
     const int KT = K / BK, G = K / BN;
     const int T = NPASS * KT;                    // stages: stage u carries W of pass u % NPASS, and A when that pass is 0
@@ -590,39 +608,51 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const unsigned long long t_entry = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
 
     const int row_l = rg * 16 + li;
-    const bool row_ok = row_l < a.rpt && m0 + row_l < M;
-    const int row = row_ok ? m0 + row_l : (M - 1);
+    bool row_ok[RT];
+    int row[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        row_ok[rt] = row_l < a.rpt && m0 + rt * a.rpt + row_l < M;
+        row[rt] = row_ok[rt] ? m0 + rt * a.rpt + row_l : (M - 1);
+    }
 
     // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..2 / 3..5, waves 6, 7 pieces 6, 7 / 8, 9, wave
     // w < 4 pieces 10 + 2 w, 11 + 2 w (H2_WSPLIT 0: 4 / 4 / 3 / 3 and one each).  A (8 per A stage): waves 0..3 the two pieces
     // of row group `wave`.  (Moving ALL W pieces to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm
     // operand in place, -3 %; it costs 1-5 % now.)
-#if H2_WSPLIT == 1
-    const int w_first = HAS_A ? 10 + 2 * wave : (wave < 6 ? 3 * (wave - 4) : 6 + 2 * (wave - 6));
-    static_assert(HAS_A ? WC == 2 : (WC == 3 || WC == 2), "W pieces per wave");
-#else
-    const int w_first = HAS_A ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6));
-    static_assert(HAS_A ? WC == 1 : (WC == 3 || WC == 4), "W pieces per wave");
-#endif
+    // RT = 2: the waves 0..3 carry four A pieces, so they take one W piece each and the waves 4..7 four / three (the 1 / 4 / 3 split)
+    constexpr bool WS1 = H2_WSPLIT == 1 && RT == 1;
+    const int w_first = WS1 ? (LEAD ? 10 + 2 * wave : (wave < 6 ? 3 * (wave - 4) : 6 + 2 * (wave - 6)))
+                            : (LEAD ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6)));
+    static_assert(WS1 ? (LEAD ? WC == 2 : (WC == 3 || WC == 2)) : (LEAD ? WC == 1 : (WC == 3 || WC == 4)), "W pieces per wave");
     constexpr int w_cnt = WC;
     unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
     // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
     // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
-    unsigned voA = (unsigned)(lane * 16);
-    unsigned voT = 0;
-    if (LNF) {
-        voA = (unsigned)(((size_t)(row - m0) * a.ldx + 4 * kq) * 4);
-        voT = (unsigned)(((size_t)(row - m0) * a.ldx + 136 * kq + 128) * 4);
+    unsigned voA[RT], voT[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        voA[rt] = (unsigned)(lane * 16);
+        voT[rt] = 0;
+        if (LNF) {
+            voA[rt] = (unsigned)(((size_t)(row[rt] - m0) * a.ldx + 4 * kq) * 4);
+            voT[rt] = (unsigned)(((size_t)(row[rt] - m0) * a.ldx + 136 * kq + 128) * 4);
+        }
+        asm volatile("" : "+v"(voA[rt]), "+v"(voT[rt]));
     }
-    asm volatile("" : "+v"(voA), "+v"(voW), "+v"(voT));
+    asm volatile("" : "+v"(voW));
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     int iw_t = 0, iw_g = 0, ia_t = 0, ia_kt = 0;
     unsigned iw_slot = 0, ia_slot = 0;
     const char* is_w[NPASS];
 #pragma unroll
     for (int g = 0; g < NPASS; ++g) is_w[g] = a.W2 + (size_t)(colbase(g) / BN) * KT * H2_W;
-    const char* is_a = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
-                           : a.A2 + ((size_t)tm * 4 + (wave & 3)) * KT * H2_RG;
+    // packed operand: the strip of row group (wave & 3) of row tile tm RT + rt; fp32 rows: the first row of the (pair of) tile(s)
+    const char* is_a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        is_a[rt] = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
+                       : a.A2 + (((size_t)tm * RT + rt) * 4 + (wave & 3)) * KT * H2_RG;
     auto w_pieces = [&](const char* src, unsigned dst) {
         asm volatile(
             "s_mov_b32 m0, %2\n\t"
@@ -635,30 +665,34 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (w_cnt > 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
         if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
     };
-    // the two A pieces of this wave's row group for A k-tile ia_kt into stage slot `slot` (waves 0..3; M0 is the caller's)
+    // the two A pieces of this wave's row group (of each of the RT row tiles) for A k-tile ia_kt into stage slot `slot` (waves
+    // 0..3; M0 is the caller's); row tile rt lives in the row groups 4 rt .. 4 rt + 3 of the stage
     auto a_pieces = [&](unsigned slot) {
-        const unsigned dst = lds0 + slot + (unsigned)(wave * H2_RG);
-        if (!LNF) {
-            if (CHAIN)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 sc1"
-                             : : "v"(voA), "s"(is_a), "s"(dst) : "memory");
-            else
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                             : : "v"(voA), "s"(is_a), "s"(dst) : "memory");
-            is_a += H2_RG;
-        } else {
-            // raw fp32: the lane's columns j = 0..3 land in the first KiB (where the hi fragment will be), j = 4..7 in the second;
-            // the instruction offset would move BOTH addresses, so the second piece gets its own source base and M0
-            const bool full = ia_kt < 4 * G;
-            const char* src = full ? is_a + (size_t)(136 * (ia_kt >> 2) + 32 * (ia_kt & 3)) * 4 : is_a + (size_t)(136 * 4 * (ia_kt - 4 * G)) * 4;
-            const char* src2 = src + (full ? 64 : 16);
-            const unsigned vo = full ? voA : voT;
-            if (CHAIN)
-                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1"
-                             : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
-            else
-                asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                             : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned dst = lds0 + slot + (unsigned)(((wave & 3) + 4 * rt) * H2_RG);
+            if (!LNF) {
+                if (CHAIN)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 sc1"
+                                 : : "v"(voA[rt]), "s"(is_a[rt]), "s"(dst) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                                 : : "v"(voA[rt]), "s"(is_a[rt]), "s"(dst) : "memory");
+                is_a[rt] += H2_RG;
+            } else {
+                // raw fp32: the lane's columns j = 0..3 land in the first KiB (where the hi fragment will be), j = 4..7 in the second;
+                // the instruction offset would move BOTH addresses, so the second piece gets its own source base and M0
+                const bool full = ia_kt < 4 * G;
+                const char* src = full ? is_a[rt] + (size_t)(136 * (ia_kt >> 2) + 32 * (ia_kt & 3)) * 4 : is_a[rt] + (size_t)(136 * 4 * (ia_kt - 4 * G)) * 4;
+                const char* src2 = src + (full ? 64 : 16);
+                const unsigned vo = full ? voA[rt] : voT[rt];
+                if (CHAIN)
+                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1"
+                                 : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
+                else
+                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                                 : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
+            }
         }
         ++ia_kt;
     };
@@ -667,14 +701,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
 #pragma unroll
         for (int g = 0; g < NPASS; ++g)
             if (g == iw_g) {
-                w_pieces(is_w[g], lds0 + iw_slot + (unsigned)(H2_A + w_first * 1024));
+                w_pieces(is_w[g], lds0 + iw_slot + (unsigned)(ABYTES + w_first * 1024));
                 is_w[g] += H2_W;
             }
         if (++iw_g == NPASS) iw_g = 0;
         dma_m0_restore(keep);
         ++iw_t;
-        iw_slot += H2_STAGE;
-        if (iw_slot == NST * H2_STAGE) iw_slot = 0;
+        iw_slot += STAGE;
+        if (iw_slot == NST * STAGE) iw_slot = 0;
     };
     auto issue_a = [&]() {
         if ((ia_t % NPASS) == 0 && HAS_A) {
@@ -683,8 +717,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             dma_m0_restore(keep);
         }
         ++ia_t;
-        ia_slot += H2_STAGE;
-        if (ia_slot == NST * H2_STAGE) ia_slot = 0;
+        ia_slot += STAGE;
+        if (ia_slot == NST * STAGE) ia_slot = 0;
     };
     // steady state: stage t + NST lives where stage t lived; NST is a multiple of NPASS, so the refilled stage has the pass of
     // the current one (compile-time at the call site) and carries A exactly when the current one did
@@ -692,19 +726,19 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         constexpr int g = decltype(wp_c)::value;
         constexpr bool with_a = decltype(ai_c)::value;
         const unsigned keep = dma_m0_save();
-        w_pieces(is_w[g], lds0 + slot + (unsigned)(H2_A + w_first * 1024));
+        w_pieces(is_w[g], lds0 + slot + (unsigned)(ABYTES + w_first * 1024));
         is_w[g] += H2_W;
         if (with_a && HAS_A) a_pieces(slot);
         dma_m0_restore(keep);
     };
-    static_assert(NST % 1 == 0 && (NST % 2) == 0 && (NST % 3) == 0, "ring depth must be a multiple of every NPASS");
+    static_assert(NST % NPASS == 0, "ring depth must be a multiple of NPASS");
 
     // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue), and behind
     // them the static scales so of the columns that leave as a packed operand (attention: the v pass; else every pass)
     constexpr int NSO = EPI == H2_EPI_ATT ? 1 : (EPI == H2_EPI_RES ? 0 : NPASS);
     constexpr int VSO = NPASS * 2 * BN;                            // float offset of the so block inside the vector region
     static_assert((NPASS * 2 + NSO) * BN * 4 <= 4092, "epilogue vectors overflow the spare LDS");
-    if (HAS_A) {
+    if (LEAD) {
         constexpr int NV = NPASS * 2 * (BN / 4);                   // float4s: [pass][c | sc][34]
         int idx = wave * 64 + lane;
         const bool vec = idx < NV;
@@ -719,11 +753,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // ---- prologue.  Chain mode: W(0) does not depend on the other workgroups and is requested BEFORE the wait for them;
     // the poll is the job of wave 7 (lane 0), its first look goes out before any DMA piece of the wave.
     bool arrived = !CHAIN;
-    if (CHAIN && !HAS_A && wave == 7)
+    if (CHAIN && !LEAD && wave == 7)
         arrived = __hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need;
     issue_w();
     if (CHAIN) {
-        if (!HAS_A && wave == 7 && !arrived) {
+        if (!LEAD && wave == 7 && !arrived) {
             const unsigned lim = 1u << a.spin_log2;
             unsigned spin = 0;
             for (; spin < lim; ++spin) {
@@ -750,11 +784,14 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // right behind A(0).  NPASS >= 2: by LDS-DMA (L1-bypassing in chain mode) into the A region of stage slot 1, which a
     // pass-1 stage never uses -- an ordinary load here would make the compiler drain the WHOLE queue (it cannot see the
     // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
-    constexpr unsigned ST_LDS = H2_STAGE;
+    // RT = 2: into the 20 KiB its ring of 4 x 34 KiB leaves free below the vector region (every stage of a one-pass GEMM carries A)
+    constexpr unsigned ST_LDS = RT == 2 ? NST * STAGE : STAGE;           // + 1 KiB per wave, + 8 KiB per row tile
+    constexpr bool ST_DMA = NPASS >= 2 || RT == 2;
+    static_assert(RT == 1 || ST_LDS + 16384 <= H2_VEC, "statistics rows overlap the epilogue vectors");
     float4 st_raw[4];
     if (LNF) {
         const int ns = K / BN;
-        if constexpr (NPASS >= 2) {
+        if constexpr (ST_DMA) {
             // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
             const int hpr = ns >> 1;
             if (lane < 16 * hpr) {
@@ -762,19 +799,23 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 // reciprocal sequence that the compiler hoists out of the phase loop and keeps alive (it spilled)
                 const unsigned inv = 65536u / (unsigned)hpr + 1u;
                 const int lq = (int)(((unsigned)lane * inv) >> 16);
-                int r = m0 + 16 * rg + lq;
-                r = r < M ? r : M - 1;
-                const float* g = a.stats + ((size_t)r * ns + 2 * (lane - lq * hpr)) * 2;
-                unsigned keep;
-                if (CHAIN)
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024)) : "memory");
-                else
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024)) : "memory");
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    int r = m0 + rt * a.rpt + 16 * rg + lq;
+                    r = r < M ? r : M - 1;
+                    const float* g = a.stats + ((size_t)r * ns + 2 * (lane - lq * hpr)) * 2;
+                    unsigned keep;
+                    if (CHAIN)
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024 + rt * 8192)) : "memory");
+                    else
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024 + rt * 8192)) : "memory");
+                }
             }
         } else {
-            const float* sp = a.stats + (size_t)row * ns * 2;
+
+            const float* sp = a.stats + (size_t)row[0] * ns * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sp + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
         }
@@ -787,113 +828,136 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     const float ainv = (!LNF && a.a_inv) ? a.a_inv[0] : 1.0f;
 
     // residual of this lane's outputs (fp32 rows this workgroup wrote itself two phases ago, or a previous launch wrote)
-    float4 rv[NTW];
+    float4 rv[RT][NTW];
     auto epilogue_operands = [&]() {
         if (EPI == H2_EPI_RES) {
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                int c = 16 * h2_slot_tile(slot0 + n) + 4 * kq;
-                c = c + 3 < BN ? c : 0;
-                const float* rp = a.R + (size_t)row * a.ldr + n0 + c;
-                if (CHAIN) rv[n] = __builtin_bit_cast(float4, h2_ld16_l2(a.R + (size_t)m0 * a.ldr, (unsigned)((size_t)(rp - (a.R + (size_t)m0 * a.ldr)) * 4)));
-                else rv[n] = ld4(rp);
-            }
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) {
+                    int c = 16 * h2_slot_tile(slot0 + n) + 4 * kq;
+                    c = c + 3 < BN ? c : 0;
+                    const float* rp = a.R + (size_t)row[rt] * a.ldr + n0 + c;
+                    if (CHAIN) rv[rt][n] = __builtin_bit_cast(float4, h2_ld16_l2(a.R + (size_t)m0 * a.ldr, (unsigned)((size_t)(rp - (a.R + (size_t)m0 * a.ldr)) * 4)));
+                    else rv[rt][n] = ld4(rp);
+                }
         }
     };
 
-    f32x4 acc[NPASS][NTW];
+    f32x4 acc[NPASS][RT][NTW];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[p][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[p][rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- LNF: z = x cv_a + cv_b = (x - mean) rstd 2^10 of this lane's row, applied when the raw values are taken out of LDS
-    float cv_a = 0.f, cv_b = 0.f;
-    float4 cvr0 = {0.f, 0.f, 0.f, 0.f}, cvr1 = {0.f, 0.f, 0.f, 0.f};
+    float cv_a[RT], cv_b[RT];
+    float4 cvr0[RT], cvr1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        cv_a[rt] = cv_b[rt] = 0.f;
+        cvr0[rt] = cvr1[rt] = float4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    f16x8 A0[2], A1[2];
+    f16x8 A0[RT][2], A1[RT][2];
     f16x8 B0[NTW][2], B1[NTW][2];
     // LNF: the lane's eight raw values of its row wait in cvr0 / cvr1 until
     // finish_a() normalises and splits them at the end of the stage
-    auto read_a = [&](unsigned slot, f16x8 (&f)[2]) {
-        if constexpr (LNF) {
-            const char* p = smem + slot + rg * H2_RG + lane * 16;
-            cvr0 = *reinterpret_cast<const float4*>(p);
-            cvr1 = *reinterpret_cast<const float4*>(p + 1024);
-        } else {
-            const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + rg * H2_RG) + lane;
-            f[0] = as[0];
-            f[1] = as[64];
+    auto read_a = [&](unsigned slot, f16x8 (&f)[RT][2]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if constexpr (LNF) {
+                const char* p = smem + slot + (rg + 4 * rt) * H2_RG + lane * 16;
+                cvr0[rt] = *reinterpret_cast<const float4*>(p);
+                cvr1[rt] = *reinterpret_cast<const float4*>(p + 1024);
+            } else {
+                const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + (rg + 4 * rt) * H2_RG) + lane;
+                f[rt][0] = as[0];
+                f[rt][1] = as[64];
+            }
         }
     };
-    auto finish_a = [&](f16x8 (&f)[2]) {
-        float z[8] = {cvr0.x, cvr0.y, cvr0.z, cvr0.w, cvr1.x, cvr1.y, cvr1.z, cvr1.w};
+    auto finish_a = [&](f16x8 (&f)[RT][2]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            z[j] = fmaf(z[j], cv_a, cv_b);
-            z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
-            if (!row_ok) z[j] = 0.f;
+        for (int rt = 0; rt < RT; ++rt) {
+            float z[8] = {cvr0[rt].x, cvr0[rt].y, cvr0[rt].z, cvr0[rt].w, cvr1[rt].x, cvr1[rt].y, cvr1[rt].z, cvr1[rt].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                z[j] = fmaf(z[j], cv_a[rt], cv_b[rt]);
+                z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
+                if (!row_ok[rt]) z[j] = 0.f;
+            }
+            split2(z, f[rt][0], f[rt][1]);
         }
-        split2(z, f[0], f[1]);
     };
     auto read_b = [&](unsigned slot, f16x8 (&f)[NTW][2]) {
-        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot + H2_A) + slot0 * 2 * 64 + lane;
+        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot + ABYTES) + slot0 * 2 * 64 + lane;
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
             f[n][0] = bs[(n * 2 + 0) * 64];
             f[n][1] = bs[(n * 2 + 1) * 64];
         }
     };
-    auto slot_after = [](unsigned sl) -> unsigned { return sl + H2_STAGE == NST * H2_STAGE ? 0u : sl + H2_STAGE; };
+    auto slot_after = [&](unsigned sl) -> unsigned { return sl + STAGE == NST * STAGE ? 0u : sl + STAGE; };
     // Three products, fixed order (A part . W part): lo.hi, hi.lo, hi.hi, each over the wave's NTW tiles.  The W fragment is
     // the FIRST MFMA operand: lane (i, kq) then holds C[row i][4 consecutive columns 16 tile + 4 kq ..].
-    auto mfma_row = [&](f32x4 (&accp)[NTW], const f16x8& af, const f16x8 (&bf)[NTW][2], int bp) {
+    // (per accumulator; with RT = 2 the same W fragment serves both row tiles)
+    auto mfma_row = [&](f32x4 (&accp)[RT][NTW], const f16x8 (&af)[RT][2], int ap, const f16x8 (&bf)[NTW][2], int bp) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
-            if (!(H2_ABL & 8)) accp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[n][bp], af, accp[n], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+                if (!(H2_ABL & 8)) accp[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[n][bp], af[rt][ap], accp[rt][n], 0, 0, 0);
     };
     // counted waits.  Per stage a wave of the waves 4..7 requests WC (4 or 3) pieces, a wave 0..3 one W piece plus two A
     // pieces in the A stages (every NPASS-th).  One barrier per stage: the stages t+1 .. t+5 are in flight when stage t
     // starts and stage t+1 is needed, so four stages may stay in flight -- at least 4 WC + 2 (A stages among four consecutive
     // ones: 4, 2, 1 for NPASS 1, 2, 3) pieces of this wave.  P2: see the stage.
-    constexpr int A_ALLOW = 4 * WC + 2 * (4 / NPASS);
+    // In general (no P2): the stages t+2 .. t+NST-1 may stay in flight at the barrier in front of stage t.
     unsigned long long t_land = 0;
     {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
         // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
         if (HAS_A) {
-            constexpr int LATER = P2 ? 2 * WC + 2 * (NPASS == 1 ? 2 : 1) : (DIST - 1) * WC + 2 * (NPASS == 1 ? 5 : (NPASS == 2 ? 2 : 1));
+            // A stages among the stages 1 .. DIST - 1: every NPASS-th
+            constexpr int LATER = P2 ? 2 * WC + APW * (NPASS == 1 ? 2 : 1) : (DIST - 1) * WC + APW * ((DIST - 1) / NPASS);
+            static_assert(LATER < 64, "vmcnt is 6 bits");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : 5 * WC) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : (DIST - 1) * WC) : "memory");
         }
         if (H2_DBG == 2 && a.dbg) t_land = __builtin_amdgcn_s_memtime();
         {
             if (LNF) {
                 // Chan's combination of the per-slice {mean, M2} partials (fixed order)
                 const int ns = K / BN;
-                if constexpr (NPASS >= 2) {
-                    const float* sl = reinterpret_cast<const float*>(smem + ST_LDS + wave * 1024) + li * ns * 2;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sl + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (ST_DMA) {
+                        const float* sl = reinterpret_cast<const float*>(smem + ST_LDS + wave * 1024 + rt * 8192) + li * ns * 2;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sl + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    float st[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        st[4 * i] = st_raw[i].x; st[4 * i + 1] = st_raw[i].y; st[4 * i + 2] = st_raw[i].z; st[4 * i + 3] = st_raw[i].w;
+                    }
+                    float msum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) msum += (i < ns) ? st[2 * i] : 0.f;
+                    const float mean = msum / (float)ns;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float d = st[2 * i] - mean;
+                        m2 += (i < ns) ? fmaf((float)BN * d, d, st[2 * i + 1]) : 0.f;
+                    }
+                    const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
+                    cv_a[rt] = rs * H2_SA;
+                    cv_b[rt] = -mean * cv_a[rt];
                 }
-                float st[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    st[4 * i] = st_raw[i].x; st[4 * i + 1] = st_raw[i].y; st[4 * i + 2] = st_raw[i].z; st[4 * i + 3] = st_raw[i].w;
-                }
-                float msum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) msum += (i < ns) ? st[2 * i] : 0.f;
-                const float mean = msum / (float)ns;
-                float m2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float d = st[2 * i] - mean;
-                    m2 += (i < ns) ? fmaf((float)BN * d, d, st[2 * i + 1]) : 0.f;
-                }
-                const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
-                cv_a = rs * H2_SA;
-                cv_b = -mean * cv_a;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
@@ -911,7 +975,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // stages left including this one -- a compile-time number, so that the counted waits, the last refills and the end of the
     // fragment reads need neither bookkeeping nor branches (a tail stage with run-time bookkeeping cost ~1500 cycles against
     // ~800 of a steady-state one, and a quarter of all stages are tail stages).
-    auto stage = [&](auto rem_c, auto wp_c, f32x4 (&accp)[NTW], const f16x8 (&a_cur)[2], f16x8 (&a_nxt)[2],
+    auto stage = [&](auto rem_c, auto wp_c, f32x4 (&accp)[RT][NTW], const f16x8 (&a_cur)[RT][2], f16x8 (&a_nxt)[RT][2],
                      const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], auto nha_c, auto sync_c) {
         constexpr int REM = decltype(rem_c)::value;
         constexpr bool FAST = REM == 0;
@@ -924,22 +988,28 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         // remaining stages up front (+40 VGPRs, spills)
         asm volatile("" : "+s"(slot_c));
         const unsigned slot_n = slot_after(slot_c);
-        const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * H2_STAGE) : slot_c - H2_STAGE;   // ring slot of stage t - 1
+        const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * STAGE) : slot_c - STAGE;   // ring slot of stage t - 1
         unsigned long long w0 = 0, w1 = 0;
         if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
         if (more && SYNC) {
             if (FAST) {
                 if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
                     constexpr int na = ((g0 + 3) % NPASS == 0 ? 1 : 0) + ((g0 + 4) % NPASS == 0 ? 1 : 0);   // A stages among them
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC + 2 * na) : "memory");
+                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC + APW * na) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
-                } else if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ALLOW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WC) : "memory");
+                } else {    // stages <= t + 1 landed; t + 2 .. t + NST - 1 may stay in flight
+                    constexpr int na = ((g0 + 2) % NPASS == 0 ? 1 : 0) + ((g0 + 3) % NPASS == 0 ? 1 : 0) +
+                                       (NST > 4 ? ((g0 + 4) % NPASS == 0 ? 1 : 0) + ((g0 + 5) % NPASS == 0 ? 1 : 0) : 0);
+                    static_assert(NST == 4 || NST == 6, "in-flight stages of the one-barrier-per-stage form");
+                    static_assert((NST - 2) * WC + APW * na < 64, "vmcnt is 6 bits");
+                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * WC + APW * na) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * WC) : "memory");
+                }
             } else {
                 // tail (a barrier in front of every stage).  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed:
                 // <= t + 1.  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
                 constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - 1;
-                constexpr int per = HAS_A ? WC + (NPASS == 1 ? 2 : 0) : WC;
+                constexpr int per = HAS_A ? WC + (NPASS == 1 ? APW : 0) : WC;
                 constexpr int allow = ahead > 0 ? ahead * per : 0;
                 static_assert(allow < 64, "vmcnt is 6 bits");
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
@@ -950,7 +1020,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             asm volatile("" ::: "memory");
             if (H2_DBG && a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
         }
-        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot_n + H2_A) + slot0 * 2 * 64 + lane;
+        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot_n + ABYTES) + slot0 * 2 * 64 + lane;
         auto rd_b = [&](int n) {
             if (more && n < NTW && !(H2_ABL & 1)) {
                 b_nxt[n][0] = bs[(n * 2 + 0) * 64];
@@ -971,18 +1041,18 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         // (Interleaving rows, reads and requests -- down to one load operation behind every MFMA --, or reads first in both
         // halves: +1 .. +11 % time)
         __builtin_amdgcn_sched_barrier(0);
-        if (!HAS_A) {
+        if (!LEAD) {
             loads();
             __builtin_amdgcn_sched_barrier(0);
         }
         unsigned long long m0 = 0;
         if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
-        mfma_row(accp, a_cur[1], b_cur, 0);             // lo . hi
-        mfma_row(accp, a_cur[0], b_cur, 1);             // hi . lo
-        mfma_row(accp, a_cur[0], b_cur, 0);             // hi . hi
+        mfma_row(accp, a_cur, 1, b_cur, 0);             // lo . hi
+        mfma_row(accp, a_cur, 0, b_cur, 1);             // hi . lo
+        mfma_row(accp, a_cur, 0, b_cur, 0);             // hi . hi
         __builtin_amdgcn_sched_barrier(0);
         if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
-        if (HAS_A) loads();
+        if (LEAD) loads();
         if (LNF && more && next_has_a && !(H2_ABL & 16)) finish_a(a_nxt);
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
@@ -1042,9 +1112,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
 
     // ------------------------------------------------------------------------------------------ epilogue
     const unsigned long long t_epi = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    // acc[p][n][r] = scaled C[row_l][colbase(p) + 16 tile(n) + 4 kq + r];   value = acc * sc_n (* 1 / a_scale) + c_n
+    // acc[p][rt][n][r] = scaled C[row_l of row tile rt][colbase(p) + 16 tile(n) + 4 kq + r];   value = acc * sc_n (* 1 / a_scale) + c_n
     auto tile_of = [&](int n) -> int { return h2_slot_tile(slot0 + n); };
-    auto value4 = [&](int p, int n, float (&v)[4]) {
+    auto value4 = [&](int p, int rt, int n, float (&v)[4]) {
         const int cl = 16 * tile_of(n) + 4 * kq;
         const bool ok = cl + 3 < BN;
         const float* vecs = reinterpret_cast<const float*>(smem + H2_VEC) + p * 2 * BN + (ok ? cl : 0);
@@ -1055,7 +1125,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         for (int r = 0; r < 4; ++r) {
             // explicit fused operations: the same roundings in every instantiation (chain phases and one-GEMM launches agree
             // bitwise); sc_n, 1 / a_scale are powers of two: their product is exact
-            float t = fmaf(acc[p][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
+            float t = fmaf(acc[p][rt][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
             if (EPI == H2_EPI_GELU) t = gelu_as(t);
             v[r] = ok ? t : 0.f;
         }
@@ -1076,9 +1146,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         float qv[NTW][4], kv[NTW][4], vv[NTW][4];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            value4(0, n, qv[n]);
-            value4(1, n, kv[n]);
-            value4(2, n, vv[n]);
+            value4(0, 0, n, qv[n]);
+            value4(1, 0, n, kv[n]);
+            value4(2, 0, n, vv[n]);
         }
         auto quad = [](float x, int j) -> float {
             const int xi = __builtin_bit_cast(int, x);
@@ -1174,7 +1244,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 const int cl = 16 * tile_of(n) + 4 * kq;
                 if (cl + 3 < BN) {
                     float v[4];
-                    value4(p, n, v);
+                    value4(p, 0, n, v);
                     st4(Tt + row_l * H2_ATT_TS + p * BN + cl, float4{v[0], v[1], v[2], v[3]});
                 }
             }
@@ -1184,89 +1254,106 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
       }
     } else {
         const int Go = N / BN;
-        char* cbase = a.C2 + ((size_t)tm * 4 + rg) * (N / BK) * H2_RG;
-        float vals[NTW][4];
+        float vals[RT][NTW][4];
 #pragma unroll
-        for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
-            const int g_out = colbase(p) / BN;
+        for (int rt = 0; rt < RT; ++rt) {
+            char* cbase = a.C2 + (((size_t)tm * RT + rt) * 4 + rg) * (N / BK) * H2_RG;
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                value4(p, n, vals[n]);
-                const int cl = 16 * tile_of(n) + 4 * kq;
-                const bool ok = cl + 3 < BN;
-                if (EPI == H2_EPI_RES) {
-                    vals[n][0] += rv[n].x; vals[n][1] += rv[n].y; vals[n][2] += rv[n].z; vals[n][3] += rv[n].w;
-                    if (!ok) vals[n][0] = vals[n][1] = vals[n][2] = vals[n][3] = 0.f;
-                }
-                if (a.C && ok && row_ok) {
-                    // fp32 rows: in chain mode the WHOLE team reads them (LayerNorm GEMM of the next phase): write-through
-                    const float4 o4 = {vals[n][0], vals[n][1], vals[n][2], vals[n][3]};
-                    h2_st16(WT, a.C + (size_t)m0 * a.ldc, (unsigned)(((size_t)(row - m0) * a.ldc + colbase(p) + cl) * 4),
-                            __builtin_bit_cast(u32x4, o4));
-                }
-            }
-            if constexpr (NSO > 0) {
-              if (a.C2) {
+            for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
+                const int g_out = colbase(p) / BN;
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
-                    float so4[4];
-                    oscale4(p, n, so4);
+                    value4(p, rt, n, vals[rt][n]);
+                    const int cl = 16 * tile_of(n) + 4 * kq;
+                    const bool ok = cl + 3 < BN;
+                    if (EPI == H2_EPI_RES) {
+                        vals[rt][n][0] += rv[rt][n].x; vals[rt][n][1] += rv[rt][n].y; vals[rt][n][2] += rv[rt][n].z; vals[rt][n][3] += rv[rt][n].w;
+                        if (!ok) vals[rt][n][0] = vals[rt][n][1] = vals[rt][n][2] = vals[rt][n][3] = 0.f;
+                    }
+                    if (a.C && ok && row_ok[rt]) {
+                        // fp32 rows: in chain mode the WHOLE team reads them (LayerNorm GEMM of the next phase): write-through
+                        const float4 o4 = {vals[rt][n][0], vals[rt][n][1], vals[rt][n][2], vals[rt][n][3]};
+                        h2_st16(WT, a.C + (size_t)m0 * a.ldc, (unsigned)(((size_t)(row[rt] - m0) * a.ldc + colbase(p) + cl) * 4),
+                                __builtin_bit_cast(u32x4, o4));
+                    }
+                }
+                if constexpr (NSO > 0) {
+                  if (a.C2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vals[n][r] *= so4[r];
-                }
+                    for (int n = 0; n < NTW; ++n) {
+                        float so4[4];
+                        oscale4(p, n, so4);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float x[8] = {vals[2 * q][0], vals[2 * q][1], vals[2 * q][2], vals[2 * q][3],
-                                        vals[2 * q + 1][0], vals[2 * q + 1][1], vals[2 * q + 1][2], vals[2 * q + 1][3]};
-                    h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
+                        for (int r = 0; r < 4; ++r) vals[rt][n][r] *= so4[r];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float x[8] = {vals[rt][2 * q][0], vals[rt][2 * q][1], vals[rt][2 * q][2], vals[rt][2 * q][3],
+                                            vals[rt][2 * q + 1][0], vals[rt][2 * q + 1][1], vals[rt][2 * q + 1][2], vals[rt][2 * q + 1][3]};
+                        h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
+                    }
+                    if (NTW == H2_T0 && kq < 2) {
+                        const float x[8] = {vals[rt][NTW - 1][0], vals[rt][NTW - 1][1], vals[rt][NTW - 1][2], vals[rt][NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
+                        h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
+                    }
+                  }
                 }
-                if (NTW == H2_T0 && kq < 2) {
-                    const float x[8] = {vals[NTW - 1][0], vals[NTW - 1][1], vals[NTW - 1][2], vals[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
-                    h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
-                }
-              }
             }
         }
         if (H2_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
         if constexpr (EPI == H2_EPI_RES) {
             if (a.stats_out) {
                 // LayerNorm partials {mean, M2} of the 136-column slice of each row (x3_gemm.hip): two exchanges through LDS
-                float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][64 rows]
+                constexpr int XR = RT * 64;
+                float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][RT x 64 rows]
                 const int half = slot0 ? 1 : 0;
-                float sum = 0.f;
+                float sum[RT];
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) sum += (vals[n][0] + vals[n][1]) + (vals[n][2] + vals[n][3]);
-                sum = xor16_add(sum);
-                sum = xor32_add(sum);
+                for (int rt = 0; rt < RT; ++rt) {
+                    sum[rt] = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) sum[rt] += (vals[rt][n][0] + vals[rt][n][1]) + (vals[rt][n][2] + vals[rt][n][3]);
+                    sum[rt] = xor16_add(sum[rt]);
+                    sum[rt] = xor32_add(sum[rt]);
+                }
                 __syncthreads();
-                if (kq == 0) xch[half * 64 + row_l] = sum;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    if (kq == 0) xch[half * XR + rt * 64 + row_l] = sum[rt];
                 __syncthreads();
-                const float mean = (xch[row_l] + xch[64 + row_l]) * (1.0f / (float)BN);
-                float q = 0.f;
+                float mean[RT];
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    const bool ok = 16 * tile_of(n) + 4 * kq + 3 < BN;
+                for (int rt = 0; rt < RT; ++rt) {
+                    mean[rt] = (xch[rt * 64 + row_l] + xch[XR + rt * 64 + row_l]) * (1.0f / (float)BN);
+                    float q = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d = vals[n][r] - mean;
-                        q = ok ? fmaf(d, d, q) : q;
+                    for (int n = 0; n < NTW; ++n) {
+                        const bool ok = 16 * tile_of(n) + 4 * kq + 3 < BN;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = vals[rt][n][r] - mean[rt];
+                            q = ok ? fmaf(d, d, q) : q;
+                        }
                     }
+                    q = xor16_add(q);
+                    q = xor32_add(q);
+                    if (kq == 0) xch[2 * XR + half * XR + rt * 64 + row_l] = q;
                 }
-                q = xor16_add(q);
-                q = xor32_add(q);
-                if (kq == 0) xch[128 + half * 64 + row_l] = q;
                 __syncthreads();
-                if (half == 0 && kq == 0 && row_ok) {
-                    const u32x2 h = {__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, xch[128 + row_l] + xch[192 + row_l])};
-                    h2_st8(WT, a.stats_out + (size_t)m0 * Go * 2, (unsigned)(((row - m0) * Go + n0 / BN) * 8), h);
-                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    if (half == 0 && kq == 0 && row_ok[rt]) {
+                        const u32x2 h = {__builtin_bit_cast(unsigned, mean[rt]),
+                                         __builtin_bit_cast(unsigned, xch[2 * XR + rt * 64 + row_l] + xch[3 * XR + rt * 64 + row_l])};
+                        h2_st8(WT, a.stats_out + (size_t)m0 * Go * 2, (unsigned)(((row[rt] - m0) * Go + n0 / BN) * 8), h);
+                    }
             }
         }
     }
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && arrive) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (H2_DBG && a.dbg) {
         if (!t_st) t_st = __builtin_amdgcn_s_memtime();
@@ -1392,6 +1479,87 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     }
 }
 
+// The same stack for teams that own TWO OR MORE row tiles (M > 64 x the number of teams the chip holds: the FULL flag set at
+// B = 1024, eight views, B >= 2048): a team walks PAIRS of row tiles.  proj, fc1 and fc2 run the two-tile stage (h2_phase RT = 2:
+// every W k-tile is fetched and read once for both tiles); the qkv + attention phase, whose three accumulator sets leave no
+// registers for a second row tile, runs the one-tile form for the two tiles one after the other.  Bitwise the same poses as
+// h2_stack_kernel (tested: the batch-split and shard equalities of tests/test_gpu_parity.py cross the switch).
+__global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = s.G, D = s.D;
+    int team, tn;
+    {
+        const int b = blockIdx.x;
+        team = (b & 7) + 8 * ((b >> 3) / G);
+        tn = (b >> 3) % G;
+        if (team >= s.n_teams) return;
+    }
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    __syncthreads();
+    auto vecs = [&](const char* w2, int N, int K) -> const float* {
+        return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
+    };
+    const int n_pairs = (s.n_tiles + 1) >> 1;
+    for (int pair0 = team; pair0 < n_pairs; pair0 += s.n_teams) {
+        unsigned need = 0;
+        // six steps per block application: qkv of the first / the second row tile of the pair, proj, fc1 of the workgroup's
+        // first / second column group, fc2.  A step that has a partner step waits for the team only in the first and arrives
+        // only in the second of the two.
+        for (int e = 0; e < 6 * s.n_apps; ++e) {
+            int wvp = wave_s, pair = pair0, tnp = tn;
+            asm volatile("" : "+s"(wvp), "+s"(pair), "+s"(tnp));
+            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(tidp));
+            const int wv = wvp;
+            const int app = e / 6, k = e - 6 * app;
+            const int ph = 4 * app + (k < 2 ? 0 : (k == 2 ? 1 : (k < 5 ? 2 : 3)));      // the GEMM this step belongs to
+            if (ph >= s.n_phases) break;
+            const bool two = 2 * pair + 1 < s.n_tiles;
+            if (k == 1 && !two) continue;
+            const bool second = k == 1 || k == 4;
+            const bool arr = !((k == 0 && two) || k == 3);
+            const unsigned nd = second ? 0u : need;
+            unsigned* ctr = s.counters + 2 * pair;       // the arrival counter of the pair = the one of its first row tile
+            const char* const* w = s.w[app];
+            bool ok = true;
+            if (s.inject > 0 && ph == s.inject && !second && pair == 0 && tnp == 0) return;     // fault injection (test hook)
+            if (k < 2) {   // x = x + proj(attn(qkv(norm1(x)))): one row tile at a time
+                const float* v = vecs(w[0], 3 * D, D);
+                const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D, nullptr, 0, nullptr, 0, s.att2,
+                               nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
+                               s.spin_log2};
+                const int tile = 2 * pair + k;
+                if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, nd, arr);
+                else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, nd, arr);
+                else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, nd, arr);
+            } else if (k == 3 || k == 4) {   // fc1 + GELU: the workgroup's two column groups one after the other (two accumulator sets
+                                             // for two row tiles do not fit the register file beside the double-buffered fragments)
+                const float* v = vecs(w[2], 2 * D, D);
+                const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
+                               nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                const int cg = 2 * tnp + (k - 3);
+                if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, cg, ctr, nd, arr);
+                else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, cg, ctr, nd, arr);
+                else ok = h2_phase<H2_EPI_GELU, true, 1, NT - H2_T0, true, H2_R2_WC2, 2>(a, smem, tidp, wv, H2_T0, pair, cg, ctr, nd, arr);
+            } else {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D)
+                const bool fc2 = k == 5;
+                const int K = fc2 ? 2 * D : D;
+                const char* w2 = fc2 ? w[3] : w[1];
+                const float* v = vecs(w2, D, K);
+                const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, nullptr, s.stats,
+                               s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, tnp, ctr, nd, arr);
+                else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
+                else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC2, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
+            }
+            if (!ok) return;
+            if (arr) need += G;
+        }
+    }
+}
+
 template <int EPI, bool LNF, int NPASS>
 static int launch_h2(const H2Args& a, hipStream_t s) {
     constexpr int LDS = H2_LDS_BYTES;
@@ -1470,6 +1638,10 @@ int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
             return MPL_E_LAUNCH;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h2_stack_kernel, 512, H2_LDS_BYTES) != hipSuccess || per_cu < 1)
             return MPL_E_UNSUPPORTED;
+        if (hipFuncSetAttribute((const void*)h2_stack2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
+            return MPL_E_LAUNCH;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h2_stack2_kernel, 512, H2_LDS_BYTES) != hipSuccess || per_cu < 1)
+            return MPL_E_UNSUPPORTED;
         resident[dev].store(cus, std::memory_order_release);
     }
     H2StackArgs a;
@@ -1484,7 +1656,12 @@ int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     a.G = D / BN;
     const int cap = resident[dev].load() / a.G;
     if (cap < 1) return MPL_E_UNSUPPORTED;
-    a.n_teams = a.n_tiles < cap ? a.n_tiles : cap;
+    // more row tiles than teams the chip holds: teams walk PAIRS of row tiles with the two-tile stage (by the shape of the launch
+    // only; the poses are bitwise the same in both forms).  g_h2_rt: A/B switch (mpl_x3_stack_mode bits 1, 2)
+    const int force = g_h2_rt.load();
+    const bool pairs = force == 2 || (force == 0 && a.n_tiles > cap);
+    const int n_units = pairs ? (a.n_tiles + 1) / 2 : a.n_tiles;
+    a.n_teams = n_units < cap ? n_units : cap;
     if (a.n_teams * a.G > H2_MAX_WGS) a.n_teams = H2_MAX_WGS / a.G;
     a.n_apps = n_apps;
     a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
@@ -1508,7 +1685,8 @@ int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned
     int rc;
     {
         ProfScope prof(MPL_K_GEMM, s);
-        hipLaunchKernelGGL(h2_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
+        if (pairs) hipLaunchKernelGGL(h2_stack2_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL(h2_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         rc = hip_check_launch();
     }
     if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;

@@ -258,9 +258,10 @@ def test_data_parallel_replicas_pack_once_per_device():
         # what a second GPU sees: parameters in FRESH storage on every forward (cloned here, broadcast there)
         def fresh_replica():
             r = replicate(m, [0], detach=True)[0]
-            for mod in r.modules():                 # replicate() leaves the copies as plain tensor attributes (_former_parameters)
+            for mod in r.modules():                 # the copies are plain tensor attributes (Parameters where storage is shared)
                 for k, p in list(mod._former_parameters.items()):
-                    setattr(mod, k, p.clone())
+                    mod._parameters.pop(k, None)
+                    object.__setattr__(mod, k, p.detach().clone())
             return r
         outs = []
         for it in range(3):
@@ -311,3 +312,31 @@ def test_shipped_call_shape_b256_v2():
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
     _assert_close(out, ref, "B=256 V=2 vs fp64 oracle")
+
+
+@pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 512), ("chosen_v4_b8_l2", 48), ("chosen_v4_b8_l2", 1), ("full_v4_b8_l2", 200),
+                                    ("chosen_v5_b19_l2", 100), ("chosen_v31_b2_l12", 9), ("chosen_v8_b4_l2", 37), ("chosen_v2_b1_l12", 97)])
+def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
+    """Teams that own two or more row tiles walk PAIRS of tiles with the two-tile stage (h2_stack2_kernel: proj / fc1 / fc2 fetch
+    every W k-tile once for both tiles).  The library picks the form by the shape of the launch, so the arithmetic of an output
+    element must not depend on it: forced either way (mpl_x3_stack_mode bits 1, 2) the poses are bitwise equal -- odd tile
+    counts (a pair with an absent partner), ragged last tiles, 60- and 62-row tiles and the LDS attention of V = 8 / 31 included."""
+    lib = cabi.load()
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    P, R, Cn = _big_inputs(B, V, 123)
+    outs = {}
+    try:
+        for rt in (1, 2):
+            cabi.check(lib.mpl_x3_stack_mode(rt << 1), "stack mode")
+            with torch.no_grad():
+                outs[rt] = m(P, rays=R, centers=Cn)
+            torch.cuda.synchronize()
+    finally:
+        cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[1], outs[2]), "the two-tile stage changed results: max |d| = %.3e" % float((outs[1] - outs[2]).abs().max())
+    if B <= 100:
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
+        _assert_close(outs[2], ref, name + " two-tile stage vs fp64 oracle")

@@ -29,7 +29,10 @@ for stop in range(4 * (NB - 1) - 1, 4 * NB + 1):
     t = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
     t = t[t[:, 0] > 0]
     ph = (stop - 1) & 3
-    nst = {0: 3, 1: 1, 2: 2, 3: 2}[ph] * (D // 32)
+    # teams that own >= 2 row tiles run the two-tile stage (h2_stack2_kernel): fc1 is then two one-pass steps of D / 32 stages
+    # (the stamps are those of the second), qkv two one-tile steps
+    pairs = ENGINE == "h2" and (M + 63) // 64 > 256 // (D // 136)
+    nst = {0: 3, 1: 1, 2: 1 if pairs else 2, 3: 2}[ph] * (D // 32)
     ent, loop, epi, sto, end = (t[:, i] for i in range(5))
     print("stop %2d %-9s waves %4d | entry->loop %6.0f (min %6.0f max %6.0f) | k loop %7.0f (%5.0f/stage, %d stages) | epilogue %6.0f | drain %5.0f | total %7.0f | DMA wait/stage %4.0f  bar/stage %4.0f"
           % (stop, names[ph], len(t), (loop - ent).mean(), (loop - ent).min(), (loop - ent).max(), (epi - loop).mean(), (epi - loop).mean() / nst, nst,
