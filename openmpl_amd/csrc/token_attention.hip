@@ -301,6 +301,14 @@ __global__ __launch_bounds__(256) void token_attention_long_kernel(const float* 
 // K and V live in LDS as [pair]{x_j, x_j+1, y_j, y_j+1, z_j, z_j+1, w_j, w_j+1}, the scores, the exponent arguments, the row
 // sum and the output accumulate as 2-vectors (packed fp32 instructions); the two halves of the output / row sum (even and odd
 // keys) are added once at the end.
+// Round 4 put this attention on the fp32 matrix cores three ways (exact fp32: v_mfma_f32_16x16x4_f32 is bitwise an fmaf chain
+// and its K = 4 is the head width) and measured all of them SLOWER than this kernel (V = 31, B = 256, one launch, 240 us here):
+// scores by 16x16x4 tiles with P V on the VALU 280 us (a lane then owns 16 keys of a row instead of a row: every score needs its
+// own 16-byte V read and the LDS pipe becomes the limit); scores and P V on v_mfma_f32_4x4x1_16B_f32 with lane = query row
+// (layout: tools/mfma4_probe.hip) 285 us, bitwise this kernel's result (that instruction runs at a quarter of the 16x16x4 rate);
+// scores and P V (O^T += V^T P^T, 12 of 16 rows padding) on 16x16x4 369 us.  P V from fp16 pairs on the 16-bit pipe was priced
+// and not built: splitting p costs as many VALU instructions per score (two conversions, a subtraction, a conversion back) as
+// the two packed multiply-adds it would replace.  The kernel stays VALU-issue bound.
 typedef float taf2 __attribute__((ext_vector_type(2)));
 template <int NR, bool FULL>
 __device__ __forceinline__ void attend_chunk_p4(const float4 (&q)[NR], taf2 (&o)[NR][4], float (&m)[NR], taf2 (&l)[NR],

@@ -287,7 +287,8 @@ class MultiView_MPL(nn.Module):
         rebuilds the small struct of addresses (_marshal).  Round 3 re-packed everything per forward (1.2 ms of GPU time)."""
         r = super()._replicate_for_data_parallel()
         r._dp_replica = True
-        r._dp_src = self._dp_src if self._dp_replica else self
+        # a plain attribute: nn.Module.__setattr__ would register the source module as a CHILD of its own replica
+        r.__dict__["_dp_src"] = self._dp_src if self._dp_replica else self
         return r
 
     # ------------------------------------------------------------------ C-ABI argument marshalling

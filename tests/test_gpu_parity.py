@@ -98,7 +98,8 @@ def test_ln_linear_residual_in_place():
     _assert_close(x, ref, "in-place residual", tol=2e-6)
 
 
-@pytest.mark.parametrize("n_tok,dim", [(2, 544), (4, 544), (4, 1088), (5, 544), (8, 1088), (31, 544), (17, 32)])
+@pytest.mark.parametrize("n_tok,dim", [(2, 544), (4, 544), (4, 1088), (5, 544), (8, 1088), (31, 544), (17, 32),
+                                       (33, 32), (64, 32), (65, 32), (68, 32), (85, 32), (527, 32), (136, 64)])
 def test_token_attention_matches_torch(n_tok, dim):
     lib = cabi.load()
     n_seq, H = 37, 8
