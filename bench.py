@@ -239,7 +239,8 @@ def stack_roofline(model, flags, batch, batches, precision, n_prof=5):
     us = gemm_ms / max(1, gemm_n) * 1e3
     ex = (fl / launches) * products * 144.0 / 136.0 * kpad / (us * 1e-6) / 1e12
     total = sum(t for t, _ in prof.values())
-    return dict(kernel={1: "x3_stack_kernel<1>", 2: "h2_stack_kernel", 3: "x3_stack_kernel<3>"}[np_], bound="mfma",
+    pairs = np_ == 2 and -(-(batch * flags["num_views"]) // 64) > 256 // (D // 136)
+    return dict(kernel={1: "x3_stack_kernel<1>", 2: "h2_stack2_kernel" if pairs else "h2_stack_kernel", 3: "x3_stack_kernel<3>"}[np_], bound="mfma",
                 launches_per_step=launches, avg_launch_us=round(us, 1), achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS,
                 unit="TFLOP/s", frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
                 kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
@@ -346,7 +347,9 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
     weight_bytes = sum(p.numel() for p in model.parameters()) * 4
     eng = "h2" if a.precision == "fp32" else "x3"
-    gemm_kernel = ((eng + "_stack_kernel") if launches == 1 else (eng + "_gemm_kernel")) if split else "ln_gemm_ng_kernel"
+    # teams that own two or more row tiles (more 64-row tiles than teams of D / 136 workgroups fit 256 CUs) run the two-tile stage
+    pairs = a.precision == "fp32" and -(-(a.batch * a.views) // 64) > 256 // (fpt_width(flags) // 136)
+    gemm_kernel = ((eng + ("_stack2_kernel" if pairs else "_stack_kernel")) if launches == 1 else (eng + "_gemm_kernel")) if split else "ln_gemm_ng_kernel"
     # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
     # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
     traffic, traffic_src = None, None
@@ -428,7 +431,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     # profiles/r03_h2_probe.txt: 33 TB/s from an L2-resident shared region, 15 TB/s from per-workgroup regions beyond L2, 21 TB/s
     # from the shared region beside the engine's MFMA + ds_read pattern): this, not the matrix pipe, is what bounds the kernel
     lds_dma = None
-    if split and np_ == 2 and launches == 1:
+    if split and np_ == 2 and launches == 1 and not pairs:
         stages = (flags["depth"] + 1) * 8 * (D // 32)            # per workgroup: (3 + 1 + 2) D/32 + 2 D/32 (fc2: K = 2 D) stages per application
         tiles = -(-M // 64)
         dma_bytes = float(stages) * 26624 * tiles * (D // 136)

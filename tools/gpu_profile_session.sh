@@ -19,7 +19,7 @@ if [ -z "$SUF" ]; then
 else
   python bench.py $ARGS --no-extra --no-cpu-baseline > $O/bench.log 2>&1
 fi
-tail -1 $O/bench.log > $O/bench.json
+grep '^{"metric"' $O/bench.log | tail -1 > $O/bench.json
 cd /tmp
 CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra $ARGS"
 echo "$CMD" | sed "s#$R/##" > $O/cmd.txt
