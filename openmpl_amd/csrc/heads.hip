@@ -93,9 +93,11 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     const float* xa_r = xa + (size_t)(xm < M ? xm : 0) * lda;
     const float* xb_r = xb ? xb + (size_t)(xm < M ? xm : 0) * ldb : nullptr;
     const float* w_r = W + (size_t)(wn < N ? wn : 0) * ldw;
-    float4 xv[2], wv[2];
+    struct Slab {
+        float4 xv[2], wv[2];
+    };
     auto elem = [&](const float* r, int k) -> float { return r[k]; };
-    auto fetch = [&](int k0) {
+    auto fetch = [&](Slab& sl, int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + sk + 16 * h;
@@ -114,15 +116,15 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
                 x4 = float4{xe[0], xe[1], xe[2], xe[3]};
                 w4 = float4{we[0], we[1], we[2], we[3]};
             }
-            xv[h] = x4;
-            wv[h] = w4;
+            sl.xv[h] = x4;
+            sl.wv[h] = w4;
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const Slab& sl, int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            st4(&Xs[buf][sr][sk + 16 * h], xv[h]);
-            st4(&Ws[buf][sr][sk + 16 * h], wv[h]);
+            st4(&Xs[buf][sr][sk + 16 * h], sl.xv[h]);
+            st4(&Ws[buf][sr][sk + 16 * h], sl.wv[h]);
         }
     };
     f32x4 acc[2][2];
@@ -130,13 +132,15 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(0);
-    stash(0);
+    // slabs are requested TWO steps ahead (two register sets that swap roles): one workgroup per CU at N = 1024 leaves a wave
+    // alone on its SIMD, and one step of 32 MFMAs is shorter than a trip to L2
+    Slab ra, rb;
+    fetch(ra, 0);
+    stash(ra, 0);
+    fetch(ra, LK);
+    fetch(rb, 2 * LK);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += LK, buf ^= 1) {
-        const bool more = k0 + LK < K;
-        if (more) fetch(k0 + LK);
+    auto step = [&](int k0, int buf, Slab& nxt) {       // nxt holds slab k0 + LK; refilled with slab k0 + 3 LK
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 a[2], b[2];
@@ -150,8 +154,13 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_k16(a[i], b[j], acc[i][j]);
         }
-        if (more) stash(buf ^ 1);       // the other buffer: its readers finished before the barrier that ended the previous step
+        if (k0 + LK < K) stash(nxt, buf ^ 1);   // the other buffer: its readers finished before the barrier that ended the previous step
+        if (k0 + 3 * LK < K) fetch(nxt, k0 + 3 * LK);
         __syncthreads();
+    };
+    for (int k0 = 0; k0 < K; k0 += 2 * LK) {
+        step(k0, 0, ra);
+        if (k0 + LK < K) step(k0 + LK, 1, rb);
     }
     // D[row = 4 kq + r][col = li] of every tile
 #pragma unroll
