@@ -1,8 +1,8 @@
 """Arithmetic robustness of the default engine through the WHOLE forward (round-3 review, Weak #1 / Next #2).
 
 The fp16x2 engine (openmpl_amd/csrc/h2_gemm.hip) carries the attention output and the GELU output between the GEMMs of a
-block as hi + lo fp16 pairs under STATIC, data-free scales (one per 136-column group, from the column bounds
-sqrt(K) |gamma o W_n|_2 + |c_n| the binding computes when it packs the weights).  The unit tests scale a plain operand
+block as hi + lo fp16 pairs under STATIC, data-free scales (one per COLUMN, from the column bounds
+sqrt(K) |gamma o W_n|_2 + |c_n| the binding computes when it packs the weights; the consumer's weights are packed against them).  The unit tests scale a plain operand
 by its measured amax; these tests put the static scales themselves under stress: whole layers far from the usual
 magnitudes, single outlier channels (the case the bound is weakest for), degenerate inputs.  Every case is checked
 against the fp64 oracle with the 1e-4 contract, and the error of the native fp32 matrix instructions ("fp32_mfma")
@@ -76,8 +76,8 @@ def _v_column(m, blk, col):
                                   "everything"])
 def test_fpt_outlier_channels(name, case):
     """One channel far outside the rest -- exactly where a per-layer static scale would be weakest: the outlier would set the
-    fp16 window of every other channel of its layer.  The scales are per 136-column group of the consuming k order and the
-    weights of the consumer absorb the ratio, so only the outlier's own group shares its window."""
+    fp16 window of every other channel of its layer.  The scales are per column and the weights of the consumer absorb them
+    (W_mk / so_k), so the operand pair is equilibrated per channel."""
     m, g = _model(name)
     P, R, Cn = golden_inputs(g, DEV)
     with torch.no_grad():
@@ -123,3 +123,32 @@ def test_degenerate_inputs(name, case):
         else:
             p.zero_()
     _errors(m, g, P, R, Cn, "%s %s" % (name, case), ratio=4.0)
+
+
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l2", "full_v4_b8_l2"])
+@pytest.mark.parametrize("case", ["v_bias_1e3", "v_bias_1e5", "fc1_row_1e4", "v_row_1e4", "everything"])
+def test_spt_outlier_channels(name, case):
+    """The same outlier channels in the SPATIAL blocks (width 32, `mpl_spt_pack`: the four Linear layers of a block run from
+    two-part fp16 operands inside spt3_kernel, their attention / GELU outputs under static scales from data-free bounds)."""
+    m, g = _model(name)
+    P, R, Cn = golden_inputs(g, DEV)
+    stacks = m.Spatial_blocks if m.multiple_spatial_blocks else [m.Spatial_blocks]
+    with torch.no_grad():
+        for st in stacks:
+            for li, blk in enumerate(st):
+                D = 32
+                if case in ("v_bias_1e3", "v_bias_1e5", "everything"):
+                    c = (5 + 11 * li) % D
+                    val = 1e5 if case == "v_bias_1e5" else 1e3
+                    blk.attn.qkv.bias[2 * D + c] = val
+                    blk.attn.proj.weight[:, c] *= 1.0 / val
+                if case in ("fc1_row_1e4", "everything"):
+                    r = (3 + 7 * li) % (2 * D)
+                    blk.mlp.fc1.weight[r] *= 1e4
+                    blk.mlp.fc1.bias[r] *= 1e4
+                    blk.mlp.fc2.weight[:, r] *= 1e-4
+                if case in ("v_row_1e4", "everything"):
+                    c = (20 + 13 * li) % D
+                    blk.attn.qkv.weight[2 * D + c] *= 1e4
+                    blk.attn.proj.weight[:, c] *= 1e-4
+    _errors(m, g, P, R, Cn, "%s SPT outlier %s" % (name, case), ratio=4.0)
