@@ -403,8 +403,8 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                                          frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                                          note="algorithmic fp32 FLOP/s against the fp32 matrix pipe this kernel does not use"),
                     clock_note="`peak` is the nominal 2.4 GHz figure; under this launch (256 workgroups, one per CU) the part "
-                               "sustains 1.95-2.06 GHz by box (GRBM_GUI_ACTIVE / duration, profiles/r03_pmc_summary.txt; 2.4 GHz with up to 128 "
-                               "workgroups of the same kernel), i.e. a 2.0-2.15 PFLOP/s ceiling: frac x 1.16-1.23 against it")
+                               "sustains 1.95-2.22 GHz by box (GRBM_GUI_ACTIVE / duration: 2.22 in profiles/r04_pmc_summary.txt, 1.96 in r03; 2.4 GHz with up to 128 "
+                               "workgroups of the same kernel), i.e. a 2.0-2.3 PFLOP/s ceiling: frac x 1.08-1.23 against it")
     else:
         roof = dict(bound="mfma", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x4_f32", achieved=round(alg, 2),
                     peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
