@@ -130,6 +130,7 @@ StackWs carve_stack_ws(void* base, size_t M, size_t D) {
 }
 
 std::atomic<bool> g_x3_per_gemm{getenv("MPL_X3_LAUNCHES") != nullptr};
+std::atomic<int> g_spin_log2{23};    // polls before a wait inside a persistent kernel counts as lost (mpl_x3_spin_limit)
 std::atomic<int> g_x3_stop{0};   // diagnostics: stop a stack after this many GEMMs (0 = run everything)
 
 // split-operand path (x3_gemm.hip): the activations between the GEMMs of a block live as split A3 operands
@@ -299,7 +300,16 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
-    if (const int np = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H)) {
+    const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
+    // at most 16 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
+    // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 / fp32x3 request keeps its engine
+    if ((np0 == 0 || np0 == 2) && sm_stack_enabled() && n_apps <= MPL_MAX_APPS) {
+        int n_blocks = 0;
+        for (int a = 0; a < n_apps; ++a) n_blocks = schedule[a] + 1 > n_blocks ? schedule[a] + 1 : n_blocks;
+        if (sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks))
+            return launch_sm_stack(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, g_spin_log2.load(), s);
+    }
+    if (const int np = np0) {
         if (np == 2) return block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
         return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, err_ws, s);
     }
@@ -372,6 +382,10 @@ inline void clear_stale_hip_error() { (void)hipGetLastError(); }
 // either engine may run the stack (the binding decides by the operands it supplies): size for the larger layout
 size_t stack_ws_bytes(size_t M, size_t D, int n_tok) {
     size_t b = carve_stack_ws(nullptr, M, D).bytes;
+    if (M <= 16) {
+        const size_t bs = sm_stack_ws_bytes((int)M, (int)D);
+        b = bs > b ? bs : b;
+    }
     const int rpt = x3_rows_per_tile(n_tok);
     if (rpt > 0 && n_tok <= 32 && x3_shape_ok((int)D, (int)(2 * D))) {
         const size_t b3 = carve_x3_ws(nullptr, M, D, rpt).bytes;
@@ -562,6 +576,7 @@ int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);
     h2_set_row_tiles((one_launch_per_gemm >> 1) & 3);      // bits 1, 2: 0 = by shape, 1 / 2 = force the one- / two-tile stage
+    sm_stack_disable((one_launch_per_gemm >> 3) & 1);      // bit 3: no small-batch engine (the team kernels for every batch)
     return MPL_OK;
 }
 
@@ -583,6 +598,7 @@ int mpl_x3_spin_limit(int log2_polls) {
     // consumes it clears it, so a test that dies between set and reset cannot leave the process deserting workgroups
     static const bool inject_ok = getenv("MPL_FAULT_INJECT") != nullptr && atoi(getenv("MPL_FAULT_INJECT")) != 0;
     if ((log2_polls >> 8) != 0 && !inject_ok) return MPL_E_UNSUPPORTED;
+    g_spin_log2.store(log2_polls & 0xff);
     x3_set_spin_log2(log2_polls & 0xff);
     h2_set_spin_log2(log2_polls & 0xff);
     set_fault_injection(log2_polls >> 8);

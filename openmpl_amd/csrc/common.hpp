@@ -187,6 +187,14 @@ int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const floa
 int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
                     hipStream_t s);
+// Block stack for at most 16 token rows (sm_stack.hip): every GEMM on the whole chip (one 16-column tile per workgroup, weights
+// read in place), grid barriers in between, exact fp32 on the matrix cores
+bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks);
+bool sm_stack_enabled();
+void sm_stack_disable(int off);            // A/B switch (mpl_x3_stack_mode bit 3)
+size_t sm_stack_ws_bytes(int M, int D);
+int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps,
+                    void* ws, size_t ws_bytes, const unsigned** err_ws, int spin_log2, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);
 // use_packed: every SPT block carries the split operand of mpl_spt_pack in qkv_w3 (spt3_kernel: Linear layers on the bf16
 // matrix cores); else the fp32-MFMA kernel reads the nn.Linear weights in place

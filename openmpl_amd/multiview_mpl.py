@@ -28,6 +28,27 @@ from . import cabi
 
 logger = logging.getLogger(__name__)
 
+# Walking ~300 parameters through nn.Module.__getattr__ costs ~0.6 ms per list, which a forward would pay three times -- more
+# than the kernels of a single frame take.  The lists are cached per module and invalidated by a process-wide generation
+# counter that torch bumps whenever ANY module registers a parameter, buffer or submodule (assignment of a new Parameter,
+# load into a fresh module, ...); in-place updates keep the objects and are caught by data_ptr / _version as before.
+_STRUCT_GEN = [0]
+
+
+def _bump_struct_gen(*_a, **_k):
+    _STRUCT_GEN[0] += 1
+    return None
+
+
+_HOOKS_OK = True
+try:
+    from torch.nn.modules import module as _tnm
+    _tnm.register_module_parameter_registration_hook(_bump_struct_gen)
+    _tnm.register_module_buffer_registration_hook(_bump_struct_gen)
+    _tnm.register_module_module_registration_hook(_bump_struct_gen)
+except Exception:                       # an older torch without the global hooks: no caching
+    _HOOKS_OK = False
+
 
 class _Container(nn.Module):
     """Holds parameters under the reference's attribute names; not callable on its own."""
@@ -266,13 +287,33 @@ class MultiView_MPL(nn.Module):
         """The packed-operand engines (h2 / x3 / bf16) need every FPT Linear shape to have a packed layout (out features a
         multiple of 136, in features of 544: widths 544 and 1088, i.e. every view-token model at DIM 32;
         mpl_split_bf16x3_bytes / mpl_pack_h2_bytes decide) and fuse the attention for up to 32 tokens per sequence."""
-        if self.no_transformer_fpt or len(self.blocks) == 0 or self.FPT_blocks_view_keypoint_tokens or self.num_views > 32:
-            return False
-        lib = cabi.load()
-        b = self.blocks[0]
-        return all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0 and
-                   lib.mpl_pack_h2_bytes(int(t.shape[0]), int(t.shape[1])) > 0
-                   for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight))
+        c = self.__dict__.get("_x3_ok")
+        if c is not None and c[0] == _STRUCT_GEN[0] and _HOOKS_OK:
+            return c[1]
+        ok = False
+        if not (self.no_transformer_fpt or len(self.blocks) == 0 or self.FPT_blocks_view_keypoint_tokens or self.num_views > 32):
+            lib = cabi.load()
+            b = self.blocks[0]
+            ok = all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0 and
+                     lib.mpl_pack_h2_bytes(int(t.shape[0]), int(t.shape[1])) > 0
+                     for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight))
+        self.__dict__["_x3_ok"] = (_STRUCT_GEN[0], ok)
+        return ok
+
+    def _tensor_lists(self):
+        """(every tensor handed to the library, the tensors of the FPT blocks, the tensors of the SPT blocks) of THIS module,
+        cached until some module of the process registers a parameter / buffer / submodule (see _STRUCT_GEN).  Replicas of
+        DataParallel are fresh objects with plain tensor attributes on every forward: never cached."""
+        c = self.__dict__.get("_tl_cache")
+        if c is not None and c[0] == _STRUCT_GEN[0] and _HOOKS_OK and not self._dp_replica:
+            return c[1]
+        fpt = [t for b in self.blocks for t in self._block_ptrs(b)]
+        stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
+        spt = [t for st in stacks for b in st for t in self._block_ptrs(b)]
+        tl = (self._param_list(), fpt, spt)
+        if not self._dp_replica:
+            self.__dict__["_tl_cache"] = (_STRUCT_GEN[0], tl)
+        return tl
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _apply(self, fn, *a, **k):
@@ -348,22 +389,19 @@ class MultiView_MPL(nn.Module):
         """What the packed operands were built from: engine selection + storage and version of every SOURCE tensor they fold
         (norm1 / norm2, weights and biases of each block).  A replica looks at the module it was replicated from."""
         src = self._dp_src if self._dp_replica else self
-        ts = []
-        if h2 or x3 or bf16 or d32:
-            ts += [t for b in src.blocks for t in src._block_ptrs(b)]
-        if spt3:
-            stacks = src.Spatial_blocks if src.multiple_spatial_blocks else [src.Spatial_blocks]
-            ts += [t for st in stacks for b in st for t in src._block_ptrs(b)]
-        return (self.matmul_precision, h2, x3, bf16, spt3, d32) + tuple((t.data_ptr(), t._version) for t in ts)
+        _, fpt, spt = src._tensor_lists()
+        ts = (fpt if (h2 or x3 or bf16 or d32) else []) + (spt if spt3 else [])
+        return (self.matmul_precision, h2, x3, bf16, spt3, d32) + tuple([(t.data_ptr(), t._version) for t in ts])
 
     def _marshal(self, device: torch.device):
         """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the struct stays valid
         under in-place updates; it is rebuilt whenever any storage address changes.  The derived (packed) operands are kept
         as long as the tensors they were built from keep their storage and version (_derived_key)."""
-        plist = self._param_list()
-        bf16 = self.matmul_precision == "bf16" and self._x3_supported()
-        x3 = self.matmul_precision == "fp32x3" and self._x3_supported()
-        h2 = self.matmul_precision == "fp32" and self._x3_supported()
+        plist = self._tensor_lists()[0]
+        x3ok = self._x3_supported()
+        bf16 = self.matmul_precision == "bf16" and x3ok
+        x3 = self.matmul_precision == "fp32x3" and x3ok
+        h2 = self.matmul_precision == "fp32" and x3ok
         # the SPT Linear layers also run from split operands (fp32 arithmetic on the fp16 matrix cores) unless the native
         # fp32 matrix instructions were asked for
         spt3 = self.matmul_precision != "fp32_mfma" and not self.no_transformer_spt
@@ -371,7 +409,7 @@ class MultiView_MPL(nn.Module):
         d32 = self.matmul_precision == "fp32" and self.FPT_blocks_view_keypoint_tokens \
             and not self.no_transformer_fpt and len(self.blocks) > 0 and tuple(self.blocks[0].attn.qkv.weight.shape) == (96, 32)
         dkey = self._derived_key(h2, x3, bf16, spt3, d32)
-        key = tuple(map(torch.Tensor.data_ptr, plist)) + dkey
+        key = tuple([t.data_ptr() for t in plist]) + dkey
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
             return ent

@@ -150,6 +150,19 @@ def test_forward_matches_reference_golden(name):
     ref = torch.from_numpy(g["out"])
     mx, nw = _assert_close(out, ref, name)
     print("%s: max-scaled %.2e norm-wise %.2e MPJPE-vs-ref %.3e" % (name, mx, nw, mpl_oracle.mpjpe(out.cpu(), ref)))
+    # fixtures of at most 16 token rows run the small-batch engine (sm_stack.hip) by default: the team kernels must reproduce
+    # the same golden
+    if g["meta"]["batch"] * g["flags"]["num_views"] <= 16:
+        lib = cabi.load()
+        try:
+            cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")
+            with torch.no_grad():
+                out2 = m(poses, rays=rays, centers=centers)
+            torch.cuda.synchronize()
+        finally:
+            cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+        out2 = out2[0] if isinstance(out2, tuple) else out2
+        _assert_close(out2, ref, name + " (team kernels)")
 
 
 def test_every_golden_case_is_supported():

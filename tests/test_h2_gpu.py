@@ -340,3 +340,38 @@ def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
         _assert_close(outs[2], ref, name + " two-tile stage vs fp64 oracle")
+
+
+@pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 1), ("chosen_v2_b1_l12", 8), ("full_v2_b1_l12", 1), ("full_v2_b1_l12", 7),
+                                    ("chosen_v4_b8_l12", 4), ("full_v4_b8_l2", 3), ("chosen_v5_b19_l2", 3), ("chosen_v8_b4_l2", 2),
+                                    ("chosen_v4_b8_l2", 1)])
+def test_small_batch_engine(name, B):
+    """At most 16 token rows (a single frame, a few frames) run sm_stack.hip: every GEMM of the block stack on the whole chip
+    (one 16-column tile per workgroup, the nn.Linear weights read in place, exact fp32 on the matrix cores), grid barriers in between,
+    instead of one team of D / 136 workgroups.  Checked against the fp64 oracle, against the team kernels on the same inputs (two
+    fp32 engines: rounding noise apart), and for batch invariance inside the engine (bitwise)."""
+    lib = cabi.load()
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    assert B * V <= 16
+    P, R, Cn = _big_inputs(B, V, 321)
+    with torch.no_grad():
+        out, k = _kinds(lambda: m(P, rays=R, centers=Cn))
+        assert k["gemm"] == 1 and k["row_stats"] == 0, k         # one persistent launch, no entry kernel
+        try:
+            cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")
+            team, k2 = _kinds(lambda: m(P, rays=R, centers=Cn))
+        finally:
+            cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+        assert k2["row_stats"] == 1, k2
+        if B > 1:
+            lo = m([x[:1].contiguous() for x in P], rays=[x[:1].contiguous() for x in R], centers=[x[:1].contiguous() for x in Cn])
+            hi = m([x[1:].contiguous() for x in P], rays=[x[1:].contiguous() for x in R], centers=[x[1:].contiguous() for x in Cn])
+            assert torch.equal(out, torch.cat([lo, hi], 0)), "the small-batch engine depends on the batch size"
+    sd = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
+    e_sm = _assert_close(out, ref, name + " small-batch engine vs fp64 oracle")
+    e_tm = _assert_close(team, ref, name + " team kernels vs fp64 oracle")
+    mx, nw = mpl_oracle.rel_errors(out.cpu(), team.cpu())
+    print("%s B=%d: small-batch engine %.2e/%.2e, team kernels %.2e/%.2e from fp64; apart %.2e" % ((name, B) + e_sm + e_tm + (mx,)))
+    assert mx < 5e-6 and nw < 5e-6

@@ -18,6 +18,17 @@ from tests.util import golden_inputs
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _team_kernels_only():
+    """The tests are about the fp16x2 team kernels: the small-batch engine (sm_stack.hip, exact fp32 MFMA, at most 16 token rows)
+    is switched off for their duration, whatever the size of a fixture."""
+    from openmpl_amd import cabi
+    lib = cabi.load()
+    cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")
+    yield
+    cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+
+
 def _errors(m, g, P, R, Cn, what, tol=TOL, ratio=None):
     """HIP "fp32" (fp16x2) and "fp32_mfma" against the fp64 oracle on the model's CURRENT weights."""
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
