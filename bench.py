@@ -647,6 +647,20 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
             m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
             torch.cuda.synchronize()
         extra["v2_b1_latency_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+        # the same frame through the team kernels (the small-batch engine of sm_stack.hip switched off: mpl_x3_stack_mode bit 3)
+        from openmpl_amd import cabi
+        try:
+            cabi.check(cabi.load().mpl_x3_stack_mode(8), "stack mode")
+            for i in range(5):
+                m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(50):
+                m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+                torch.cuda.synchronize()
+            extra["v2_b1_latency_team_kernels_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+        finally:
+            cabi.check(cabi.load().mpl_x3_stack_mode(0), "stack mode")
     del m0
     # batch curve (the reference's shipped call shape is TEST.BATCH_SIZE 256 with two views, configs/h36m/mpl_amass/h36m.yaml:107,
     # :37-39): whole forward, CHOSEN flag set, depth 12.  The block stack is a chain of 52 dependent GEMMs per 64-row tile that

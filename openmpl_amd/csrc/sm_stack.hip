@@ -56,7 +56,8 @@ bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks) {
            ((D / H) & 3) == 0 && 16 * 2 * D * 4 <= SM_LDS_W && n_apps >= 1 && n_apps <= MPL_MAX_APPS && n_blocks >= 1 &&
            n_blocks <= SM_MAX_BLOCKS;
 }
-size_t sm_stack_ws_bytes(int M, int D) { return ((size_t)M * 6 * D) * sizeof(float) + 256; }
+constexpr int SM_BAR_WORDS = 32 * 17 + 32;    // 8 group counters, 8 generation words, the top counter (128 bytes apart), the error word
+size_t sm_stack_ws_bytes(int M, int D) { return ((size_t)M * 6 * D + SM_BAR_WORDS) * sizeof(float) + 256; }
 
 enum { SM_EPI_STORE = 0, SM_EPI_GELU = 1, SM_EPI_RES = 2 };
 
@@ -109,16 +110,34 @@ __device__ __forceinline__ bool sm_grid_sync(const SmArgs& a, char* smem, unsign
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (wave == 0) {
-        // every store of this workgroup was write-through and has been waited for by its wave (in front of the barrier above)
-        if (lane == 0) __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every store of this workgroup was write-through and has been waited for by its wave (in front of the barrier above).
+        // Two levels, as the guide's "barrier-xcd" row: the workgroups b mod 8 = x (one XCD, as dispatched today: for speed only, any
+        // partition is correct) arrive on counter x; the last of them arrives on the top counter for its group, waits for the
+        // other groups there and releases its own group through generation word x.  `target` counts barriers passed.
+        const int grp = (int)(blockIdx.x & 7u);
+        const unsigned n_grp = ((unsigned)a.n_wg - (unsigned)grp + 7u) >> 3, n_top = a.n_wg < 8 ? (unsigned)a.n_wg : 8u;
+        unsigned* cnt = a.bar + 32 * grp;           // 128 bytes apart: no two hot words on one line
+        unsigned* gen = a.bar + 32 * (8 + grp);
+        unsigned* top = a.bar + 32 * 16;
+        bool leader = false;
+        if (lane == 0) leader = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == n_grp * (target + 1u);
+        if (lane == 0 && leader) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sm_request_w(smem, next, 0, lane & 15, lane >> 4);
         if (lane == 0) {
-            const unsigned want = target + (unsigned)a.n_wg;
             const unsigned lim = 1u << a.spin_log2;
             unsigned spin = 0;
-            for (; spin < lim; ++spin) {
-                if ((int)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
-                __builtin_amdgcn_s_sleep(1);
+            if (leader) {
+                const unsigned want = n_top * (target + 1u);
+                for (; spin < lim; ++spin) {
+                    if ((int)(__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (spin < lim) __hip_atomic_store(gen, target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (; spin < lim; ++spin) {
+                    if ((int)(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (target + 1u)) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             if (spin == lim) {  // a workgroup that never arrived is an ERROR (the GPU was shared for longer than the bound): report, leave
                 *s_fail = 1u;
@@ -127,7 +146,7 @@ __device__ __forceinline__ bool sm_grid_sync(const SmArgs& a, char* smem, unsign
             }
         }
     }
-    target += (unsigned)a.n_wg;
+    target += 1u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -359,7 +378,7 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     a.att = a.qkv + (size_t)M * 3 * D;
     a.hid = a.att + (size_t)M * D;
     a.bar = reinterpret_cast<unsigned*>(a.hid + (size_t)M * 2 * D);
-    a.err_ws = a.bar + 1;
+    a.err_ws = a.bar + 32 * 17;
     a.err_host = device_error_word(dev);
     a.M = M; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
     // every workgroup must be resident (grid barrier): at most one per CU, and no more than the widest GEMM has column tiles
@@ -382,7 +401,7 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
             return MPL_E_LAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    if (hipMemsetAsync(a.bar, 0, 16, s) != hipSuccess) return MPL_E_LAUNCH;
+    if (hipMemsetAsync(a.bar, 0, SM_BAR_WORDS * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     // a grid barrier needs the chip like the team kernels do: serialised with them per device (api.hip)
     hipEvent_t ev = stack_chain_event(dev);
     if (!ev) return MPL_E_LAUNCH;
