@@ -225,9 +225,13 @@ int mpl_ln_linear_bf16(const float *x, int M, int K, int has_ln, float eps, cons
  * the buffer must hold 64 bytes per wave of the largest launch.  NULL (the default) switches it off.  The stamps are
  * compiled only into a library built with -DX3_DBG=1 (MPL_HIPCC_FLAGS); in the product build the call is a no-op. */
 int mpl_x3_debug_buffer(void *device_buffer);
-/* Diagnostics / A-B: 0 (default) = a block stack on packed operands is ONE persistent launch (row-tile chains of
+/* Diagnostics / A-B: bit 0: 0 (default) = a block stack on packed operands is ONE persistent launch (row-tile chains of
  * workgroups, x3_stack_kernel / h2_stack_kernel); 1 = one launch per GEMM (results agree to <= 4 ulp, each mode is bitwise
- * deterministic).  Bits 8.. = stop after that many GEMM phases (tools/chain_phase.py). */
+ * deterministic).  Bits 1-2: 0 = the fp16x2 stack picks its stage by the shape of the launch (teams that own two or more row
+ * tiles walk PAIRS of tiles, h2_stack2_kernel), 1 / 2 = force the one- / two-tile stage (bitwise the same poses).  Bit 3: no
+ * small-batch engine (sm_stack.hip: stacks of at most 16 token rows run every GEMM on the whole chip with grid barriers in
+ * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bits 8.. = stop after that
+ * many GEMM phases (tools/chain_phase.py). */
 int mpl_x3_stack_mode(int one_launch_per_gemm);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
