@@ -188,3 +188,30 @@ def test_tools_and_bench_compile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
         py_compile.compile(f, doraise=True)
+
+
+def test_cached_parameter_lists_follow_reassignment():
+    """The lists of tensors handed to the library are cached per module (walking ~300 parameters through nn.Module.__getattr__
+    cost more than the kernels of a single frame) and must be invalidated by ANYTHING that rebinds a parameter object: plain
+    assignment, load_state_dict(assign=True), a new submodule.  In-place updates keep the objects (data_ptr / _version cover them)."""
+    import torch
+    from openmpl_amd.multiview_mpl import MultiView_MPL
+    m = MultiView_MPL(num_views=2, depth=2, pose_3d_emb_learnable=True).eval()
+    a = m._tensor_lists()
+    assert m._tensor_lists() is a, "an unchanged module must serve the cached lists"
+    old = m.blocks[0].attn.qkv.weight
+    m.blocks[0].attn.qkv.weight = torch.nn.Parameter(torch.zeros_like(old))
+    b = m._tensor_lists()
+    assert b is not a and any(t is m.blocks[0].attn.qkv.weight for t in b[1]) and not any(t is old for t in b[1])
+    with torch.no_grad():
+        m.blocks[1].mlp.fc1.weight.mul_(2.0)                 # in place: same objects, the version moves
+    assert m._tensor_lists() is b
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    c = m._tensor_lists()
+    assert c is not b and all(any(t is p for p in m.parameters()) for t in c[1])
+    m.head[1] = torch.nn.Linear(544, 51)
+    assert m._tensor_lists() is not c
+    # a DataParallel replica is a fresh object with plain tensor attributes: never served from (or stored in) a cache
+    r = m._replicate_for_data_parallel()
+    assert r._dp_replica and "_tl_cache" not in r.__dict__ or r.__dict__.get("_tl_cache") is m.__dict__.get("_tl_cache")
