@@ -306,8 +306,11 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if ((np0 == 0 || np0 == 2) && sm_stack_enabled() && n_apps <= MPL_MAX_APPS) {
         int n_blocks = 0;
         for (int a = 0; a < n_apps; ++a) n_blocks = schedule[a] + 1 > n_blocks ? schedule[a] + 1 : n_blocks;
-        if (sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks))
-            return launch_sm_stack(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, g_spin_log2.load(), s);
+        if (sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks)) {
+            const int rc = launch_sm_stack(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, g_spin_log2.load(), s);
+            if (rc != MPL_E_UNSUPPORTED) return rc;       // fewer CUs than column tiles: the team kernels below
+            if (err_ws) *err_ws = nullptr;
+        }
     }
     if (const int np = np0) {
         if (np == 2) return block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);

@@ -384,8 +384,10 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     a.err_ws = a.bar + 32 * 17;
     a.err_host = device_error_word(dev);
     a.M = M; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
-    // every workgroup must be resident (grid barrier): at most one per CU, and no more than the widest GEMM has column tiles
-    a.n_wg = 3 * D / 16 < cus ? 3 * D / 16 : cus;
+    // every workgroup must be resident (grid barrier, ~150 KiB of LDS each: one per CU) and every column tile of the widest GEMM
+    // needs a workgroup of its own: a device with fewer CUs than that runs the team kernels instead
+    if (3 * D / 16 > cus) return MPL_E_UNSUPPORTED;
+    a.n_wg = 3 * D / 16;
     a.spin_log2 = spin_log2;
     a.eps = 1e-6f;      // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     for (int i = 0; i < MPL_MAX_APPS; ++i) a.sched[i] = i < n_apps ? schedule[i] : 0;
