@@ -350,8 +350,8 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     # teams that own two or more row tiles (more 64-row tiles than teams of D / 136 workgroups fit 256 CUs) run the two-tile stage
     pairs = a.precision == "fp32" and -(-(a.batch * a.views) // 64) > 256 // (fpt_width(flags) // 136)
     gemm_kernel = ((eng + ("_stack2_kernel" if pairs else "_stack_kernel")) if launches == 1 else (eng + "_gemm_kernel")) if split else "ln_gemm_ng_kernel"
-    small = a.precision in ("fp32", "fp32_mfma") and a.batch * a.views <= 16 and launches == 1
-    if small:       # at most 16 token rows: the small-batch engine (sm_stack.hip), exact fp32 MFMA on the whole chip
+    small = a.precision in ("fp32", "fp32_mfma") and a.batch * a.views <= 32 and launches == 1
+    if small:       # at most 32 token rows: the small-batch engine (sm_stack.hip), exact fp32 MFMA on the whole chip
         gemm_kernel, split = "sm_stack_kernel", False
     # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
     # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
@@ -413,7 +413,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                     peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     arithmetic="native fp32 MFMA")
     if small:
-        # at most 16 token rows: 2 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
+        # at most 32 token rows: 2-4 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
         # and is bounded by that and by its 65 grid barriers, not by the matrix pipe
         gbs = alg_bytes * gemms / launches / (avg_launch_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x4_f32", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,

@@ -301,7 +301,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
-    // at most 16 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
+    // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 / fp32x3 request keeps its engine
     if ((np0 == 0 || np0 == 2) && sm_stack_enabled() && n_apps <= MPL_MAX_APPS) {
         int n_blocks = 0;
@@ -385,7 +385,7 @@ inline void clear_stale_hip_error() { (void)hipGetLastError(); }
 // either engine may run the stack (the binding decides by the operands it supplies): size for the larger layout
 size_t stack_ws_bytes(size_t M, size_t D, int n_tok) {
     size_t b = carve_stack_ws(nullptr, M, D).bytes;
-    if (M <= 16) {
+    if (M <= (size_t)sm_stack_max_rows()) {
         const size_t bs = sm_stack_ws_bytes((int)M, (int)D);
         b = bs > b ? bs : b;
     }

@@ -193,6 +193,7 @@ bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks);
 bool sm_stack_enabled();
 void sm_stack_disable(int off);            // A/B switch (mpl_x3_stack_mode bit 3)
 size_t sm_stack_ws_bytes(int M, int D);
+int sm_stack_max_rows();
 int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps,
                     void* ws, size_t ws_bytes, const unsigned** err_ws, int spin_log2, hipStream_t s);
 int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, hipStream_t s);

@@ -1,4 +1,4 @@
-// Block stack for SMALL batches (round 4): at most 16 token rows (B V <= 16: a single frame, a few frames).
+// Block stack for SMALL batches (round 4): at most 32 token rows (B V <= 32: a single frame, a few frames / persons).
 //
 // Reference ops (MPL/lib/models/multiview_mpl.py): the `for blk in self.blocks` loop :420-423 -- Block.forward :84-92
 // (x += proj(attn(qkv(norm1(x)))); x += fc2(gelu(fc1(norm2(x))))), Attention.forward :55-64, Mlp.forward :31-37.
@@ -15,7 +15,8 @@
 //     not depend on anybody, the tile of the NEXT GEMM is requested BEFORE the grid barrier: its latency (HBM / Infinity Cache:
 //     all 114 MB are touched once per forward) hides behind the barrier;
 //   * the four waves split K (wave w takes the k steps u = w mod 4, exactly the pieces it requested itself: its own counted
-//     wait, no workgroup barrier for the weights), the A fragments (the <= 16 rows of x / att / hid, L2 resident) are requested
+//     wait, no workgroup barrier for the weights), the A fragments (one or two 16-row tiles of x / att / hid against every weight
+//     fragment) are requested
 //     together up front, LayerNorm statistics are reduced across the waves through LDS (two-pass, the row values stay in
 //     registers), the four partial accumulators are added in a fixed order, wave 0 applies the epilogue.
 // Arithmetic: exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32 = an fmaf chain per output), exact-erf GELU, fp32 softmax:
@@ -35,12 +36,17 @@
 namespace mpl {
 
 constexpr int SM_MAX_BLOCKS = 24;
-constexpr int SM_MAX_ROWS = 16;
+constexpr int SM_MAX_MT = 2;        // 16-row MFMA tiles of token rows per launch.  (Four were built and measured: every one of the N / 16 workgroups
+                                    // of a GEMM reads ALL of A past its L1 -- 102 x 139 KB per qkv at 64 rows -- and a further row tile costs +2.5 us
+                                    // per step: 0.59-0.62 ms per stack at 32 rows, 0.79 at 48, 0.90-0.93 at 64 against 0.80-0.83 for the team kernels.)
+constexpr int SM_MAX_ROWS = 16 * SM_MAX_MT;
 constexpr int SM_MAX_TOK = 16;
 constexpr int SM_UMAX = 17;      // k steps of 16 a wave holds as A fragments at a time: K <= 1088 in one go (LayerNorm GEMMs: K = D)
-constexpr int SM_LDS_W = 144 * 1024;            // weight tiles (two buffers when they fit); 16 x K x 4 B each
-constexpr int SM_LDS_X = SM_LDS_W;              // exchange area: LayerNorm partials [4][16], accumulators [4][256]
-constexpr int SM_LDS_BYTES = SM_LDS_X + 4 * 1024 + 512;
+constexpr int SM_LDS_W = 136 * 1024;            // weight tiles (two buffers when they fit); 16 x K x 4 B each
+constexpr int SM_LDS_X = SM_LDS_W;              // exchange area: accumulators [row tile][4 waves][256] | LayerNorm partials [row tile][4][16]
+constexpr int SM_LDS_RED = SM_LDS_X + SM_MAX_MT * 4 * 1024;
+constexpr int SM_LDS_FAIL = SM_LDS_RED + SM_MAX_MT * 256 + 256;
+constexpr int SM_LDS_BYTES = SM_LDS_FAIL + 256;
 
 struct SmBlock {
     const float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
@@ -60,6 +66,7 @@ bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks) {
            n_blocks <= SM_MAX_BLOCKS;
 }
 constexpr int SM_BAR_WORDS = 32 * 17 + 32;    // 8 group counters, 8 generation words, the top counter (128 bytes apart), the error word
+int sm_stack_max_rows() { return SM_MAX_ROWS; }
 size_t sm_stack_ws_bytes(int M, int D) { return ((size_t)M * 6 * D + SM_BAR_WORDS) * sizeof(float) + 256; }
 
 enum { SM_EPI_STORE = 0, SM_EPI_GELU = 1, SM_EPI_RES = 2 };
@@ -68,6 +75,8 @@ enum { SM_EPI_STORE = 0, SM_EPI_GELU = 1, SM_EPI_RES = 2 };
 // visibility": write-through `sc0 sc1` stores AND L1-bypassing `sc1` loads on both sides, the arrival behind a drained store
 // queue) instead of an agent release + acquire per barrier (buffer_wbl2 + buffer_inv: ~3.4 us of the ~9.7 us a step took with
 // them): a workgroup writes 1 KiB per step, so the per-store price of write-through is nothing here.
+// (Measured and not kept: ONE agent-scope invalidate (`buffer_inv sc1`) behind every grid barrier + plain cacheable loads, so that the
+// workgroups of an XCD would share one fetch of A through their L2: +2.3 us per step at 16 rows, nothing gained at 32-64.)
 typedef unsigned sm_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sm_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -156,25 +165,33 @@ __device__ __forceinline__ bool sm_grid_sync(const SmArgs& a, char* smem, unsign
     return *s_fail == 0u;
 }
 
-// One 16-column tile of  C = epi( LN?(A) . W^T + bias ), M <= 16 rows: the four waves split K, wave 0 finishes.  The weight tile
-// `cur` was requested earlier (by this same wave for its own k steps: its own wait covers them); `next` is requested by the
-// waves 1..3 as soon as the workgroup is done with the multiply-adds (wave 0's share: sm_grid_sync).
-template <int EPI, bool LN>
+// One 16-column tile of  C = epi( LN?(A) . W^T + bias ), M <= 16 MT rows (MT row tiles of 16 against every weight fragment): the
+// four waves split K, wave 0 finishes.  The weight tile `cur` was requested earlier (by this same wave for its own k steps: its
+// own wait covers them); `next` is requested by the waves 1..3 as soon as the workgroup is done with the multiply-adds (wave 0's
+// share: sm_grid_sync).  The arithmetic of a row does not depend on MT (same k split, same order of additions).
+template <int EPI, bool LN, int MT>
 __device__ __forceinline__ void sm_tile(char* smem, const SmTile& cur, const SmTile& next, const float* __restrict__ A, int lda,
                                         const float* __restrict__ g, const float* __restrict__ be, float eps, const float* __restrict__ bias,
                                         float* __restrict__ C, int ldc, int M, int N, int wave, int lane) {
     const int li = lane & 15, kq = lane >> 4;
     const int K = cur.K;
     const bool active = cur.on;
-    float* xch = reinterpret_cast<float*>(smem + SM_LDS_X);          // [4 waves][256]
-    float* red = xch + 4 * 256;                                      // [4 waves][16] LayerNorm partials
-    const int row = li < M ? li : M - 1;
-    const unsigned ao = (unsigned)(row * lda + 4 * kq);              // A was written by other workgroups of this launch: sm_ld4
+    float* xch = reinterpret_cast<float*>(smem + SM_LDS_X);          // [MT][4 waves][256]
+    float* red = reinterpret_cast<float*>(smem + SM_LDS_RED);        // [MT][4 waves][16] LayerNorm partials
+    unsigned ao[MT];                                                 // A was written by other workgroups of this launch: sm_ld4
+#pragma unroll
+    for (int rt = 0; rt < MT; ++rt) {
+        const int row = 16 * rt + li < M ? 16 * rt + li : M - 1;
+        ao[rt] = (unsigned)(row * lda + 4 * kq);
+    }
     const int nu_all = (K / 16 - wave + 3) / 4;                      // k steps of this wave
     const int nu = nu_all < SM_UMAX ? nu_all : SM_UMAX;              // ... of the first go (all of them unless K > 1088: fc2 at D = 1088)
-    float4 a4[SM_UMAX];
+    float4 a4[MT][SM_UMAX];
 #pragma unroll
-    for (int i = 0; i < SM_UMAX; ++i) a4[i] = (i < nu && active) ? sm_ld4(A, ao + 16 * (wave + 4 * i)) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+        for (int i = 0; i < SM_UMAX; ++i)
+            a4[rt][i] = (i < nu && active) ? sm_ld4(A, ao[rt] + 16 * (wave + 4 * i)) : float4{0.f, 0.f, 0.f, 0.f};
     // everything else the step will need from memory is requested NOW, beside the A fragments (one memory round trip for the whole
     // step instead of three dependent ones): the LayerNorm gain / offset of this lane's columns, wave 0's bias and residual values
     float4 g4[LN ? SM_UMAX : 1], b4[LN ? SM_UMAX : 1];
@@ -186,86 +203,129 @@ __device__ __forceinline__ void sm_tile(char* smem, const SmTile& cur, const SmT
             b4[i] = (i < nu && active) ? ld4(be + k) : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    float bn = 0.f, rsd[4] = {0.f, 0.f, 0.f, 0.f};
+    float bn = 0.f, rsd[MT][4];
+#pragma unroll
+    for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsd[rt][r] = 0.f;
     if (wave == 0 && active) {
         bn = bias[cur.n0 + li];
         if (EPI == SM_EPI_RES) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)     // this workgroup's own columns of x (or the SPT kernel's rows)
-                rsd[r] = 4 * kq + r < M ? sm_ld1(C, (unsigned)((4 * kq + r) * ldc + cur.n0 + li)) : 0.f;
+            for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // this workgroup's own columns of x (or the SPT kernel's rows)
+                    const int m = 16 * rt + 4 * kq + r;
+                    rsd[rt][r] = m < M ? sm_ld1(C, (unsigned)(m * ldc + cur.n0 + li)) : 0.f;
+                }
         }
     }
     if (LN) {
         // two-pass statistics of the row over ALL K columns: this lane holds 1/16 of the row (its kq quarter of its wave's k steps)
-        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < SM_UMAX; ++i) s += (a4[i].x + a4[i].y) + (a4[i].z + a4[i].w);
-        s = xor32_add(xor16_add(s));
-        if (kq == 0) red[wave * 16 + li] = s;
-        __syncthreads();
-        const float mean = ((red[li] + red[16 + li]) + (red[32 + li] + red[48 + li])) / (float)K;
-        __syncthreads();
-        float q = 0.f;
+        for (int rt = 0; rt < MT; ++rt) {
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < SM_UMAX; ++i)
-            if (i < nu) {
-                const float d0 = a4[i].x - mean, d1 = a4[i].y - mean, d2 = a4[i].z - mean, d3 = a4[i].w - mean;
-                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-        q = xor32_add(xor16_add(q));
-        if (kq == 0) red[wave * 16 + li] = q;
+            for (int i = 0; i < SM_UMAX; ++i) s += (a4[rt][i].x + a4[rt][i].y) + (a4[rt][i].z + a4[rt][i].w);
+            s = xor32_add(xor16_add(s));
+            if (kq == 0) red[(rt * 4 + wave) * 16 + li] = s;
+        }
         __syncthreads();
-        const float rstd = 1.0f / sqrtf(((red[li] + red[16 + li]) + (red[32 + li] + red[48 + li])) / (float)K + eps);
-        const float sh = -mean * rstd;
+        float mean[MT];
 #pragma unroll
-        for (int i = 0; i < SM_UMAX; ++i)
-            if (i < nu) {
-                a4[i].x = fmaf(fmaf(a4[i].x, rstd, sh), g4[i].x, b4[i].x);
-                a4[i].y = fmaf(fmaf(a4[i].y, rstd, sh), g4[i].y, b4[i].y);
-                a4[i].z = fmaf(fmaf(a4[i].z, rstd, sh), g4[i].z, b4[i].z);
-                a4[i].w = fmaf(fmaf(a4[i].w, rstd, sh), g4[i].w, b4[i].w);
-            }
+        for (int rt = 0; rt < MT; ++rt) {
+            const float* rr = red + rt * 64;
+            mean[rt] = ((rr[li] + rr[16 + li]) + (rr[32 + li] + rr[48 + li])) / (float)K;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < MT; ++rt) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < SM_UMAX; ++i)
+                if (i < nu) {
+                    const float d0 = a4[rt][i].x - mean[rt], d1 = a4[rt][i].y - mean[rt], d2 = a4[rt][i].z - mean[rt], d3 = a4[rt][i].w - mean[rt];
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            q = xor32_add(xor16_add(q));
+            if (kq == 0) red[(rt * 4 + wave) * 16 + li] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < MT; ++rt) {
+            const float* rr = red + rt * 64;
+            const float rstd = 1.0f / sqrtf(((rr[li] + rr[16 + li]) + (rr[32 + li] + rr[48 + li])) / (float)K + eps);
+            const float sh = -mean[rt] * rstd;
+#pragma unroll
+            for (int i = 0; i < SM_UMAX; ++i)
+                if (i < nu) {
+                    a4[rt][i].x = fmaf(fmaf(a4[rt][i].x, rstd, sh), g4[i].x, b4[i].x);
+                    a4[rt][i].y = fmaf(fmaf(a4[rt][i].y, rstd, sh), g4[i].y, b4[i].y);
+                    a4[rt][i].z = fmaf(fmaf(a4[rt][i].z, rstd, sh), g4[i].z, b4[i].z);
+                    a4[rt][i].w = fmaf(fmaf(a4[rt][i].w, rstd, sh), g4[i].w, b4[i].w);
+                }
+        }
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int rt = 0; rt < MT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (active) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's weight pieces (its own requests) have landed
         const float4* wf = reinterpret_cast<const float4*>(smem + cur.buf) + lane;
 #pragma unroll
         for (int i = 0; i < SM_UMAX; ++i)
-            if (i < nu) acc = mfma16_k16(a4[i], wf[(wave + 4 * i) * 64], acc);
+            if (i < nu) {
+                const float4 w = wf[(wave + 4 * i) * 64];
+#pragma unroll
+                for (int rt = 0; rt < MT; ++rt) acc[rt] = mfma16_k16(a4[rt][i], w, acc[rt]);
+            }
         for (int i0 = SM_UMAX; i0 < nu_all; i0 += SM_UMAX) {        // K > 1088 (never a LayerNorm GEMM): the rest in further goes
 #pragma unroll
-            for (int i = 0; i < SM_UMAX; ++i) a4[i] = (i0 + i < nu_all) ? sm_ld4(A, ao + 16 * (wave + 4 * (i0 + i))) : float4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+                for (int i = 0; i < SM_UMAX; ++i)
+                    a4[rt][i] = (i0 + i < nu_all) ? sm_ld4(A, ao[rt] + 16 * (wave + 4 * (i0 + i))) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < SM_UMAX; ++i)
-                if (i0 + i < nu_all) acc = mfma16_k16(a4[i], wf[(wave + 4 * (i0 + i)) * 64], acc);
+                if (i0 + i < nu_all) {
+                    const float4 w = wf[(wave + 4 * (i0 + i)) * 64];
+#pragma unroll
+                    for (int rt = 0; rt < MT; ++rt) acc[rt] = mfma16_k16(a4[rt][i], w, acc[rt]);
+                }
         }
     }
     // the four K quarters, added in a fixed order by wave 0
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xch[wave * 256 + r * 64 + lane] = acc[r];
+    for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(rt * 4 + wave) * 256 + r * 64 + lane] = acc[rt][r];
     __syncthreads();                                                 // every wave is done with the tile in LDS, too
     if (wave != 0) sm_request_w(smem, next, wave, li, kq);
     if (wave == 0 && active) {
         const int n = cur.n0 + li;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 4 * kq + r;                                // D[row = 4 kq + r][col = li]
-            float v = ((xch[r * 64 + lane] + xch[256 + r * 64 + lane]) + (xch[512 + r * 64 + lane] + xch[768 + r * 64 + lane])) + bn;
-            if (EPI == SM_EPI_GELU) v = gelu_erf(v);
-            if (m < M) {
-                const unsigned co = (unsigned)(m * ldc + n);
-                if (EPI == SM_EPI_RES) v += rsd[r];
-                sm_st1(C, co, v);
+        for (int rt = 0; rt < MT; ++rt) {
+            const float* xr = xch + rt * 1024;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * rt + 4 * kq + r;                  // D[row = 4 kq + r][col = li] of row tile rt
+                float v = ((xr[r * 64 + lane] + xr[256 + r * 64 + lane]) + (xr[512 + r * 64 + lane] + xr[768 + r * 64 + lane])) + bn;
+                if (EPI == SM_EPI_GELU) v = gelu_erf(v);
+                if (m < M) {
+                    const unsigned co = (unsigned)(m * ldc + n);
+                    if (EPI == SM_EPI_RES) v += rsd[rt][r];
+                    sm_st1(C, co, v);
+                }
             }
         }
     }
 }
 
+template <int MT>
 __global__ __launch_bounds__(256) void sm_stack_kernel(const SmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float (*S)[SM_MAX_TOK + 1] = reinterpret_cast<float (*)[SM_MAX_TOK + 1]>(smem + SM_LDS_X);      // attention scores (between GEMMs)
-    volatile unsigned* s_fail = reinterpret_cast<volatile unsigned*>(smem + SM_LDS_X + 4 * 1024 + 256);
+    volatile unsigned* s_fail = reinterpret_cast<volatile unsigned*>(smem + SM_LDS_FAIL);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -294,7 +354,7 @@ __global__ __launch_bounds__(256) void sm_stack_kernel(const SmArgs a) {
             t_fc2{b.fc2_w, 2 * D, 16 * t, b_fc2, has_d};
         const SmTile t_nq{more ? a.blk[a.sched[app + 1]].qkv_w : nullptr, D, 16 * t, b_lo, more && has_qkv};
         // ---- qkv = norm1(x) . Wqkv^T + b                                            (Attention.forward :55)
-        sm_tile<SM_EPI_STORE, true>(smem, t_qkv, t_proj, a.x, D, b.ln1_w, b.ln1_b, a.eps, b.qkv_b, a.qkv, 3 * D, M, 3 * D, wave, lane);
+        sm_tile<SM_EPI_STORE, true, MT>(smem, t_qkv, t_proj, a.x, D, b.ln1_w, b.ln1_b, a.eps, b.qkv_b, a.qkv, 3 * D, M, 3 * D, wave, lane);
         if (!sm_grid_sync(a, smem, target, tid, s_fail, t_proj, false)) return;
         // ---- attention, one (sequence, head) at a time                              (:56-64)
         {
@@ -347,14 +407,14 @@ __global__ __launch_bounds__(256) void sm_stack_kernel(const SmArgs a) {
         }
         if (!sm_grid_sync(a, smem, target, tid, s_fail, none, true)) return;
         // ---- x += att . Wproj^T + b                                                 (:65, Block.forward :90)
-        sm_tile<SM_EPI_RES, false>(smem, t_proj, t_fc1, a.att, D, nullptr, nullptr, 0.f, b.proj_b, a.x, D, M, D, wave, lane);
+        sm_tile<SM_EPI_RES, false, MT>(smem, t_proj, t_fc1, a.att, D, nullptr, nullptr, 0.f, b.proj_b, a.x, D, M, D, wave, lane);
         if (!sm_grid_sync(a, smem, target, tid, s_fail, t_fc1, false)) return;
         // ---- hid = gelu(norm2(x) . W1^T + b)                                        (Mlp.forward :32-33)
-        sm_tile<SM_EPI_GELU, true>(smem, t_fc1, roomy ? t_fc2 : none, a.x, D, b.ln2_w, b.ln2_b, a.eps, b.fc1_b, a.hid, 2 * D, M, 2 * D, wave, lane);
+        sm_tile<SM_EPI_GELU, true, MT>(smem, t_fc1, roomy ? t_fc2 : none, a.x, D, b.ln2_w, b.ln2_b, a.eps, b.fc1_b, a.hid, 2 * D, M, 2 * D, wave, lane);
         if (!sm_grid_sync(a, smem, target, tid, s_fail, roomy ? t_fc2 : none, false)) return;
         // ---- x += hid . W2^T + b                                                    (:35, Block.forward :91)
         if (!roomy) sm_request_w(smem, t_fc2, wave, li, kq);
-        sm_tile<SM_EPI_RES, false>(smem, t_fc2, t_nq, a.hid, 2 * D, nullptr, nullptr, 0.f, b.fc2_b, a.x, D, M, D, wave, lane);
+        sm_tile<SM_EPI_RES, false, MT>(smem, t_fc2, t_nq, a.hid, 2 * D, nullptr, nullptr, 0.f, b.fc2_b, a.x, D, M, D, wave, lane);
         if (!sm_grid_sync(a, smem, target, tid, s_fail, t_nq, false)) return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -400,11 +460,14 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     }
     if (err_ws) *err_ws = a.err_ws;
     if (int rc = refuse_stream_capture(s)) return rc;
-    static std::atomic<bool> attr_set[64];
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)sm_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES) != hipSuccess)
+    // row tiles of 16 per weight fragment: 1 or 2 (two instantiations; the result of a row does not depend on the choice)
+    const int mi = M <= 16 ? 0 : 1;
+    void (*kernel)(const SmArgs) = mi == 0 ? sm_stack_kernel<1> : sm_stack_kernel<2>;
+    static std::atomic<bool> attr_set[64][2];
+    if (!attr_set[dev][mi].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES) != hipSuccess)
             return MPL_E_LAUNCH;
-        attr_set[dev].store(true, std::memory_order_release);
+        attr_set[dev][mi].store(true, std::memory_order_release);
     }
     if (hipMemsetAsync(a.bar, 0, SM_BAR_WORDS * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     // a grid barrier needs the chip like the team kernels do: serialised with them per device (api.hip)
@@ -415,7 +478,7 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     int rc;
     {
         ProfScope prof(MPL_K_GEMM, s);
-        hipLaunchKernelGGL(sm_stack_kernel, dim3(a.n_wg), dim3(256), SM_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(kernel, dim3(a.n_wg), dim3(256), SM_LDS_BYTES, s, a);
         rc = hip_check_launch();
     }
     if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;

@@ -150,9 +150,9 @@ def test_forward_matches_reference_golden(name):
     ref = torch.from_numpy(g["out"])
     mx, nw = _assert_close(out, ref, name)
     print("%s: max-scaled %.2e norm-wise %.2e MPJPE-vs-ref %.3e" % (name, mx, nw, mpl_oracle.mpjpe(out.cpu(), ref)))
-    # fixtures of at most 16 token rows run the small-batch engine (sm_stack.hip) by default: the team kernels must reproduce
+    # fixtures of at most 32 token rows run the small-batch engine (sm_stack.hip) by default: the team kernels must reproduce
     # the same golden
-    if g["meta"]["batch"] * g["flags"]["num_views"] <= 16:
+    if g["meta"]["batch"] * g["flags"]["num_views"] <= 32:
         lib = cabi.load()
         try:
             cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")

@@ -344,16 +344,18 @@ def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
 
 @pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 1), ("chosen_v2_b1_l12", 8), ("full_v2_b1_l12", 1), ("full_v2_b1_l12", 7),
                                     ("chosen_v4_b8_l12", 4), ("full_v4_b8_l2", 3), ("chosen_v5_b19_l2", 3), ("chosen_v8_b4_l2", 2),
-                                    ("chosen_v4_b8_l2", 1)])
+                                    ("chosen_v4_b8_l2", 1), ("chosen_v4_b8_l12", 8), ("chosen_v4_b8_l2", 7), ("chosen_v2_b1_l12", 13),
+                                    ("chosen_v2_b1_l12", 16), ("full_v4_b8_l2", 8), ("full_v2_b1_l12", 13), ("chosen_v5_b19_l2", 6),
+                                    ("chosen_v8_b4_l2", 4), ("chosen_v8_b4_l2", 3)])
 def test_small_batch_engine(name, B):
-    """At most 16 token rows (a single frame, a few frames) run sm_stack.hip: every GEMM of the block stack on the whole chip
+    """At most 32 token rows (a single frame, a few frames / persons) run sm_stack.hip: every GEMM of the block stack on the whole chip
     (one 16-column tile per workgroup, the nn.Linear weights read in place, exact fp32 on the matrix cores), grid barriers in between,
     instead of one team of D / 136 workgroups.  Checked against the fp64 oracle, against the team kernels on the same inputs (two
     fp32 engines: rounding noise apart), and for batch invariance inside the engine (bitwise)."""
     lib = cabi.load()
     m, g = _model(name)
     V = g["flags"]["num_views"]
-    assert B * V <= 16
+    assert B * V <= 32
     P, R, Cn = _big_inputs(B, V, 321)
     with torch.no_grad():
         out, k = _kinds(lambda: m(P, rays=R, centers=Cn))

@@ -7,7 +7,7 @@ from bench import build_model, make_batch, model_flags  # noqa: E402
 from openmpl_amd import cabi  # noqa: E402
 dev = torch.device("cuda", 0)
 lib = cabi.load()
-for fs, V, Bs in (("chosen", 2, (1, 4, 8)), ("chosen", 4, (1, 4)), ("full", 4, (1, 4)), ("chosen", 8, (1, 2))):
+for fs, V, Bs in (("chosen", 2, (1, 8, 16, 32)), ("chosen", 4, (1, 4, 8, 12, 16)), ("full", 4, (1, 4, 8)), ("chosen", 8, (1, 2, 8))):
     m = build_model(model_flags(fs, V, 12), dev)
     for B in Bs:
         b = [make_batch(B, V, dev, seed=B, step=s) for s in range(2)]

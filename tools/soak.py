@@ -17,7 +17,7 @@ for flags, B in ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024)
                  (dict(num_views=8, depth=2, pose_3d_emb_learnable=True), 1000),       # 125 row tiles: pairs, the last one half empty
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True), 8190),       # four pairs per team, ragged last tile
                  (dict(num_views=5, depth=2, pose_3d_emb_learnable=True), 333),
-                 (dict(num_views=2, depth=12, pose_3d_emb_learnable=True), 1),         # <= 16 token rows: the small-batch engine (sm_stack.hip)
+                 (dict(num_views=2, depth=12, pose_3d_emb_learnable=True), 1),         # <= 32 token rows: the small-batch engine (sm_stack.hip)
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True, confidence_input_as_third=True, input_rays_as_token=True,
                        multiple_spatial_blocks=True, add_3D_pos_encoding_to_rays=True), 4),
                  (dict(num_views=8, depth=12, pose_3d_emb_learnable=True), 2),
