@@ -49,6 +49,7 @@ struct SptParams {
     int B, V, in_ch, n_apps;
     unsigned flags;
     int c3;  // channel count of the pos_3d_* tensors (d or 2d)
+    int spw;  // sequences per workgroup (spt_kernel: 1..16, few sequences spread over the chip; spt3_kernel: always SEQ)
     int abl;  // bench-only ablation mask (MPL_SPT_ABL): 1 no attention, 2 no GELU, 4 no MFMA phases, 8 no epilogue math
     unsigned char sched[MPL_MAX_APPS];  // layer | weighted << 7
 };
@@ -141,6 +142,61 @@ __device__ __forceinline__ void load_fc2_frags(const mpl_block_weights& bw, Bloc
     }
 }
 
+// ---- the same fragments from a block STAGED in LDS (spt_kernel<true>: few sequences per workgroup).  A staged block is 32 1-KiB
+// pieces in fragment order -- qkv: piece 2 n + h = W[16 n + li][16 h + 4 kq ..]; proj 12 + 2 n + h; fc1 16 + 2 n + h; fc2
+// 24 + 4 n + q -- and, from float SPT_WB_VEC on, the vectors qkv_b[96] | proj_b[32] | fc1_b[64] | fc2_b[32] | ln1_w | ln1_b |
+// ln2_w | ln2_b (32 each).
+constexpr int SPT_WB_VEC = 8192;                 // floats
+constexpr int SPT_WB_FLOATS = SPT_WB_VEC + 512;  // one staged block
+constexpr int SPT_SMALL_ROWS = 144;              // token rows of the staged form: up to 8 sequences (136 rows) per workgroup
+constexpr int SPT_SMALL_SPW = 8;
+constexpr int SPT_SMALL_LDS_BYTES = (SPT_SMALL_ROWS * (XS + QS) + 2 * SPT_WB_FLOATS) * 4;   // 147968
+// Staging is LDS-DMA with per-lane source addresses, pieces 0..31 weights, 32 / 33 the vectors; the waves w0 .. w0 + nw - 1 share them
+// round robin.  What it costs is the rate at which the CU's address path accepts requests: ~60 cycles per piece in fragment order (16
+// half-used lines; ~40 for a contiguous KiB), and a wave stands in its request until it is accepted -- 2100 cycles per wave and
+// application when all eight waves request at the head of an application.  The requests are therefore made by the waves the attention
+// phase leaves idle (17 nl x 8 (row, head) pairs: 136 threads at one sequence per workgroup).  Measured and not kept: ordinary 16-byte
+// loads into registers at the head of the application, written to LDS three phases later (the loads queue up in the same address path:
+// 3150 cycles); contiguous pieces from a packed copy (1330 cycles when everybody requests: not worth a second derived operand).
+__device__ __forceinline__ const float* spt_uniform(const float* q) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void stage_block(const mpl_block_weights& bwv, float* wb, int wave, int lane, int w0, int nw) {
+    if (wave < w0 || wave >= w0 + nw) return;
+    const int li = lane & 15, kq = lane >> 4;
+    // The pointers came by vector loads: ALL of them into scalar registers first.  Left in vector registers the compiler puts a
+    // vmcnt(0) in front of every use behind an opaque DMA statement -- i.e. waits for the previous piece's trip to memory, piece by piece.
+    struct { const float *qkv_w, *proj_w, *fc1_w, *fc2_w, *qkv_b, *proj_b, *fc1_b, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b; } bw;
+    bw.qkv_w = spt_uniform(bwv.qkv_w); bw.proj_w = spt_uniform(bwv.proj_w); bw.fc1_w = spt_uniform(bwv.fc1_w); bw.fc2_w = spt_uniform(bwv.fc2_w);
+    bw.qkv_b = spt_uniform(bwv.qkv_b); bw.proj_b = spt_uniform(bwv.proj_b); bw.fc1_b = spt_uniform(bwv.fc1_b); bw.fc2_b = spt_uniform(bwv.fc2_b);
+    bw.ln1_w = spt_uniform(bwv.ln1_w); bw.ln1_b = spt_uniform(bwv.ln1_b); bw.ln2_w = spt_uniform(bwv.ln2_w); bw.ln2_b = spt_uniform(bwv.ln2_b);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wb);
+    for (int pc = wave - w0; pc < 34; pc += nw) {
+        const float* src;
+        bool on = true;
+        if (pc < 12) src = bw.qkv_w + ((pc >> 1) * 16 + li) * SD + 16 * (pc & 1) + 4 * kq;
+        else if (pc < 16) src = bw.proj_w + (((pc - 12) >> 1) * 16 + li) * SD + 16 * (pc & 1) + 4 * kq;
+        else if (pc < 24) src = bw.fc1_w + (((pc - 16) >> 1) * 16 + li) * SD + 16 * (pc & 1) + 4 * kq;
+        else if (pc < 32) src = bw.fc2_w + (((pc - 24) >> 2) * 16 + li) * (2 * SD) + 16 * (pc & 3) + 4 * kq;
+        else if (pc == 32)
+            src = lane < 24 ? bw.qkv_b + 4 * lane
+                : lane < 32 ? bw.proj_b + 4 * (lane - 24)
+                : lane < 48 ? bw.fc1_b + 4 * (lane - 32)
+                : lane < 56 ? bw.fc2_b + 4 * (lane - 48) : bw.ln1_w + 4 * (lane - 56);
+        else {
+            src = lane < 8 ? bw.ln1_b + 4 * lane : lane < 16 ? bw.ln2_w + 4 * (lane - 8) : bw.ln2_b + 4 * (lane - 16);
+            on = lane < 24;
+        }
+        if (on) dma16(src, lds0 + (unsigned)(pc * 1024));
+    }
+}
+__device__ __forceinline__ float4 wb4(const float* wb, int piece, int lane) { return *reinterpret_cast<const float4*>(wb + piece * 256 + lane * 4); }
+// Fragments are read ON DEMAND, tile by tile (a wave owns one or two output tiles of a phase; eight waves reading all fragments of a
+// phase into registers were 96 KiB of LDS traffic per qkv phase).
+__device__ __forceinline__ float4 wbv4(const float* wb, int off, int kq) { return *reinterpret_cast<const float4*>(wb + SPT_WB_VEC + off + 4 * kq); }
+
 // "Touch" prefetched fragments: an empty asm that reads them makes hipcc place their s_waitcnt HERE.  Every phase
 // first touches the fragments it is about to use (they were loaded at least one phase earlier, so the wait is
 // free) and only then issues the next prefetch -- otherwise the compiler's vmcnt(0) in front of the first MFMA
@@ -175,14 +231,14 @@ __device__ __forceinline__ void row_to_sj(int r, int& sq, int& j) {
 // joint embedding (:355-396) of the workgroup's 16 sequences -> X
 template <bool TM>
 __device__ __forceinline__ void spt_embed(const SptParams& p, const mpl_spt_set& set, float* X, int tid, int b0,
-                                          const float* pose, const float* ray, const float* cen) {
-    for (int idx = tid; idx < ROWS * SD; idx += NTHR) {
+                                          const float* pose, const float* ray, const float* cen, int nseq = SEQ, int nrows = ROWS) {
+    for (int idx = tid; idx < nrows * SD; idx += NTHR) {
         const int r = idx >> 5, c = idx & 31;
         int sq, j;
         row_to_sj<TM>(r, sq, j);
         const int b = b0 + sq;
         float x = 0.f;
-        if (b < p.B) {
+        if (b < p.B && sq < nseq) {
             const float* in = pose + ((size_t)b * SJ + j) * 3;
             const float* we = set.embed_w + c * p.in_ch;
             x = set.embed_b[c] + we[0] * in[0] + we[1] * in[1];
@@ -210,17 +266,17 @@ __device__ __forceinline__ void spt_embed(const SptParams& p, const mpl_spt_set&
 // Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...]
 template <bool TM>
 __device__ __forceinline__ void spt_epilogue(const SptParams& p, const float* X, int tid, int view, int b0, const float* pose,
-                                             const float* ray, const float* cen) {
+                                             const float* ray, const float* cen, int nseq = SEQ, int nrows = ROWS) {
     // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
     const bool to_rays = (p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);   // feature concat (:469-471)
     const bool ray_tok = !(p.flags & MPL_F_POS3D_TO_RAYS) && (p.flags & MPL_F_RAYS_TOKEN);  // token concat (:486-489)
     const int cw = to_rays ? 2 * SD : SD;                 // channels per joint in the output row
     const int Df = SJ * SD * ((p.flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
-    for (int r = tid; r < ROWS; r += NTHR) {
+    for (int r = tid; r < nrows; r += NTHR) {
         int sq, j;
         row_to_sj<TM>(r, sq, j);
         const int b = b0 + sq;
-        if (b >= p.B) continue;
+        if (b >= p.B || sq >= nseq) continue;
         const float* xr = X + r * XS;
         float v[SD];
         float s = 0.f;
@@ -289,30 +345,61 @@ __device__ __forceinline__ void spt_epilogue(const SptParams& p, const float* X,
     }
 }
 
+// STAGED = false: the weights of a phase come straight from global memory into registers, requested one phase ahead (a phase
+// over 17 row tiles is longer than the trip).  STAGED = true (at most SPT_SMALL_SPW sequences per workgroup): with 2-9 row tiles
+// a phase is SHORTER than the trip to L2 / HBM (measured: 134 us per launch with the one-phase-ahead scheme at one sequence per
+// workgroup, i.e. 2 us = one memory round trip per phase), so the whole block of the NEXT application is staged in LDS by LDS-DMA
+// while the current one computes (32 KiB + vectors, two buffers in the LDS the missing rows leave free) and a phase reads its
+// fragments from there.  The arithmetic of a row is the same instruction sequence in both forms.
+template <bool STAGED>
 __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;
-    float* Q = smem + ROWS * XS;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int RX = STAGED ? SPT_SMALL_ROWS : ROWS;
+    float* WB = smem;                                   // STAGED: two staged blocks in front (1-KiB aligned pieces)
+    float* X = smem + (STAGED ? 2 * SPT_WB_FLOATS : 0);
+    float* Q = X + RX * XS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int view = blockIdx.x % p.V;
-    const int b0 = (blockIdx.x / p.V) * SEQ;
+    const int b0 = (blockIdx.x / p.V) * p.spw;
     const mpl_spt_set set = p.sets[(p.flags & MPL_F_MULTI_SPT) ? view : 0];
     const float* pose = p.poses[view];
     const float* ray = p.rays[view];
     const float* cen = p.centers[view];
+    // Few sequences (B V below the 16 x CU count a full launch needs) are SPREAD: p.spw = 1 .. 16 sequences per workgroup, rows
+    // sequence-major, so the live rows are the first 17 nl and only their `mt` row tiles are walked (a single frame: one sequence
+    // = 2 row tiles per workgroup instead of 17 mostly empty ones).  The arithmetic of a row does not depend on spw.
+    const int nl = p.B - b0 < p.spw ? p.B - b0 : p.spw;
+    const int rows_live = nl * SJ;
+    const int mt = (rows_live + 15) >> 4;
 
     // weights of the first Block application: issue the loads before anything else
     BlockFrags F;
     mpl_block_weights bw, bw_next;
     if (p.n_apps > 0) {
         bw = set.blocks[p.sched[0] & 0x7f];
-        load_qkv_frags(bw, F, li, kq);
+        if (STAGED) stage_block(bw, WB, wave, lane, 0, NWAVE);
+        else load_qkv_frags(bw, F, li, kq);
+        // STAGED: the pointers of an application are fetched one application ahead of the requests that need them
+        if (STAGED && p.n_apps > 1) bw_next = set.blocks[p.sched[1] & 0x7f];
     }
 
     // ---------------- phase 0: joint embedding (:355-396) ----------------
-    spt_embed<false>(p, set, X, tid, b0, pose, ray, cen);
+    spt_embed<false>(p, set, X, tid, b0, pose, ray, cen, nl, mt * 16);
+    // STAGED: nothing inside the application loop may come by a vector load from global memory -- the compiler's vmcnt(0) in front
+    // of its use would wait for the block in flight.  The schedule bytes and the confidences of the live rows (the weighted
+    // applications, :61-62) therefore wait in the free tails of the two vector regions.
+    unsigned char* sched_l = reinterpret_cast<unsigned char*>(WB + SPT_WB_FLOATS + SPT_WB_VEC + 352);      // [MPL_MAX_APPS]
+    float* conf_l = WB + SPT_WB_VEC + 352;                                                                  // [SPT_SMALL_ROWS]
+    if (STAGED) {
+        if (tid < MPL_MAX_APPS) sched_l[tid] = p.sched[tid];
+        for (int r = tid; r < rows_live; r += NTHR) {
+            const int sq = r / SJ;
+            conf_l[r] = pose[((size_t)(b0 + sq) * SJ + (r - sq * SJ)) * 3 + 2];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the first block have landed
+    }
     __syncthreads();
 
     // ---------------- block applications (:405-410) ----------------
@@ -328,20 +415,39 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         }
     };
     for (int app = 0; app < p.n_apps; ++app) {
-        const bool weighted = (p.sched[app] & 0x80) != 0;
+        const bool weighted = ((STAGED ? sched_l[app] : p.sched[app]) & 0x80) != 0;
         const bool more = app + 1 < p.n_apps;
-        if (more) bw_next = set.blocks[p.sched[app + 1] & 0x7f];   // pointers only; used two phases later
+        if (!STAGED && more) bw_next = set.blocks[p.sched[app + 1] & 0x7f];   // pointers only; used two phases later
+        const float* wb = WB + (app & 1) * SPT_WB_FLOATS;
+        mpl_block_weights bw_after;
         // Prefetch schedule: every phase first touches its own fragments, then issues the loads of the NEXT phase
         // (proj weights during qkv, fc1 during proj, fc2 during fc1, the next application's qkv during fc2), so each
         // group has a whole phase to arrive and at most two groups are live at a time.
+        if (!STAGED) {
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { touch(F.wq[n][0]); touch(F.wq[n][1]); touch(F.bq[n]); }
-        touch(F.g1a); touch(F.g1b); touch(F.e1a); touch(F.e1b);
-        load_proj_frags(bw, F, li, kq);
+            for (int n = 0; n < 6; ++n) { touch(F.wq[n][0]); touch(F.wq[n][1]); touch(F.bq[n]); }
+            touch(F.g1a); touch(F.g1b); touch(F.e1a); touch(F.e1b);
+            load_proj_frags(bw, F, li, kq);
+        }
 
         // ---- QKV = LN1(X) . Wqkv^T + b : 17 x 6 tiles -> Q[:, 0:96]
-        {
-            const int lo = (MT * 6 * wave) / NWAVE, hi = (MT * 6 * (wave + 1)) / NWAVE;
+        if (STAGED) {
+            const int lo = (mt * 6 * wave) / NWAVE, hi = (mt * 6 * (wave + 1)) / NWAVE;
+            const float4 g0 = wbv4(wb, 224, kq), g1 = wbv4(wb, 240, kq), e0 = wbv4(wb, 256, kq), e1 = wbv4(wb, 272, kq);
+            float4 a0, a1;
+            int m_have = -1;
+            for (int u = lo; u < hi && !(p.abl & 4); ++u) {
+                const int m = u / 6, n = u - 6 * m;
+                const float4 w0 = wb4(wb, 2 * n, lane), w1 = wb4(wb, 2 * n + 1, lane);
+                const float bq = wb[SPT_WB_VEC + n * 16 + li];
+                if (m != m_have) { ln_frags(X, m, li, kq, g0, g1, e0, e1, a0, a1); m_have = m; }
+                const f32x4 c = tile_k32(a0, a1, w0, w1);
+                float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qd[r * QS] = c[r] + bq;
+            }
+        } else {
+            const int lo = (mt * 6 * wave) / NWAVE, hi = (mt * 6 * (wave + 1)) / NWAVE;
             for (int m = lo / 6; m <= (hi - 1) / 6 && !(p.abl & 4); ++m) {
                 float4 a0, a1;
                 ln_frags(X, m, li, kq, F.g1a, F.g1b, F.e1a, F.e1b, a0, a1);
@@ -359,8 +465,17 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         __syncthreads();
         stamp(0);
 
+        // STAGED: the block of the next application is requested NOW, by the waves the attention leaves idle (stage_block).  Its readers
+        // finished an application ago.
+        if (STAGED && more) {
+            const int busy = (rows_live * SH + 63) >> 6;                  // waves with attention work
+            const int w0 = busy < NWAVE - 1 ? busy : 0;
+            stage_block(bw_next, WB + ((app + 1) & 1) * SPT_WB_FLOATS, wave, lane, w0, NWAVE - w0);
+            if (app + 2 < p.n_apps) bw_after = set.blocks[sched_l[app + 2] & 0x7f];
+        }
+        stamp(5);
         // ---- attention: thread per (row, head); 17 scores in registers (:55-64)
-        for (int pr = tid; pr < ROWS * SH && !(p.abl & 1); pr += NTHR) {
+        for (int pr = tid; pr < rows_live * SH && !(p.abl & 1); pr += NTHR) {
             const int r = pr >> 3, h = pr & 7;
             const int sq = r / SJ;
             const float* kb = Q + (sq * SJ) * QS + SD + 4 * h;
@@ -382,7 +497,8 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
             float inv = 1.0f / l;
             if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales query row r
                 const int b = b0 + sq;
-                inv *= (b < p.B) ? pose[((size_t)b * SJ + (r - sq * SJ)) * 3 + 2] : 0.f;
+                if (STAGED) inv *= conf_l[r];
+                else inv *= (b < p.B) ? pose[((size_t)b * SJ + (r - sq * SJ)) * 3 + 2] : 0.f;
             }
             float4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -400,11 +516,26 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         stamp(1);
 
         // ---- X += attn_out . Wproj^T + b : 17 x 2 tiles
+        if (!STAGED) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) { touch(F.wp[n][0]); touch(F.wp[n][1]); touch(F.bp[n]); }
-        load_fc1_frags(bw, F, li, kq);
-        {
-            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            for (int n = 0; n < 2; ++n) { touch(F.wp[n][0]); touch(F.wp[n][1]); touch(F.bp[n]); }
+            load_fc1_frags(bw, F, li, kq);
+        }
+        if (STAGED) {
+            const int lo = (mt * 2 * wave) / NWAVE, hi = (mt * 2 * (wave + 1)) / NWAVE;
+            for (int u = lo; u < hi && !(p.abl & 4); ++u) {
+                const int m = u >> 1, n = u & 1;
+                const float4 w0 = wb4(wb, 12 + 2 * n, lane), w1 = wb4(wb, 12 + 2 * n + 1, lane);
+                const float bp = wb[SPT_WB_VEC + 96 + n * 16 + li];
+                const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
+                const float4 a0 = ld4(ar), a1 = ld4(ar + 16);
+                const f32x4 c = tile_k32(a0, a1, w0, w1);
+                float* xd = X + (m * 16 + 4 * kq) * XS + n * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xd[r * XS] += c[r] + bp;
+            }
+        } else {
+            const int lo = (mt * 2 * wave) / NWAVE, hi = (mt * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 4); ++m) {
                 const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
                 const float4 a0 = ld4(ar), a1 = ld4(ar + 16);
@@ -423,12 +554,29 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         stamp(2);
 
         // ---- Hid = gelu(LN2(X) . W1^T + b) : 17 x 4 tiles -> Q[:, 0:64]
+        if (!STAGED) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) { touch(F.w1[n][0]); touch(F.w1[n][1]); touch(F.b1[n]); }
-        touch(F.g2a); touch(F.g2b); touch(F.e2a); touch(F.e2b);
-        load_fc2_frags(bw, F, li, kq);
-        {
-            const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
+            for (int n = 0; n < 4; ++n) { touch(F.w1[n][0]); touch(F.w1[n][1]); touch(F.b1[n]); }
+            touch(F.g2a); touch(F.g2b); touch(F.e2a); touch(F.e2b);
+            load_fc2_frags(bw, F, li, kq);
+        }
+        if (STAGED) {
+            const int lo = (mt * 4 * wave) / NWAVE, hi = (mt * 4 * (wave + 1)) / NWAVE;
+            const float4 g0 = wbv4(wb, 288, kq), g1 = wbv4(wb, 304, kq), e0 = wbv4(wb, 320, kq), e1 = wbv4(wb, 336, kq);
+            float4 a0, a1;
+            int m_have = -1;
+            for (int u = lo; u < hi && !(p.abl & 4); ++u) {
+                const int m = u >> 2, n = u & 3;
+                const float4 w0 = wb4(wb, 16 + 2 * n, lane), w1 = wb4(wb, 16 + 2 * n + 1, lane);
+                const float b1 = wb[SPT_WB_VEC + 128 + n * 16 + li];
+                if (m != m_have) { ln_frags(X, m, li, kq, g0, g1, e0, e1, a0, a1); m_have = m; }
+                const f32x4 c = tile_k32(a0, a1, w0, w1);
+                float* qd = Q + (m * 16 + 4 * kq) * QS + n * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qd[r * QS] = (p.abl & 2) ? (c[r] + b1) : gelu_erf(c[r] + b1);
+            }
+        } else {
+            const int lo = (mt * 4 * wave) / NWAVE, hi = (mt * 4 * (wave + 1)) / NWAVE;
             for (int m = lo >> 2; m <= ((hi - 1) >> 2) && !(p.abl & 4); ++m) {
                 float4 a0, a1;
                 ln_frags(X, m, li, kq, F.g2a, F.g2b, F.e2a, F.e2b, a0, a1);
@@ -448,15 +596,31 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
         stamp(3);
 
         // ---- X += Hid . W2^T + b : K = 64, 17 x 2 tiles
+        if (!STAGED) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < 2; ++n) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) touch(F.w2[n][q]);
-            touch(F.b2[n]);
+                for (int q = 0; q < 4; ++q) touch(F.w2[n][q]);
+                touch(F.b2[n]);
+            }
+            if (more) load_qkv_frags(bw_next, F, li, kq);   // qkv fragments are long dead: next application's weights
         }
-        if (more) load_qkv_frags(bw_next, F, li, kq);   // qkv fragments are long dead: next application's weights
-        {
-            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+        if (STAGED) {
+            const int lo = (mt * 2 * wave) / NWAVE, hi = (mt * 2 * (wave + 1)) / NWAVE;
+            for (int u = lo; u < hi && !(p.abl & 4); ++u) {
+                const int m = u >> 1, n = u & 1;
+                const float4 w0 = wb4(wb, 24 + 4 * n, lane), w1 = wb4(wb, 24 + 4 * n + 1, lane), w2 = wb4(wb, 24 + 4 * n + 2, lane),
+                             w3 = wb4(wb, 24 + 4 * n + 3, lane);
+                const float b2 = wb[SPT_WB_VEC + 192 + n * 16 + li];
+                const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
+                const float4 a0 = ld4(ar), a1 = ld4(ar + 16), a2 = ld4(ar + 32), a3 = ld4(ar + 48);
+                const f32x4 c = tile_k32(a0, a1, w0, w1) + tile_k32(a2, a3, w2, w3);
+                float* xd = X + (m * 16 + 4 * kq) * XS + n * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xd[r * XS] += c[r] + b2;
+            }
+        } else {
+            const int lo = (mt * 2 * wave) / NWAVE, hi = (mt * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 4); ++m) {
                 const float* ar = Q + (m * 16 + li) * QS + 4 * kq;
                 const float4 a0 = ld4(ar), a1 = ld4(ar + 16), a2 = ld4(ar + 32), a3 = ld4(ar + 48);
@@ -471,18 +635,20 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
                 }
             }
         }
+        if (STAGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next block have landed
         __syncthreads();
         stamp(4);
         bw = bw_next;
+        if (STAGED && app + 2 < p.n_apps) bw_next = bw_after;
     }
 
     if ((p.abl & 16) && lane == 0 && blockIdx.x < 32) {
         float* o = p.xs + (size_t)(blockIdx.x * NWAVE + wave) * 8;
-        for (int k = 0; k < 5; ++k) o[k] = (float)ph[k];
+        for (int k = 0; k < 6; ++k) o[k] = (float)ph[k];
         return;
     }
     if (p.abl & 16) return;
-    spt_epilogue<false>(p, X, tid, view, b0, pose, ray, cen);
+    spt_epilogue<false>(p, X, tid, view, b0, pose, ray, cen, nl, rows_live);
 }
 
 // =====================================================================================================================
@@ -1210,12 +1376,29 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)spt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPT_LDS_BYTES) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void*)spt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPT_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)spt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPT_SMALL_LDS_BYTES) != hipSuccess)
             return MPL_E_LAUNCH;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    const int grid = cfg->num_views * ((in->batch + SEQ - 1) / SEQ);
+    // Sequences per workgroup of the fp32-MFMA kernel: as few as keep the launch inside one wave of workgroups (one per CU), so
+    // that a single frame or a few hundred sequences use the whole chip with 2-3 live row tiles per workgroup instead of a few
+    // workgroups with 17; up to SPT_SMALL_SPW per workgroup run the staged form (spt_kernel<true>).
+    static std::atomic<int> n_cus[64];
+    int cus = n_cus[dev].load(std::memory_order_acquire);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+        n_cus[dev].store(cus, std::memory_order_release);
+    }
+    int spw = SEQ;
+    for (int c = 1; c < SEQ; ++c)
+        if ((long long)cfg->num_views * ((in->batch + c - 1) / c) <= cus) { spw = c; break; }
+    // the packed-operand kernel (the default "fp32" arithmetic) gives way only in the small-batch mode of the forward (at most
+    // sm_stack_max_rows() sequences: the FPT stack then runs sm_stack.hip, exact fp32 as well) -- ONE switch point in the batch
+    // size, beyond which the result of a pose is bitwise independent of the batch
+    if (use_packed && sm_stack_enabled() && (long long)in->batch * cfg->num_views <= sm_stack_max_rows()) use_packed = 0;
+    p.spw = use_packed ? SEQ : spw;
+    const int grid = cfg->num_views * ((in->batch + p.spw - 1) / p.spw);
     ProfScope prof(MPL_K_SPT, s);
     if (use_packed) {
         static std::atomic<bool> attr3[64];
@@ -1226,7 +1409,8 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
         }
         hipLaunchKernelGGL(spt3_kernel, dim3(grid), dim3(NTHR), SPT3_LDS_BYTES, s, p);
     } else {
-        hipLaunchKernelGGL(spt_kernel, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);
+        if (p.spw <= SPT_SMALL_SPW) hipLaunchKernelGGL(spt_kernel<true>, dim3(grid), dim3(NTHR), SPT_SMALL_LDS_BYTES, s, p);
+        else hipLaunchKernelGGL(spt_kernel<false>, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);
     }
     return hip_check_launch();
 }

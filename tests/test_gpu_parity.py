@@ -270,10 +270,13 @@ def _big_inputs(B, V, seed):
     return mk(p), mk(r), mk(c)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp32_mfma"])
 @pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2"])
-def test_poses_are_independent_bitwise(name):
-    """Every pose is independent: permuting / splitting the batch must not change a bit."""
+def test_poses_are_independent_bitwise(name, prec):
+    """Every pose is independent: permuting / splitting the batch must not change a bit.  ("fp32_mfma": the three
+    batches take 16, 5 and 12 sequences per SPT workgroup -- the form with the weights staged in LDS and the one without.)"""
     m, g = _model(name)
+    m.set_matmul_precision(prec)
     B, V = 1024, g["flags"]["num_views"]
     P, R, Cn = _big_inputs(B, V, 99)
     with torch.no_grad():
@@ -646,22 +649,32 @@ def test_spt_engines_agree_and_packs_are_used():
         m, g = _model(name)
         poses, rays, centers = golden_inputs(g, DEV)
         dev, B, poses, rays, centers = m._check_inputs(poses, rays, centers)
-        taps = {}
-        for prec in ("fp32", "fp32_mfma"):
-            m.set_matmul_precision(prec)
-            ent = m._marshal(dev)
-            assert bool(ent["weights"].spt_packed) == (prec == "fp32")
-            assert bool(ent["derived"]["spt"]) == (prec == "fp32")
-            inp = cabi.Inputs()
-            inp.batch = B
-            for v in range(m.num_views):
-                inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
-            xs = torch.full((B, m.num_views, lib.mpl_fpt_width(C.byref(ent["cfg"]))), float("nan"), device=DEV)
-            cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), _stream()), "spt")
-            taps[prec] = xs.cpu().reshape(-1)
-            _assert_close(taps[prec], torch.from_numpy(g["tap_fpt_in"]).reshape(-1), name + " fpt_in " + prec, tol=2e-5)
-        mx, nw = mpl_oracle.rel_errors(taps["fp32"], taps["fp32_mfma"])
-        assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
+        # the fixtures have at most 32 sequences: the small-batch mode of the forward would run the fp32-MFMA kernel (its form with the
+        # weights staged in LDS) for BOTH precisions; mpl_x3_stack_mode bit 3 switches that mode off
+        for small in (False, True):
+            taps = {}
+            try:
+                cabi.check(lib.mpl_x3_stack_mode(0 if small else 8), "stack mode")
+                for prec in ("fp32", "fp32_mfma"):
+                    m.set_matmul_precision(prec)
+                    ent = m._marshal(dev)
+                    assert bool(ent["weights"].spt_packed) == (prec == "fp32")
+                    assert bool(ent["derived"]["spt"]) == (prec == "fp32")
+                    inp = cabi.Inputs()
+                    inp.batch = B
+                    for v in range(m.num_views):
+                        inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
+                    xs = torch.full((B, m.num_views, lib.mpl_fpt_width(C.byref(ent["cfg"]))), float("nan"), device=DEV)
+                    cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), _stream()), "spt")
+                    taps[prec] = xs.cpu().reshape(-1)
+                    _assert_close(taps[prec], torch.from_numpy(g["tap_fpt_in"]).reshape(-1), name + " fpt_in " + prec, tol=2e-5)
+            finally:
+                cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+            mx, nw = mpl_oracle.rel_errors(taps["fp32"], taps["fp32_mfma"])
+            if small:
+                assert torch.equal(taps["fp32"], taps["fp32_mfma"]), "small-batch mode: one SPT kernel for both precisions"
+            else:
+                assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
         m.set_matmul_precision("fp32")
 
 
