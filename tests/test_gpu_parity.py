@@ -700,3 +700,42 @@ def test_block_stack_launch_modes_agree():
     assert torch.equal(outs["gemm"], outs["gemm2"])
     mx, nw = mpl_oracle.rel_errors(outs["chain"].cpu(), outs["gemm"].cpu())
     assert mx < 5e-6 and nw < 2e-6, (mx, nw)
+
+
+@pytest.mark.parametrize("name", ["chosen_v4_b8_l2", "full_v4_b8_l2", "deep_head_h1024_v3_b5_l2"])
+def test_parameters_need_only_4_byte_alignment(name):
+    """torch.nn.DataParallel (valid_mpl.py:177-178) hands the replicas on the devices 1.. parameters that are VIEWS into one
+    coalesced broadcast buffer (comm.broadcast_coalesced): a tensor starts wherever the previous one ended, and behind
+    weighted_mean.weight / .bias (V and 1 elements) and head.1.bias (51) that is a 4-byte, not a 16-byte boundary.  Every kernel
+    reads its parameters with 16-byte loads or LDS-DMA pieces; on gfx950 those need dword alignment only.  Here: every parameter and
+    buffer re-homed to an address = 4 (mod 16); small-batch mode and team kernels, both fp32 precisions, bitwise the aligned result."""
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+
+    def run():
+        out = {}
+        for B in (2, 64):
+            P, R, Cn = _big_inputs(B, V, 5)
+            for prec in ("fp32", "fp32_mfma"):
+                m.set_matmul_precision(prec)
+                with torch.no_grad():
+                    o = m(P, rays=R, centers=Cn)
+                out[(B, prec)] = (o[0] if isinstance(o, tuple) else o).clone()
+        m.set_matmul_precision("fp32")
+        return out
+
+    want = run()
+    keep = []
+    for p in list(m.parameters()) + list(m.buffers()):
+        if not p.is_floating_point():
+            continue
+        flat = torch.empty(p.numel() + 8, device=p.device, dtype=p.dtype)
+        v = flat[1:1 + p.numel()].view(p.shape)
+        v.copy_(p.data)
+        p.data = v
+        keep.append(flat)
+        assert p.data_ptr() % 16 == 4
+    got = run()
+    for k in want:
+        assert torch.isfinite(got[k]).all()
+        assert torch.equal(got[k], want[k]), (name, k)
