@@ -21,6 +21,8 @@ for flags, B in ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024)
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True, confidence_input_as_third=True, input_rays_as_token=True,
                        multiple_spatial_blocks=True, add_3D_pos_encoding_to_rays=True), 4),
                  (dict(num_views=8, depth=12, pose_3d_emb_learnable=True), 2),
+                 (dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 8),         # 32 rows: two row tiles per weight fragment
+                 (dict(num_views=3, depth=2, pose_3d_emb_learnable=True, confidence_as_attention_uncertainty_weight=True), 7),
                  (dict(num_views=6, depth=2, pose_3d_emb_learnable=True, FPT_blocks_view_keypoint_tokens=True), 100)):
     m = MultiView_MPL(**flags).cuda().eval()
     detrng.fill_module_(m, seed=21)
