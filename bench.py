@@ -429,7 +429,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     # the SPT Linear layers run from two-part fp16 operands (spt3_kernel, the arithmetic of the h2 engine) unless fp32_mfma was
     # asked for: the executed matrix work is then 3 fp16 products per product of the four Linear layers (272 = 17 x 16 rows
     # per workgroup, no padding); the 17 x 17 x hd 4 attention is VALU work and not part of `achieved`
-    spt_packed = a.precision != "fp32_mfma" and not small      # small-batch mode: the spread fp32-MFMA kernel (spt_kernel<true>)
+    spt_packed = a.precision != "fp32_mfma"
     spt_lin = (flags["depth"] + 1) * 16.0 * 17 * 32 * 32 * flags["num_views"] * a.batch
     if spt_packed:
         spt_ex = spt_lin * 3.0 / (spt_us * 1e-6) / 1e12

@@ -230,9 +230,7 @@ int mpl_x3_debug_buffer(void *device_buffer);
  * deterministic).  Bits 1-2: 0 = the fp16x2 stack picks its stage by the shape of the launch (teams that own two or more row
  * tiles walk PAIRS of tiles, h2_stack2_kernel), 1 / 2 = force the one- / two-tile stage (bitwise the same poses).  Bit 3: no
  * small-batch engine (sm_stack.hip: stacks of at most 32 token rows run every GEMM on the whole chip with grid barriers in
- * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart; mpl_spt_tokens / mpl_forward of
- * at most 32 sequences then also run the fp32-MFMA SPT kernel in its spread form, one sequence per workgroup with the weights
- * staged in LDS, instead of the packed-operand one -- the small-batch MODE of the forward).  Bits 8.. = stop after that
+ * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bits 8.. = stop after that
  * many GEMM phases (tools/chain_phase.py). */
 int mpl_x3_stack_mode(int one_launch_per_gemm);
 

@@ -49,7 +49,7 @@ struct SptParams {
     int B, V, in_ch, n_apps;
     unsigned flags;
     int c3;  // channel count of the pos_3d_* tensors (d or 2d)
-    int spw;  // sequences per workgroup (spt_kernel: 1..16, few sequences spread over the chip; spt3_kernel: always SEQ)
+    int spw;  // sequences per workgroup (spt_kernel: 1..16, few sequences spread over the chip; spt3_kernel<SS>: SS)
     int abl;  // bench-only ablation mask (MPL_SPT_ABL): 1 no attention, 2 no GELU, 4 no MFMA phases, 8 no epilogue math
     unsigned char sched[MPL_MAX_APPS];  // layer | weighted << 7
 };
@@ -222,23 +222,23 @@ __device__ __forceinline__ f32x4 tile_k32(const float4& a0, const float4& a1, co
 // Row order of the token matrix X in LDS.  TM = false: row = sequence * 17 + joint (the fp32-MFMA kernel); TM = true:
 // row = joint * 16 + sequence -- token-major: MFMA row tile j holds joint j of the 16 sequences, so a lane of a transposed
 // accumulator tile is one (sequence, head) and the attention needs no cross-lane traffic (spt3_kernel).
-template <bool TM>
+template <bool TM, int SS = SEQ>
 __device__ __forceinline__ void row_to_sj(int r, int& sq, int& j) {
-    if (TM) { j = r >> 4; sq = r & 15; }
+    if (TM) { j = r / SS; sq = r % SS; }       // SS sequences per joint (a power of two): rows beyond 17 SS belong to no joint (j >= 17)
     else { sq = r / SJ; j = r - sq * SJ; }
 }
 
 // joint embedding (:355-396) of the workgroup's 16 sequences -> X
-template <bool TM>
+template <bool TM, int SS = SEQ>
 __device__ __forceinline__ void spt_embed(const SptParams& p, const mpl_spt_set& set, float* X, int tid, int b0,
                                           const float* pose, const float* ray, const float* cen, int nseq = SEQ, int nrows = ROWS) {
     for (int idx = tid; idx < nrows * SD; idx += NTHR) {
         const int r = idx >> 5, c = idx & 31;
         int sq, j;
-        row_to_sj<TM>(r, sq, j);
+        row_to_sj<TM, SS>(r, sq, j);
         const int b = b0 + sq;
         float x = 0.f;
-        if (b < p.B && sq < nseq) {
+        if (b < p.B && sq < nseq && j < SJ) {
             const float* in = pose + ((size_t)b * SJ + j) * 3;
             const float* we = set.embed_w + c * p.in_ch;
             x = set.embed_b[c] + we[0] * in[0] + we[1] * in[1];
@@ -264,7 +264,7 @@ __device__ __forceinline__ void spt_embed(const SptParams& p, const mpl_spt_set&
 }
 
 // Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...]
-template <bool TM>
+template <bool TM, int SS = SEQ>
 __device__ __forceinline__ void spt_epilogue(const SptParams& p, const float* X, int tid, int view, int b0, const float* pose,
                                              const float* ray, const float* cen, int nseq = SEQ, int nrows = ROWS) {
     // ---------------- epilogue: Spatial_norm (:412) + per-view glue (:465-491) -> xs[b*V+v][...] ------------
@@ -274,9 +274,9 @@ __device__ __forceinline__ void spt_epilogue(const SptParams& p, const float* X,
     const int Df = SJ * SD * ((p.flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
     for (int r = tid; r < nrows; r += NTHR) {
         int sq, j;
-        row_to_sj<TM>(r, sq, j);
+        row_to_sj<TM, SS>(r, sq, j);
         const int b = b0 + sq;
-        if (b >= p.B || sq >= nseq) continue;
+        if (b >= p.B || sq >= nseq || j >= SJ) continue;
         const float* xr = X + r * XS;
         float v[SD];
         float s = 0.f;
@@ -836,7 +836,15 @@ __device__ __forceinline__ f32x4 mfma3(const sf16x8 (&w)[2], const sf16x8& ah, c
     return c;
 }
 
+// SS = sequences per workgroup (16, 8, 4, 2 or 1): rows = joint * SS + sequence, 17 SS of them in MTS row tiles.  A launch of few
+// sequences takes as few per workgroup as keep it within one workgroup per CU (launch_spt): the kernel's time is VALU work per ROW
+// TILE, so 4 sequences per workgroup walk 5 tiles instead of 17.  The arithmetic of a row does not depend on SS (the matrix
+// instructions treat rows independently; the attention of a (sequence, head, query joint) visits the keys in the same order).
+template <int SS>
 __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
+    constexpr int RLIVE = SJ * SS;                 // live rows
+    constexpr int MTS = (RLIVE + 15) / 16;         // row tiles
+    constexpr int NT = (MTS + 3) / 4;              // row tiles of a wave in the qkv / attention phases (tiles part, part + 4, ...)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
     float* Kb = smem + ROWS * XS;
@@ -859,7 +867,8 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
     };
     const int hg = wave & 1, part = wave >> 1;     // head group, joint class
     const int view = blockIdx.x % p.V;
-    const int b0 = (blockIdx.x / p.V) * SEQ;
+    const int b0 = (blockIdx.x / p.V) * SS;
+    const int sl = li % SS;                        // this lane's sequence in every row tile (16 is a multiple of SS)
     const mpl_spt_set set = p.sets[(p.flags & MPL_F_MULTI_SPT) ? view : 0];
     const float* pose = p.poses[view];
     const float* ray = p.rays[view];
@@ -887,11 +896,10 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         stage_w(R_Q, bw.qkv_w3, SPT_PACK_QKV, 12);
     }
     const float4 par0 = p.n_apps > 0 ? load_par(bw) : float4{0.f, 0.f, 0.f, 0.f};
-    spt_embed<true>(p, set, X, tid, b0, pose, ray, cen);
+    spt_embed<true, SS>(p, set, X, tid, b0, pose, ray, cen, SS, MTS * 16);
     store_par(0, par0);
     phase_sync();
 
-    const int nj = part == 0 ? 5 : 4;              // joints part, part + 4, ... of this wave
     auto load_w = [&](const char* region, int unit, sf16x8 (&w)[2]) {      // from the staged section in LDS
         const sf16x8* g = reinterpret_cast<const sf16x8*>(region) + (size_t)unit * 2 * 64 + lane;
         w[0] = g[0];
@@ -937,14 +945,16 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 bq[c] = ::mpl::ld4(par + SPT_C_QKV + 32 * c + 16 * hg + 4 * kq);
                 sq[c] = ::mpl::ld4(par + SPT_NCOL + SPT_C_QKV + 32 * c + 16 * hg + 4 * kq);
             }
-            float4 q[5];
+            float4 q[NT];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 q[t] = float4{0.f, 0.f, 0.f, 0.f};
-                if (t < nj && !(p.abl & 8)) {
-                    const int j = part + 4 * t;
+                if (part + 4 * t < MTS && !(p.abl & 8)) {
+                    const int m = part + 4 * t;
+                    const int j = (16 * m + li) / SS;                   // this lane's joint in row tile m (SS = 16: j = m)
+                    const bool live = 16 * m + li < RLIVE;
                     sf16x8 ah, al;
-                    ln_frag(j, ah, al);
+                    ln_frag(m, ah, al);
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     const f32x4 cq = mfma3(wq[0], ah, al, z), ck = mfma3(wq[1], ah, al, z), cv = mfma3(wq[2], ah, al, z);
                     q[t] = float4{fmaf(cq[0], sq[0].x, bq[0].x), fmaf(cq[1], sq[0].y, bq[0].y), fmaf(cq[2], sq[0].z, bq[0].z),
@@ -955,17 +965,18 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     // a plain [h][seq]{x, y, z, w} record behind the 8 pairs
                     const float kx = fmaf(ck[0], sq[1].x, bq[1].x), ky = fmaf(ck[1], sq[1].y, bq[1].y);
                     const float kz = fmaf(ck[2], sq[1].z, bq[1].z), kw = fmaf(ck[3], sq[1].w, bq[1].w);
-                    if (j < SJ - 1) {
-                        float* kp = Kb + ((((j >> 1) * 2) * SH + h) * SEQ + li) * 4 + (j & 1);
+                    if (live && j < SJ - 1) {
+                        float* kp = Kb + ((((j >> 1) * 2) * SH + h) * SS + sl) * 4 + (j & 1);
                         kp[0] = kx;
                         kp[2] = ky;
-                        kp[SH * SEQ * 4] = kz;
-                        kp[SH * SEQ * 4 + 2] = kw;
-                    } else {
-                        st4(Kb + (SJ - 1) * SH * SEQ * 4 + (h * SEQ + li) * 4, float4{kx, ky, kz, kw});
+                        kp[SH * SS * 4] = kz;
+                        kp[SH * SS * 4 + 2] = kw;
+                    } else if (live) {
+                        st4(Kb + (SJ - 1) * SH * SS * 4 + (h * SS + sl) * 4, float4{kx, ky, kz, kw});
                     }
-                    st4(Vb + ((j * SH + h) * SEQ + li) * 4, float4{fmaf(cv[0], sq[2].x, bq[2].x), fmaf(cv[1], sq[2].y, bq[2].y),
-                                                                    fmaf(cv[2], sq[2].z, bq[2].z), fmaf(cv[3], sq[2].w, bq[2].w)});
+                    if (live)
+                        st4(Vb + ((j * SH + h) * SS + sl) * 4, float4{fmaf(cv[0], sq[2].x, bq[2].x), fmaf(cv[1], sq[2].y, bq[2].y),
+                                                                       fmaf(cv[2], sq[2].z, bq[2].z), fmaf(cv[3], sq[2].w, bq[2].w)});
                 }
             }
             phase_sync();
@@ -975,14 +986,14 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
             // proj operand (par[448], a power of two).
             if (!(p.abl & 1)) {
                 const int h = 4 * hg + kq;
-                float sc[5][SJ];
+                float sc[NT][SJ];
 #pragma unroll
                 for (int jp = 0; jp < SJ / 2; ++jp) {
-                    const float4 k01 = ::mpl::ld4(Kb + (((jp * 2) * SH + h) * SEQ + li) * 4);        // x_j x_j+1 y_j y_j+1
-                    const float4 k23 = ::mpl::ld4(Kb + (((jp * 2 + 1) * SH + h) * SEQ + li) * 4);    // z_j z_j+1 w_j w_j+1
+                    const float4 k01 = ::mpl::ld4(Kb + (((jp * 2) * SH + h) * SS + sl) * 4);        // x_j x_j+1 y_j y_j+1
+                    const float4 k23 = ::mpl::ld4(Kb + (((jp * 2 + 1) * SH + h) * SS + sl) * 4);    // z_j z_j+1 w_j w_j+1
                     const f32x2 kx = {k01.x, k01.y}, ky = {k01.z, k01.w}, kz = {k23.x, k23.y}, kw = {k23.z, k23.w};
 #pragma unroll
-                    for (int t = 0; t < 5; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         const f32x2 qx = {q[t].x, q[t].x}, qy = {q[t].y, q[t].y}, qz = {q[t].z, q[t].z}, qw = {q[t].w, q[t].w};
                         f32x2 s2 = qx * kx;
                         s2 = __builtin_elementwise_fma(qy, ky, s2);
@@ -993,15 +1004,15 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     }
                 }
                 {
-                    const float4 k = ::mpl::ld4(Kb + (SJ - 1) * SH * SEQ * 4 + (h * SEQ + li) * 4);
+                    const float4 k = ::mpl::ld4(Kb + (SJ - 1) * SH * SS * 4 + (h * SS + sl) * 4);
 #pragma unroll
-                    for (int t = 0; t < 5; ++t)
+                    for (int t = 0; t < NT; ++t)
                         sc[t][SJ - 1] = fmaf(q[t].w, k.w, fmaf(q[t].z, k.z, fmaf(q[t].y, k.y, q[t].x * k.x)));
                 }
                 const float s_att = par[2 * SPT_NCOL];
-                float inv[5];
+                float inv[NT];
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     float mx = sc[t][0];
 #pragma unroll
                     for (int j = 1; j < SJ; ++j) mx = fmaxf(mx, sc[t][j]);
@@ -1013,18 +1024,18 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     }
                     inv[t] = __builtin_amdgcn_rcpf(l) * s_att;              // v_rcp_f32 (1 ulp)
                     if (weighted) {  // attn * conf_weights.unsqueeze(1) after softmax (:61-62): scales the query row
-                        const int b = b0 + li;
-                        inv[t] *= (b < p.B && t < nj) ? pose[((size_t)b * SJ + (part + 4 * t)) * 3 + 2] : 0.f;
+                        const int b = b0 + sl, r = 16 * (part + 4 * t) + li;
+                        inv[t] *= (b < p.B && r < RLIVE) ? pose[((size_t)b * SJ + r / SS) * 3 + 2] : 0.f;
                     }
                 }
-                float4 o[5];
+                float4 o[NT];
 #pragma unroll
-                for (int t = 0; t < 5; ++t) o[t] = float4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT; ++t) o[t] = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < SJ; ++j) {
-                    const float4 v = ::mpl::ld4(Vb + ((j * SH + h) * SEQ + li) * 4);
+                    const float4 v = ::mpl::ld4(Vb + ((j * SH + h) * SS + sl) * 4);
 #pragma unroll
-                    for (int t = 0; t < 5; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         const float pj = sc[t][j];
                         o[t].x = fmaf(pj, v.x, o[t].x);
                         o[t].y = fmaf(pj, v.y, o[t].y);
@@ -1033,7 +1044,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     o[t] = float4{o[t].x * inv[t], o[t].y * inv[t], o[t].z * inv[t], o[t].w * inv[t]};
                     // the confidence weights are data: only with them can the operand leave the window its static scale assumes
                     if (weighted)
@@ -1041,8 +1052,8 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                                       __builtin_amdgcn_fmed3f(o[t].z, -65000.f, 65000.f), __builtin_amdgcn_fmed3f(o[t].w, -65000.f, 65000.f)};
                 }
 #pragma unroll
-                for (int t = 0; t < 5; ++t)
-                    if (t < nj) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
+                for (int t = 0; t < NT; ++t)
+                    if (part + 4 * t < MTS) st4(ATT + ((part + 4 * t) * 16 + li) * ATS + 4 * h, o[t]);
             }
         }
         phase_sync();
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 bp[n] = ::mpl::ld4(par + SPT_C_PROJ + 16 * n + 4 * kq);
                 sp[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_PROJ + 16 * n + 4 * kq);
             }
-            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            const int lo = (MTS * 2 * wave) / NWAVE, hi = (MTS * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 32); ++m) {
                 sf16x8 ah, al;
                 raw_frag(ATT + (m * 16 + li) * ATS + 8 * kq, ah, al);
@@ -1086,7 +1097,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 s1[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_FC1 + 16 * n + 4 * kq);
             }
             const float hs = par[2 * SPT_NCOL + 1];     // half the static scale of the fc2 operand (a power of two)
-            const int lo = (MT * 4 * wave) / NWAVE, hi = (MT * 4 * (wave + 1)) / NWAVE;
+            const int lo = (MTS * 4 * wave) / NWAVE, hi = (MTS * 4 * (wave + 1)) / NWAVE;
             for (int m = lo >> 2; m <= ((hi - 1) >> 2) && !(p.abl & 64); ++m) {
                 sf16x8 ah, al;
                 ln_frag(m, ah, al);
@@ -1120,7 +1131,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
                 b2[n] = ::mpl::ld4(par + SPT_C_FC2 + 16 * n + 4 * kq);
                 s2[n] = ::mpl::ld4(par + SPT_NCOL + SPT_C_FC2 + 16 * n + 4 * kq);
             }
-            const int lo = (MT * 2 * wave) / NWAVE, hi = (MT * 2 * (wave + 1)) / NWAVE;
+            const int lo = (MTS * 2 * wave) / NWAVE, hi = (MTS * 2 * (wave + 1)) / NWAVE;
             for (int m = lo >> 1; m <= ((hi - 1) >> 1) && !(p.abl & 128); ++m) {
                 sf16x8 ah0, al0, ah1, al1;
                 raw_frag(HID + (m * 16 + li) * HS + 8 * kq, ah0, al0);
@@ -1141,7 +1152,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
         }
         phase_sync();
     }
-    spt_epilogue<true>(p, X, tid, view, b0, pose, ray, cen);
+    spt_epilogue<true, SS>(p, X, tid, view, b0, pose, ray, cen, SS, MTS * 16);
 }
 
 // ---------------------------------------------------------------------------------------------- D = 32 FPT blocks
@@ -1393,21 +1404,22 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     int spw = SEQ;
     for (int c = 1; c < SEQ; ++c)
         if ((long long)cfg->num_views * ((in->batch + c - 1) / c) <= cus) { spw = c; break; }
-    // the packed-operand kernel (the default "fp32" arithmetic) gives way only in the small-batch mode of the forward (at most
-    // sm_stack_max_rows() sequences: the FPT stack then runs sm_stack.hip, exact fp32 as well) -- ONE switch point in the batch
-    // size, beyond which the result of a pose is bitwise independent of the batch
-    if (use_packed && sm_stack_enabled() && (long long)in->batch * cfg->num_views <= sm_stack_max_rows()) use_packed = 0;
-    p.spw = use_packed ? SEQ : spw;
+    // the packed-operand kernel takes 16, 8, 4, 2 or 1 sequences per workgroup (bitwise the same rows)
+    int ss = 1;
+    while (ss < spw) ss *= 2;
+    p.spw = use_packed ? ss : spw;
     const int grid = cfg->num_views * ((in->batch + p.spw - 1) / p.spw);
     ProfScope prof(MPL_K_SPT, s);
     if (use_packed) {
-        static std::atomic<bool> attr3[64];
-        if (!attr3[dev].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute((const void*)spt3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPT3_LDS_BYTES) != hipSuccess)
+        void (*k3)(const SptParams) = ss == 1 ? spt3_kernel<1> : ss == 2 ? spt3_kernel<2> : ss == 4 ? spt3_kernel<4> : ss == 8 ? spt3_kernel<8> : spt3_kernel<16>;
+        const int ki = ss == 1 ? 0 : ss == 2 ? 1 : ss == 4 ? 2 : ss == 8 ? 3 : 4;
+        static std::atomic<bool> attr3[64][5];
+        if (!attr3[dev][ki].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, SPT3_LDS_BYTES) != hipSuccess)
                 return MPL_E_LAUNCH;
-            attr3[dev].store(true, std::memory_order_release);
+            attr3[dev][ki].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL(spt3_kernel, dim3(grid), dim3(NTHR), SPT3_LDS_BYTES, s, p);
+        hipLaunchKernelGGL(k3, dim3(grid), dim3(NTHR), SPT3_LDS_BYTES, s, p);
     } else {
         if (p.spw <= SPT_SMALL_SPW) hipLaunchKernelGGL(spt_kernel<true>, dim3(grid), dim3(NTHR), SPT_SMALL_LDS_BYTES, s, p);
         else hipLaunchKernelGGL(spt_kernel<false>, dim3(grid), dim3(NTHR), SPT_LDS_BYTES, s, p);

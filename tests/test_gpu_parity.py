@@ -293,6 +293,14 @@ def test_poses_are_independent_bitwise(name, prec):
     assert torch.equal(full[perm], shuf), "batch permutation changed results"
     assert torch.equal(full, torch.cat([lo, hi], 0)), "batch split changed results"
     assert torch.isfinite(full).all()
+    # the SPT kernels take 1, 2, 4, 8 or 16 sequences per workgroup by the size of the launch (as few as fill one workgroup per
+    # CU): the first n poses alone, for an n of every class (n V > 32: above the small-batch mode), against the same poses in the
+    # full batch
+    with torch.no_grad():
+        for n in (9, 40, 100, 200, 400):
+            part = m([x[:n].contiguous() for x in P], rays=[x[:n].contiguous() for x in R], centers=[x[:n].contiguous() for x in Cn])
+            assert torch.equal(part, full[:n]), "the first %d poses alone differ from the same poses in the batch of %d" % (n, B)
+    m.set_matmul_precision("fp32")
 
 
 def test_configs3_batch_8192_equals_its_eight_shards_bitwise():
@@ -649,32 +657,22 @@ def test_spt_engines_agree_and_packs_are_used():
         m, g = _model(name)
         poses, rays, centers = golden_inputs(g, DEV)
         dev, B, poses, rays, centers = m._check_inputs(poses, rays, centers)
-        # the fixtures have at most 32 sequences: the small-batch mode of the forward would run the fp32-MFMA kernel (its form with the
-        # weights staged in LDS) for BOTH precisions; mpl_x3_stack_mode bit 3 switches that mode off
-        for small in (False, True):
-            taps = {}
-            try:
-                cabi.check(lib.mpl_x3_stack_mode(0 if small else 8), "stack mode")
-                for prec in ("fp32", "fp32_mfma"):
-                    m.set_matmul_precision(prec)
-                    ent = m._marshal(dev)
-                    assert bool(ent["weights"].spt_packed) == (prec == "fp32")
-                    assert bool(ent["derived"]["spt"]) == (prec == "fp32")
-                    inp = cabi.Inputs()
-                    inp.batch = B
-                    for v in range(m.num_views):
-                        inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
-                    xs = torch.full((B, m.num_views, lib.mpl_fpt_width(C.byref(ent["cfg"]))), float("nan"), device=DEV)
-                    cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), _stream()), "spt")
-                    taps[prec] = xs.cpu().reshape(-1)
-                    _assert_close(taps[prec], torch.from_numpy(g["tap_fpt_in"]).reshape(-1), name + " fpt_in " + prec, tol=2e-5)
-            finally:
-                cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
-            mx, nw = mpl_oracle.rel_errors(taps["fp32"], taps["fp32_mfma"])
-            if small:
-                assert torch.equal(taps["fp32"], taps["fp32_mfma"]), "small-batch mode: one SPT kernel for both precisions"
-            else:
-                assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
+        taps = {}
+        for prec in ("fp32", "fp32_mfma"):
+            m.set_matmul_precision(prec)
+            ent = m._marshal(dev)
+            assert bool(ent["weights"].spt_packed) == (prec == "fp32")
+            assert bool(ent["derived"]["spt"]) == (prec == "fp32")
+            inp = cabi.Inputs()
+            inp.batch = B
+            for v in range(m.num_views):
+                inp.poses[v], inp.rays[v], inp.centers[v] = poses[v].data_ptr(), rays[v].data_ptr(), centers[v].data_ptr()
+            xs = torch.full((B, m.num_views, lib.mpl_fpt_width(C.byref(ent["cfg"]))), float("nan"), device=DEV)
+            cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), _stream()), "spt")
+            taps[prec] = xs.cpu().reshape(-1)
+            _assert_close(taps[prec], torch.from_numpy(g["tap_fpt_in"]).reshape(-1), name + " fpt_in " + prec, tol=2e-5)
+        mx, nw = mpl_oracle.rel_errors(taps["fp32"], taps["fp32_mfma"])
+        assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
         m.set_matmul_precision("fp32")
 
 
