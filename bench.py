@@ -16,13 +16,15 @@ When invoked plainly with --gpus N > 1 the parent process imports nothing that t
 children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's line.
 
 Rank 0 prints ONE JSON line: value = whole-job poses/s, plus
-  roofline     -- dominant kernel (x3_gemm_kernel: the GEMMs of the FPT blocks): FLOPs per launch / mean launch duration
-                  measured live with HIP events on the launch stream (mpl_profile_start/stop).  The default fp32 path
-                  computes those GEMMs on the bf16 matrix cores from exactly split operands (fp32 in, fp32 out, fp32
-                  accumulation, products at least fp32-accurate: csrc/x3_gemm.hip), so the binding ceiling is the bf16
-                  matrix pipe: `frac` = executed bf16 MFMA FLOP/s / 2.5 PFLOP/s; `fp32_equivalent` keeps the
-                  algorithmic fp32 FLOP/s against the 157.3 TFLOP/s fp32 matrix peak.  `kernels` lists every kernel
-                  kind of the forward (SPT included) the same way.
+  roofline     -- dominant kernel (h2_stack_kernel: every GEMM of the FPT block stack in one persistent launch): FLOPs per
+                  launch / mean launch duration, measured live with HIP events on the launch stream (mpl_profile_start/stop)
+                  over a whole region of `steps` forwards.  The default fp32 path computes those GEMMs on the fp16 matrix
+                  cores from operands split in two fp16 parts (fp32 in, fp32 out, fp32 accumulation, three partial products
+                  per product: csrc/h2_gemm.hip), so the binding ceiling is the 16-bit matrix pipe: `frac` = `frac_useful` =
+                  algorithmic FLOPs x 3 products / 2.5 PFLOP/s; `frac_executed` adds the 144/136 column-tile padding the
+                  pipe also executes; `fp32_equivalent` keeps the algorithmic fp32 FLOP/s against the 157.3 TFLOP/s fp32
+                  matrix peak.  `kernels` lists every kernel kind of the forward (SPT included) the same way; `rooflines`
+                  repeats the entry for the other engines (bf16 at V = 8, the small-batch engine at one frame).
   cpu_baseline -- the oracle (a port of the reference's CPU PyTorch path) timed on this box's host cores, headline
                   workload first, BASELINE.md section 4's other configurations under `others`.
 """
@@ -63,9 +65,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs / engines)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the rank code path (process group + all-gather) even at one GPU")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32x3", "fp32_mfma", "bf16"],
-                    help="fp32: fp16x2 split-operand GEMMs on the fp16 matrix cores (default); fp32x3: the round-2 engine "
-                         "(three bf16 parts, six products); fp32_mfma: native fp32 MFMA; "
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_mfma", "bf16"],
+                    help="fp32: fp16x2 split-operand GEMMs on the fp16 matrix cores (default); fp32_mfma: native fp32 MFMA; "
                          "bf16: bf16 operands (BASELINE.json configs[2]: use with --views 8 --depth 2 / 12)")
     return ap.parse_args()
 
@@ -214,35 +215,57 @@ def timed_steps(model, batches, steps, warmup, lifter=None, global_batch=None):
         return time.perf_counter() - t0
 
 
-def stack_roofline(model, flags, batch, batches, precision, n_prof=5):
+def stack_kernel_name(precision, batch, views, D, dev, launches=1):
+    """Name of the kernel that runs the FPT block stack, by the rules of the library (api.hip block_stack_impl,
+    h2_phase.hpp h2_launch_stack): row tiles of (64 // V) * V rows, teams of D / 136 workgroups, as many teams as the device
+    has compute units for."""
+    import torch
+    if precision == "fp32_mfma" or D % 136:
+        return "ln_gemm_ng_kernel"
+    if precision == "fp32" and batch * views <= 32 and launches == 1:
+        return "sm_stack_kernel"
+    if launches != 1:
+        return "h2_gemm_kernel"
+    rpt = (64 // views) * views
+    n_tiles = -(-(batch * views) // rpt)
+    cap = torch.cuda.get_device_properties(dev).multi_processor_count // (D // 136)
+    if precision == "bf16":
+        return "h2_stack_kernel<1>"           # bf16 operands: one row tile per team step (the pair form is not faster)
+    return "h2_stack2_kernel<2>" if n_tiles > cap else "h2_stack_kernel<2>"
+
+
+def stack_roofline(model, flags, batch, batches, precision, dev, n_prof=20):
     """Roofline-shaped entry of the dominant kernel (the persistent block-stack launch) of any configuration: mean launch
-    duration from HIP events on the launch stream, executed MFMA FLOP/s = algorithmic FLOPs x products per product x 144/136
-    column padding (x K padding of the bf16 engine), against the dense 16-bit matrix peak."""
+    duration from HIP events on the launch stream over n_prof forwards; `frac` (= `frac_useful`) = algorithmic FLOPs x partial
+    products per product / duration against the dense 16-bit matrix peak, `frac_executed` adds the padding the pipe also
+    multiplies (144 / 136 column tiles; bf16: the zero k-tile that pads 17 k-tiles to 9 pairs)."""
     import torch
     from openmpl_amd import cabi
-    P, R, C = batches[0]
     with torch.no_grad():
-        for _ in range(2):
+        for i in range(3):
+            P, R, C = batches[i % len(batches)]
             model(P, rays=R, centers=C)
         cabi.profile_start()
-        for _ in range(n_prof):
+        for i in range(n_prof):
+            P, R, C = batches[i % len(batches)]
             model(P, rays=R, centers=C)
         torch.cuda.synchronize()
         prof = cabi.profile_stop()
     gemm_ms, gemm_n = prof["gemm"]
     fl, gemms = gemm_flops_per_forward(flags, batch)
     D = fpt_width(flags)
-    np_ = {"bf16": 1, "fp32": 2}.get(precision, 3)
-    kpad = ((-(-(D // 32) // 3) * 3) / (D // 32)) if np_ == 1 else 1.0
-    products = {3: 6.0, 2: 3.0, 1: 1.0}[np_]
+    np_ = 1 if precision == "bf16" else 2
+    kpad = (2 * (-(-(D // 32) // 2)) / (D // 32)) if np_ == 1 else 1.0
+    products = {2: 3.0, 1: 1.0}[np_]
     launches = max(1, gemm_n // n_prof)
     us = gemm_ms / max(1, gemm_n) * 1e3
-    ex = (fl / launches) * products * 144.0 / 136.0 * kpad / (us * 1e-6) / 1e12
+    useful = (fl / launches) * products / (us * 1e-6) / 1e12
     total = sum(t for t, _ in prof.values())
-    pairs = np_ == 2 and -(-(batch * flags["num_views"]) // 64) > 256 // (D // 136)
-    return dict(kernel={1: "x3_stack_kernel<1>", 2: "h2_stack2_kernel" if pairs else "h2_stack_kernel", 3: "x3_stack_kernel<3>"}[np_], bound="mfma",
-                launches_per_step=launches, avg_launch_us=round(us, 1), achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS,
-                unit="TFLOP/s", frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+    return dict(kernel=stack_kernel_name(precision, batch, flags["num_views"], D, dev, launches), bound="mfma",
+                launches_per_step=launches, launches_timed=gemm_n, avg_launch_us=round(us, 1), achieved=round(useful, 1),
+                peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(useful / PEAK_BF16_MFMA_TFLOPS, 4),
+                frac_useful=round(useful / PEAK_BF16_MFMA_TFLOPS, 4),
+                frac_executed=round(useful * 144.0 / 136.0 * kpad / PEAK_BF16_MFMA_TFLOPS, 4),
                 kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
                 share_of_kernel_time=round(gemm_ms / total, 3) if total else None)
 
@@ -299,7 +322,7 @@ def run_rank(a):
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # backend "nccl" IS RCCL on ROCm
         lifter = ShardedLifter(model)
-    split = a.precision in ("fp32", "fp32x3", "bf16") and model._x3_supported()
+    split = a.precision in ("fp32", "bf16") and model._x3_supported()
     # a few distinct resident batches (per rank: pre-sharded inputs) so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
 
@@ -325,19 +348,24 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     import torch
     from openmpl_amd import cabi
     from oracle import mpl_oracle
-    # ---- per-kernel time, measured live with HIP events on the launch stream (NOT part of the timed region above)
+    # ---- per-kernel time, measured live with HIP events on the launch stream: a WHOLE region of `steps` forwards run like the
+    # timed one (same batches, back to back, warm), with every launch bracketed -- not a handful of forwards behind an idle gap
     P, R, C = batches[0]
-    n_prof = 5
+    n_prof = max(a.steps, 50)
     with torch.no_grad():
+        for i in range(5):
+            Pw, Rw, Cw = batches[i % len(batches)]
+            model(Pw, rays=Rw, centers=Cw)
         cabi.profile_start()
-        for _ in range(n_prof):
-            model(P, rays=R, centers=C)
+        for i in range(n_prof):
+            Pw, Rw, Cw = batches[i % len(batches)]
+            model(Pw, rays=Rw, centers=Cw)
         torch.cuda.synchronize()
         prof = cabi.profile_stop()
     gemm_ms, gemm_n = prof["gemm"]
     fl, gemms = gemm_flops_per_forward(flags, a.batch)
-    # the split-operand engine runs ALL GEMMs of the block stack in ONE persistent launch (csrc/x3_gemm.hip,
-    # x3_stack_kernel); the fp32-MFMA engine (and MPL_X3_LAUNCHES=1) launch one kernel per GEMM
+    # the packed-operand engines run ALL GEMMs of the block stack in ONE persistent launch (csrc/h2_phase.hpp,
+    # h2_stack_kernel); the fp32-MFMA engine (and MPL_X3_LAUNCHES=1) launch one kernel per GEMM
     assert gemm_n % n_prof == 0 and gemm_n // n_prof in (1, gemms), (gemm_n, gemms)
     launches = gemm_n // n_prof
     avg_launch_ms = gemm_ms / gemm_n
@@ -346,60 +374,65 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
     total_flop = mpl_oracle.flop_count({k: v for k, v in flags.items()})
     io_bytes = (a.views * (17 * 2 if a.flagset == "chosen" else 17 * 6 + 3) * 4 + 51 * 4)   # 748 / 1884 B
     weight_bytes = sum(p.numel() for p in model.parameters()) * 4
-    eng = "h2" if a.precision == "fp32" else "x3"
-    # teams that own two or more row tiles (more 64-row tiles than teams of D / 136 workgroups fit 256 CUs) run the two-tile stage
-    pairs = a.precision == "fp32" and -(-(a.batch * a.views) // 64) > 256 // (fpt_width(flags) // 136)
-    gemm_kernel = ((eng + ("_stack2_kernel" if pairs else "_stack_kernel")) if launches == 1 else (eng + "_gemm_kernel")) if split else "ln_gemm_ng_kernel"
-    small = a.precision in ("fp32", "fp32_mfma") and a.batch * a.views <= 32 and launches == 1
+    D = fpt_width(flags)
+    # the kernel that ran, by the library's own rules (row tiles of (64 // V) V rows, teams of D / 136 workgroups, the
+    # device's CU count): teams that own two or more row tiles run the two-tile stage (fp16x2 operands)
+    gemm_kernel = stack_kernel_name(a.precision if split else "fp32_mfma", a.batch, a.views, D, dev, launches)
+    pairs = gemm_kernel.startswith("h2_stack2")
+    small = gemm_kernel == "sm_stack_kernel"
     if small:       # at most 32 token rows: the small-batch engine (sm_stack.hip), exact fp32 MFMA on the whole chip
-        gemm_kernel, split = "sm_stack_kernel", False
+        split = False
     # HBM/fabric bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
-    # PMC passes of this same command (profiles/rNN_gemm_traffic.json), and only for the profiled workload shape.
+    # PMC passes of this same command (profiles/rNN_gemm_traffic.json) -- for the profiled workload shape, and ONLY while the
+    # library is built from the sources the passes ran on (source hash recorded by tools/make_profiles.py): a number taken
+    # with another kernel is not this kernel's traffic
     traffic, traffic_src = None, None
     try:
+        from openmpl_amd import build as mpl_build
         tp = latest_profile("gemm_traffic.json")
         if tp and a.flagset == "chosen" and a.batch == 1024 and a.views == 4 and a.depth == 12:
             tj = json.load(open(tp))
-            if tj.get("kernel") == gemm_kernel and a.precision == "fp32":
-                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tp, ROOT) + ": " + tj["source"]
+            if tj.get("kernel", "").split("<")[0] == gemm_kernel.split("<")[0] and a.precision == "fp32":
+                if tj.get("srchash") == mpl_build.source_hash():
+                    traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tp, ROOT) + ": " + tj["source"]
+                else:
+                    traffic_src = "%s was taken with other kernel sources (srchash %s...): not reported" % (
+                        os.path.relpath(tp, ROOT), str(tj.get("srchash"))[:12])
     except Exception:
         pass
-    D = fpt_width(flags)
     # algorithmic bytes of the mean GEMM launch: A + W operand + C (+ residual) once each
     M = a.batch * a.views
-    np_ = {"bf16": 1, "fp32": 2}.get(a.precision, 3)   # 16-bit parts per operand element of the packed-operand engine
+    np_ = 1 if a.precision == "bf16" else 2            # 16-bit parts per operand element of the packed-operand engine
     kpad = 1.0
-    if split and np_ == 1:                    # bf16 engine: K padded with zero k-tiles to whole stages of 96
-        kpad = (-(-(D // 32) // 3) * 3) / (D // 32)
+    if split and np_ == 1:                    # bf16 engine: an odd k-tile count is padded with one zero k-tile (pairs of k-tiles)
+        kpad = 2 * (-(-(D // 32) // 2)) / (D // 32)
     w_bytes = 2.0 * np_ * 144.0 / 136.0 * kpad if split else 4.0   # packed operand: np bf16 parts in 144/136-padded fragment order
     a_bytes = 2.0 * np_ * kpad if split else 4.0                   # activations travel between the GEMMs as np bf16 parts
-    # h2: the residual stream x (fp32) IS the operand of the LayerNorm GEMMs; x3 / bf16 hand a packed copy of x on as well
+    # fp16x2: the residual stream x (fp32) IS the operand of the LayerNorm GEMMs; bf16 hands a packed copy of x on as well
     x_copy = M * D * a_bytes if (split and np_ != 2) else 0
     alg_bytes = ((M * D * a_bytes + 3 * D * D * w_bytes + M * D * a_bytes)                 # LN1 + qkv + attention: x in, att out
                  + (M * D * a_bytes + D * D * w_bytes + 2 * M * D * 4 + x_copy)            # proj: att in, x in/out (+ packed x out)
                  + (M * D * a_bytes + 2 * D * D * w_bytes + M * 2 * D * a_bytes)           # fc1: x in, hid out
                  + (M * 2 * D * a_bytes + 2 * D * D * w_bytes + 2 * M * D * 4 + x_copy)) / 4.0   # fc2: hid in, x in/out
     if split:
-        # executed matrix-pipe work: 6 (fp32: three bf16 parts per operand) or 1 (bf16) partial products per product on
-        # 144-column (9 x 16) tiles of 136; the bf16 engine also multiplies the zero k-tiles that pad K to stages of 96
-        products = {3: 6.0, 2: 3.0, 1: 1.0}[np_]
-        ex = alg * products * 144.0 / 136.0 * kpad
+        # matrix-pipe work: 3 (fp32: two fp16 parts per operand) or 1 (bf16) partial products per product = USEFUL work; the pipe
+        # EXECUTES 144-column (9 x 16) tiles for 136 columns (and, bf16, the zero k-tile that pads an odd k-tile count) on top
+        products = {2: 3.0, 1: 1.0}[np_]
+        useful = alg * products
+        ex = useful * 144.0 / 136.0 * kpad
         roof = dict(bound="mfma", kernel=gemm_kernel,
                     instruction="v_mfma_f32_16x16x32_f16" if np_ == 2 else "v_mfma_f32_16x16x32_bf16",
-                    achieved=round(ex, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                    achieved=round(useful, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(useful / PEAK_BF16_MFMA_TFLOPS, 4), frac_useful=round(useful / PEAK_BF16_MFMA_TFLOPS, 4),
+                    frac_executed=round(ex / PEAK_BF16_MFMA_TFLOPS, 4), executed_tflops=round(ex, 1),
                     arithmetic=("fp32 GEMM: operands split into 2 fp16 terms under exact power-of-two scales, 3 partial products "
                                 "per fp32 product on the fp16 matrix cores (same rate as bf16; 9 MFMA column tiles per 136 output "
                                 "columns), fp32 accumulation -- as accurate as an fp32 GEMM (extra.max_scaled_err_vs_fp64); "
-                                "`achieved` = algorithmic fp32 FLOPs x 3 x 144/136 = executed fp16 MFMA FLOP/s; "
+                                "`achieved` / `frac` = algorithmic fp32 FLOPs x 3 (useful fp16 MFMA FLOP/s); `frac_executed` x 144/136; "
                                 if np_ == 2 else
-                                "fp32 GEMM: operands split exactly into 3 bf16 terms, 6 significant partial products per "
-                                "fp32 product on the bf16 matrix cores (9 MFMA column tiles per 136 output columns), fp32 "
-                                "accumulation; `achieved` = algorithmic fp32 FLOPs x 6 x 144/136 = executed bf16 MFMA FLOP/s; "
-                                if np_ == 3 else
-                                "bf16 GEMM: one bf16 per operand element, fp32 accumulation; `achieved` = algorithmic FLOPs x "
-                                "144/136 (9 MFMA column tiles per 136 columns) x %.4f (K padded to stages of 96) = executed bf16 "
-                                "MFMA FLOP/s; " % kpad) +
+                                "bf16 GEMM: one bf16 per operand element, fp32 accumulation; `achieved` / `frac` = algorithmic FLOPs "
+                                "(useful bf16 MFMA FLOP/s); `frac_executed` x 144/136 (9 MFMA column tiles per 136 columns) x %.4f "
+                                "(17 k-tiles padded to 9 pairs); " % kpad) +
                                "one launch = every GEMM of the FPT block stack (persistent row-tile chains), its duration also "
                                "contains the fused softmax attention, the operand packing and the LayerNorm statistics",
                     fp32_equivalent=dict(achieved=round(alg, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -460,7 +493,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                     share_of_kernel_time=round(gemm_ms / sum(t for t, _ in prof.values()), 3)),
                dict(spt_roof, launches_per_step=1, avg_launch_us=round(spt_us, 2), flops_per_launch=spt_fl, bound="mfma",
                     share_of_kernel_time=round(spt_ms / sum(t for t, _ in prof.values()), 3))]
-    roof.update(traffic=traffic, traffic_source=traffic_src,
+    roof.update(launches_timed=gemm_n, traffic=traffic, traffic_source=traffic_src,
                 traffic_ratio=(round(traffic / alg_bytes, 3) if traffic else None), lds_dma=lds_dma,
                 avg_launch_us=round(avg_launch_ms * 1e3, 2),
                 launches_per_step=launches, gemms_per_launch=gemms // launches, flops_per_launch=fl / launches,
@@ -469,8 +502,8 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                 whole_forward_frac_of_fp32_peak=round(value / world * total_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 hbm_frac=round(value / world * (io_bytes + weight_bytes / a.batch) / 1e9 / PEAK_HBM_GBS, 5),
                 kernel_ms_per_step=kernel_ms,
-                kernel_ms_note="per-launch HIP-event brackets of 5 extra forwards outside the timed region; every "
-                               "bracket adds ~1 us, so their sum slightly exceeds ms_per_step")
+                kernel_ms_note="per-launch HIP-event brackets of a whole extra region of %d forwards run like the timed one "
+                               "(every bracket adds ~1 us per launch to that region)" % n_prof)
 
     # ---- parity of this very run against the oracle (bounded: 64 poses)
     nb = min(64, a.batch)
@@ -541,8 +574,22 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                    "global_batch": world * a.batch,
                    "parallelism": ("dp%d: pre-sharded batch, 1 async RCCL all_gather of (B/G,17,3) per step" % world)
                    if used_dist else "single GPU"},
-        "roofline": roof, "cpu_baseline": cpu_base, "parity": parity, "extra": extra,
+        "roofline": roof, "rooflines": rooflines(roof, extra, a), "cpu_baseline": cpu_base, "parity": parity, "extra": extra,
     }
+
+
+def rooflines(roof, extra, a):
+    """The roofline entries of this run side by side: the headline kernel, the bf16 engine at BASELINE configs[2]'s shape (depth 2
+    and 12) and the small-batch engine at one frame -- each from launches timed in this process."""
+    keys = ("kernel", "bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "frac_useful", "frac_executed")
+    pick = lambda d, wl: dict({k: d[k] for k in keys if k in d}, workload=wl)
+    out = [pick(roof, "V=%d B=%d depth %d %s %s" % (a.views, a.batch, a.depth, a.flagset.upper(), a.precision))]
+    for key, wl in (("cmu_v8_depth2", "V=8 B=%d depth 2 CHOSEN bf16" % a.batch), ("cmu_v8_depth12", "V=8 B=%d depth 12 CHOSEN bf16" % a.batch)):
+        if key in extra and "bf16_roofline" in extra[key]:
+            out.append(pick(extra[key]["bf16_roofline"], wl))
+    if "v2_b1_roofline" in extra:
+        out.append(pick(extra["v2_b1_roofline"], "V=2 B=1 depth %d CHOSEN fp32 (one frame)" % a.depth))
+    return out
 
 
 def extras(a, model, flags, batches, dev, sd, got, ref, nb):
@@ -560,7 +607,7 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
     errs = {"hip_" + a.precision: e(got), "reference_fp32_cpu": e(ref)}
     n_o = max(10, a.steps // 2)
-    for other in ("fp32", "fp32x3", "fp32_mfma"):          # the other fp32 engines: rate and distance from fp64
+    for other in ("fp32", "fp32_mfma"):                    # the other fp32 engine: rate and distance from fp64
         if other == a.precision:
             continue
         model.set_matmul_precision(other)
@@ -594,7 +641,7 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
     r3 = mpl_oracle.forward(sd3, f3, cpu(P3, 64), cpu(R3, 64), cpu(C3, 64))
     mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
-    roof16 = stack_roofline(m3, f3, a.batch, b3, "bf16")
+    roof16 = stack_roofline(m3, f3, a.batch, b3, "bf16", dev)
     extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1), "bf16_ms_per_step": round(a.batch / v16 * 1e3, 4),
                               "bf16_roofline": roof16,
                               "bf16_tflops": round(v16 * mpl_oracle.flop_count(f3) / 1e12, 1),
@@ -611,7 +658,7 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     v16d = a.batch * n3d / timed_steps(m3d, b3, n3d, 2)
     extra["cmu_v8_depth12"] = {"fp32_poses_per_s": round(v32d, 1), "bf16_poses_per_s": round(v16d, 1),
                                "bf16_ms_per_step": round(a.batch / v16d * 1e3, 4),
-                               "bf16_roofline": stack_roofline(m3d, f3d, a.batch, b3, "bf16")}
+                               "bf16_roofline": stack_roofline(m3d, f3d, a.batch, b3, "bf16", dev)}
     del m3d
     # PCIe-inclusive rate of the headline workload: the same forwards fed from pinned host tensors, H2D
     # of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
@@ -660,8 +707,22 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
             m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
             torch.cuda.synchronize()
         extra["v2_b1_latency_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
-        # the same frame through the team kernels (the small-batch engine of sm_stack.hip switched off: mpl_x3_stack_mode bit 3)
+        # roofline of the small-batch engine (sm_stack_kernel: every GEMM on the whole chip, the fp32 nn.Linear weights streamed
+        # once per forward): algorithmic bytes = the FPT weights of the depth + 1 block applications, against the HBM peak
         from openmpl_amd import cabi
+        cabi.profile_start()
+        for i in range(20):
+            m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+        torch.cuda.synchronize()
+        pr0 = cabi.profile_stop()
+        us0 = pr0["gemm"][0] / max(1, pr0["gemm"][1]) * 1e3
+        w0 = (a.depth + 1) * 8.0 * 544 * 544 * 4
+        extra["v2_b1_roofline"] = dict(kernel=stack_kernel_name("fp32", 1, 2, 544, dev), bound="hbm", launches_timed=pr0["gemm"][1],
+                                       avg_launch_us=round(us0, 1), algorithmic_bytes_per_launch=round(w0),
+                                       achieved=round(w0 / (us0 * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                       frac=round(w0 / (us0 * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                                       note="65 grid barriers x ~6 us, not bandwidth, bound this launch (DESIGN.md section 4)")
+        # the same frame through the team kernels (the small-batch engine of sm_stack.hip switched off: mpl_x3_stack_mode bit 3)
         try:
             cabi.check(cabi.load().mpl_x3_stack_mode(8), "stack mode")
             for i in range(5):

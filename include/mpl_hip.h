@@ -8,8 +8,8 @@
  * no torch types.  All `const float*` below are DEVICE pointers to fp32 data in the
  * reference's own parameter layouts (nn.Linear weight = [out][in] row-major, i.e. the
  * tensors of the reference state_dict are consumed as they are).  The one exception is
- * optional DERIVED data: the bf16 / split-operand copies of the FPT Linear weights that
- * mpl_pack_bf16 / mpl_split_bf16x3 build from those tensors; whoever hands them over
+ * optional DERIVED data: the packed fp16x2 / bf16 copies of the FPT Linear weights that
+ * mpl_pack_h2 / mpl_pack_bf16 build from those tensors; whoever hands them over
  * must rebuild them when the source parameters change (the Python binding keys them on
  * the parameters' storage addresses and versions).
  * `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); every call only
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 10
+#define MPL_HIP_ABI_VERSION 11
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -83,19 +83,15 @@ typedef struct mpl_block_weights {
      * accumulation (activations handed from GEMM to GEMM as bf16; LayerNorm statistics, softmax, GELU, the residual
      * stream and the output stay fp32) -- BASELINE.json configs[2] "bf16".  The fp32 tensors remain the source of truth. */
     const uint16_t *qkv_w16, *proj_w16, *fc1_w16, *fc2_w16;
-    /* Optional split operands (mpl_split_bf16x3) of the four Linear layers: qkv built with norm1 folded, fc1 with norm2
-     * folded, proj / fc2 plain.  When all four are non-NULL (and the *_w16 are NULL) in every block of a stack whose
-     * shape the engine supports (D a multiple of 544, n_tok <= 32), the stack runs as fp32 arithmetic on the bf16 matrix
-     * cores: every fp32 operand is the exact sum of three bf16 numbers, each product is accumulated in fp32 from its six
-     * significant partial products -- at least as accurate as an fp32 multiply (csrc/x3_gemm.hip) at 2.7x less matrix-
-     * pipe time than the native fp32 MFMA.  Shapes must satisfy mpl_split_bf16x3_bytes() != 0, else leave them NULL. */
+    /* qkv_w3: the row-local split operand of a d = 32 block (mpl_spt_pack for the SPT blocks of an mpl_spt_set, mpl_d32_pack for
+     * the keypoint-token FPT blocks); proj_w3 / fc1_w3 / fc2_w3 are unused and must be NULL (they carried the three-part bf16
+     * operands of the round-2 fp32 engine, removed in round 5). */
     const uint16_t *qkv_w3, *proj_w3, *fc1_w3, *fc2_w3;
     /* Optional fp16x2 operands (mpl_pack_h2) of the four Linear layers, same folding as above: the DEFAULT fp32 engine of the
      * FPT block stack (csrc/h2_gemm.hip).  Every fp32 operand is split in two fp16 parts under an exact power-of-two scale
      * (per weight column; static per activation column, from a data-free bound), each product is accumulated in fp32
      * from three partial products ("3xTF32" on the fp16 matrix cores): as accurate as an fp32 GEMM, half the matrix
-     * instructions and two thirds of the operand bytes of the *_w3 engine.  Used when all four are non-NULL (and *_w16,
-     * *_w3 are NULL) in every block; shapes must satisfy mpl_pack_h2_bytes() != 0.  qkv_h2 / fc1_h2 come from mpl_pack_h2 (norm1 /
+     * instructions of the round-2 three-part engine.  Used when all four are non-NULL (and the *_w16 are NULL) in every block; shapes must satisfy mpl_pack_h2_bytes() != 0.  qkv_h2 / fc1_h2 come from mpl_pack_h2 (norm1 /
      * norm2 folded); proj_h2 / fc2_h2 from mpl_pack_h2_scaled against the static output scales of the layer that produces their
      * input: in_scale = mpl_pack_h2_out_scale(qkv_h2, 3D, D) + 2D (the v columns) for proj, mpl_pack_h2_out_scale(fc1_h2, 2D, D)
      * for fc2.  The stack verifies that pairing on the device (fingerprints inside the operands) and poisons the call's output
@@ -180,22 +176,6 @@ int mpl_ln_linear(const float *x, int M, int K, const float *ln_w, const float *
                   const float *bias, int N, int epilogue, const float *residual, float *y, float *stats,
                   void *stream);
 
-/* Split operand of an nn.Linear layer (W[N][K], bias[N]) for the fp32-on-bf16-matrix-core GEMMs: three bf16 parts per
- * weight (hi + mid + lo == w exactly) in MFMA fragment order, followed by two fp32 vectors of N entries.  With
- * ln_w / ln_b != NULL the LayerNorm in front of the layer is folded in:  LN(x).W^T + b = rstd (x.(gamma o W)^T - mean s) + c,
- * the operand holds gamma o W, s_n = sum_k gamma_k W_nk and c_n = b_n + sum_k beta_k W_nk (else c = bias, s = 0).
- * mpl_split_bf16x3_bytes() is the size of `dst` in bytes, or 0 when the shape is not supported (N must be a multiple
- * of 136, K of 544). */
-size_t mpl_split_bf16x3_bytes(int N, int K);
-int mpl_split_bf16x3(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
-                     void *stream);
-/* mpl_ln_linear on the split operand W3 (built WITH ln_w / ln_b when has_ln): fp32 in, fp32 out, same epilogues.
- * `stats` as in mpl_ln_linear (needed when has_ln); `workspace` holds the split copy of x
- * (mpl_ln_linear_x3_workspace_bytes). */
-size_t mpl_ln_linear_x3_workspace_bytes(int M, int K);
-int mpl_ln_linear_x3(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W3, int N, int epilogue,
-                     const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
-
 /* Split operand of ONE SPT block (d = 32: qkv 96x32, proj 32x32, fc1 64x32, fc2 32x64): the four weights as two fp16 parts
  * each (hi | lo, MFMA fragment order) under one exact power-of-two scale per output column, with norm1 / norm2 folded into
  * the qkv / fc1 weights; behind them the epilogue vectors c_n (bias + folded LayerNorm offset), the multipliers sc_n and the
@@ -211,24 +191,26 @@ int mpl_spt_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
  * block application instead of four GEMMs and two LayerNorm-statistics passes. */
 int mpl_d32_pack(const mpl_block_weights *block, uint16_t *dst, void *stream);
 
-/* The same for the bf16 engine: ONE bf16 per weight (round to nearest even of gamma o W), K padded with zero k-tiles to a
- * multiple of 96, the same fold vectors (s summed over the ROUNDED weights).  mpl_ln_linear_bf16: operands rounded to bf16
- * (x before the folded LayerNorm is applied), products exact, fp32 accumulation; fp32 in, fp32 out. */
+/* Packed bf16 operand of an nn.Linear layer (W[N][K], bias[N]) for the bf16 engine (csrc/b1_gemm.hip): ONE bf16 per weight
+ * (round to nearest even of gamma o W) in MFMA fragment order, two 32-deep k-tiles per 2-KiB fragment slot (an odd k-tile count
+ * is padded with a zero k-tile), followed by fp32 vectors of N entries: with ln_w / ln_b != NULL the LayerNorm in front of the
+ * layer is folded in, LN(x).W^T + b = rstd (x16.(gamma o W)^T - mean s) + c with s_n = sum_k of the ROUNDED gamma_k W_nk and
+ * c_n = b_n + sum_k beta_k W_nk (else c = bias, s = 0).  mpl_pack_bf16_bytes() is the size of `dst` in bytes, or 0 when the
+ * shape is not supported (N must be a multiple of 136, K of 544). */
 size_t mpl_pack_bf16_bytes(int N, int K);
 int mpl_pack_bf16(const float *W, const float *bias, const float *ln_w, const float *ln_b, int N, int K, uint16_t *dst,
                   void *stream);
-int mpl_ln_linear_bf16(const float *x, int M, int K, int has_ln, float eps, const uint16_t *W1, int N, int epilogue,
-                       const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Diagnostics (tools/x3_phase.py): when non-NULL, every split-operand GEMM launch writes five shader-clock stamps per
+/* Diagnostics (tools/chain_phase.py): when non-NULL, every packed-operand GEMM launch writes five shader-clock stamps per
  * wave (entry, k-loop start, k-loop end, stores issued, stores drained) at device_buffer[(block * 8 + wave) * 8 ..];
  * the buffer must hold 64 bytes per wave of the largest launch.  NULL (the default) switches it off.  The stamps are
- * compiled only into a library built with -DX3_DBG=1 (MPL_HIPCC_FLAGS); in the product build the call is a no-op. */
+ * compiled only into a library built with -DH2_DBG=1 (MPL_HIPCC_FLAGS); in the product build the call is a no-op. */
 int mpl_x3_debug_buffer(void *device_buffer);
 /* Diagnostics / A-B: bit 0: 0 (default) = a block stack on packed operands is ONE persistent launch (row-tile chains of
- * workgroups, x3_stack_kernel / h2_stack_kernel); 1 = one launch per GEMM (results agree to <= 4 ulp, each mode is bitwise
- * deterministic).  Bits 1-2: 0 = the fp16x2 stack picks its stage by the shape of the launch (teams that own two or more row
- * tiles walk PAIRS of tiles, h2_stack2_kernel), 1 / 2 = force the one- / two-tile stage (bitwise the same poses).  Bit 3: no
+ * workgroups, h2_stack_kernel); 1 = one launch per GEMM (results agree to <= 4 ulp, each mode is bitwise
+ * deterministic).  Bits 1-2: 0 = the stack picks its stage by the shape of the launch (fp16x2: teams that own two or more row
+ * tiles walk PAIRS of tiles, h2_stack2_kernel; bf16: always one tile at a time), 1 / 2 = force the one- / two-tile stage
+ * (bitwise the same poses; bf16: h2_stackp_kernel, pairs in every phase).  Bit 3: no
  * small-batch engine (sm_stack.hip: stacks of at most 32 token rows run every GEMM on the whole chip with grid barriers in
  * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bits 8.. = stop after that
  * many GEMM phases (tools/chain_phase.py). */
@@ -315,7 +297,7 @@ int mpl_ln_linear_h2(const float *x, int M, int K, int has_ln, float eps, const 
                      const float *residual, float *y, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- device-side failures.  The block stack runs as ONE persistent launch whose workgroups hand operands to each
- * other (x3_gemm.hip); it needs all its workgroups resident, i.e. the device to itself for the duration of the launch
+ * other (h2_phase.hpp); it needs all its workgroups resident, i.e. the device to itself for the duration of the launch
  * (single tenant: launches of this library on different streams of one process are serialised by the library, other
  * processes on the same GPU are not).  A workgroup whose wait for a partner runs out (~10 s) never goes on with stale
  * operands: it sets a sticky per-device error word, the poses of that call are NaN, and EVERY later call on the device
@@ -338,7 +320,7 @@ int mpl_x3_spin_limit(int log2_polls);
 #define MPL_K_GEMM 2
 #define MPL_K_ATTENTION 3
 #define MPL_K_FUSE_HEAD 4
-#define MPL_K_PACK 5 /* derived-operand builders: mpl_pack_h2*, mpl_spt_pack, mpl_d32_pack, mpl_pack_bf16, mpl_split_bf16x3 */
+#define MPL_K_PACK 5 /* derived-operand builders: mpl_pack_h2*, mpl_spt_pack, mpl_d32_pack, mpl_pack_bf16 */
 #define MPL_K_COUNT 6
 int mpl_profile_start(void);
 int mpl_profile_stop(float *kind_ms, int *kind_launches, int n_kinds);

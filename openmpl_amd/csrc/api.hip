@@ -133,45 +133,17 @@ std::atomic<bool> g_x3_per_gemm{getenv("MPL_X3_LAUNCHES") != nullptr};
 std::atomic<int> g_spin_log2{23};    // polls before a wait inside a persistent kernel counts as lost (mpl_x3_spin_limit)
 std::atomic<int> g_x3_stop{0};   // diagnostics: stop a stack after this many GEMMs (0 = run everything)
 
-// split-operand path (x3_gemm.hip): the activations between the GEMMs of a block live as split A3 operands
-struct X3Ws {
-    unsigned short *x3, *att3, *hid3;
-    float* stats;
-    unsigned* counters;          // one arrival counter per row tile (x3_stack_kernel)
-    size_t bytes;
-};
-
-X3Ws carve_x3_ws(void* base, size_t M, size_t D, int rpt) {
-    X3Ws w;
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        char* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
-        off += align_up(bytes, 256);
-        return p;
-    };
-    w.x3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt, 3)));
-    w.att3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)D, rpt, 3)));
-    w.hid3 = reinterpret_cast<unsigned short*>(take(x3_act_bytes((int)M, (int)(2 * D), rpt, 3)));
-    w.stats = reinterpret_cast<float*>(take(M * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
-    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt + 1024) * sizeof(unsigned)));   // + X3_MAX_WGS placement words
-    w.bytes = off;
-    return w;
-}
-
-// 2 = every block carries fp16x2 operands (h2_gemm.hip, the default fp32 engine), 3 = split-bf16x3 operands, 1 = packed bf16
-// operands, 0 = none of them (or the shape has no packed layout): the stack then runs on the fp32 matrix instructions
+// 2 = every block carries fp16x2 operands (h2_gemm.hip, the default fp32 engine), 1 = packed bf16 operands (b1_gemm.hip), 0 = none
+// of them (or the shape has no packed layout): the stack then runs on the fp32 matrix instructions
 int stack_packed_parts(const mpl_block_weights* blocks, const uint8_t* schedule, int n_apps, int n_tok, int D, int H) {
-    if (n_apps <= 0 || !x3_attention_fusable(n_tok, D, H) || !x3_shape_ok(D, 2 * D)) return 0;
+    if (n_apps <= 0 || !h2_attention_fusable(n_tok, D, H) || !h2_shape_ok(D, 2 * D)) return 0;
     int np = 0;
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        const int bp = (b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16) ? 1
-                     : ((b.qkv_w3 && b.proj_w3 && b.fc1_w3 && b.fc2_w3) ? 3
-                     : ((b.qkv_h2 && b.proj_h2 && b.fc1_h2 && b.fc2_h2) ? 2 : 0));
+        const int bp = (b.qkv_w16 && b.proj_w16 && b.fc1_w16 && b.fc2_w16) ? 1 : ((b.qkv_h2 && b.proj_h2 && b.fc1_h2 && b.fc2_h2) ? 2 : 0);
         if (bp == 0 || (np && bp != np)) return 0;
         np = bp;
     }
-    if (np == 2 && (!h2_attention_fusable(n_tok, D, H) || !h2_shape_ok(D, 2 * D))) return 0;
     return np;
 }
 
@@ -201,51 +173,64 @@ H2Ws carve_h2_ws(void* base, size_t M, size_t D, int rpt) {
 int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
                    int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s);
 
-// Block stack on split operands: per application LN1+qkv+attention | proj+residual | LN2+fc1+GELU | fc2+residual, the
-// activations handed from epilogue to k loop as A3 (x3 -> att3 -> x3 -> hid3 -> x3), x itself stays fp32 in place.
-int block_stack_x3(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
-                   int n_apps, void* ws, size_t ws_bytes, int np, const unsigned** err_ws, hipStream_t s) {
-    const int M = n_seq * n_tok, rpt = x3_rows_per_tile(n_tok);
-    const X3Ws w = carve_x3_ws(ws, (size_t)M, (size_t)D, rpt);
-    if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
-    if (err_ws) *err_ws = w.counters + (M + rpt - 1) / rpt;
-    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
-    int rc;
-    // entry of the stack, one launch: the rows as packed operand, their LayerNorm slice partials, zeroed arrival counters
-    const int n_tiles = (M + rpt - 1) / rpt;
-    // (n_tiles arrival counters + the error word of this call, see launch_x3_stack)
-    if ((rc = launch_split_rows(x, M, D, D, rpt, w.x3, np, w.stats, w.counters, n_tiles + 1, s))) return rc;
-    auto op = [&](const mpl_block_weights& b, int i) -> const uint16_t* {
-        return np == 3 ? (&b.qkv_w3)[i] : (&b.qkv_w16)[i];     // {qkv, proj, fc1, fc2} operands of the engine in use
+// bf16 path (b1_gemm.hip): x stays fp32 in place (residual stream, statistics) and travels to the LayerNorm GEMMs as the packed
+// bf16 copy x16 that the residual epilogues rewrite; the attention output and the GELU output travel as packed bf16 operands
+struct B1Ws {
+    unsigned short *x16, *att1, *hid1;
+    float* stats;
+    unsigned* counters;
+    size_t bytes;
+};
+B1Ws carve_b1_ws(void* base, size_t M, size_t D, int rpt) {
+    B1Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? reinterpret_cast<char*>(base) + off : nullptr;
+        off += align_up(bytes, 256);
+        return p;
     };
-    // A/B switch (mpl_x3_stack_mode, or MPL_X3_LAUNCHES=1 in the environment): one launch per GEMM -- the same phases with
-    // kernel boundaries in between -- instead of the persistent row-tile chains
-    if (!g_x3_per_gemm.load(std::memory_order_relaxed)) {
-        const unsigned short* ops[MPL_MAX_APPS * 4];
-        if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
-        for (int a = 0; a < n_apps; ++a) {
-            const mpl_block_weights& b = blocks[schedule[a]];
-            for (int i = 0; i < 4; ++i) ops[4 * a + i] = op(b, i);
-        }
-        return launch_x3_stack(x, M, D, n_tok, H, ops, n_apps, w.x3, w.att3, w.hid3, w.stats, w.counters, eps, g_x3_stop.load(), np, true, s);
+    w.x16 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)D, rpt, 1)));
+    w.att1 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)D, rpt, 1)));
+    w.hid1 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)(2 * D), rpt, 1)));
+    w.stats = reinterpret_cast<float*>(take((M + 64) * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
+    w.counters = reinterpret_cast<unsigned*>(take(((M + rpt - 1) / rpt + 64) * sizeof(unsigned)));
+    w.bytes = off;
+    return w;
+}
+int block_stack_b1(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks, const uint8_t* schedule,
+                   int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
+    const int M = n_seq * n_tok, rpt = h2_rows_per_tile(n_tok);
+    const float eps = 1e-6f;  // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
+    if (n_apps > MPL_MAX_APPS) return MPL_E_UNSUPPORTED;
+    const B1Ws w = carve_b1_ws(ws, (size_t)M, (size_t)D, rpt);
+    if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
+    const int n_tiles = (M + rpt - 1) / rpt;
+    if (err_ws) *err_ws = w.counters + n_tiles;
+    int rc;
+    const unsigned short* ops[MPL_MAX_APPS * 4];
+    for (int a = 0; a < n_apps; ++a) {
+        const mpl_block_weights& b = blocks[schedule[a]];
+        for (int i = 0; i < 4; ++i) ops[4 * a + i] = (&b.qkv_w16)[i];
     }
+    // entry of the stack, one launch: the rows as packed bf16 operand, their LayerNorm slice partials, zeroed counters + error word
+    if ((rc = launch_b1_entry(x, M, D, D, rpt, w.x16, w.stats, w.counters, n_tiles + 1, s))) return rc;
+    if (!g_x3_per_gemm.load(std::memory_order_relaxed))
+        return launch_b1_stack(x, w.x16, M, D, n_tok, H, ops, n_apps, w.att1, w.hid1, w.stats, w.counters, eps, g_x3_stop.load(), s);
+    // A/B switch (mpl_x3_stack_mode): the same phases as one launch per GEMM
     const int stop = g_x3_stop.load();
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-        // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
-        if ((rc = launch_x3_qkv_attention(w.x3, op(b, 0), w.stats, eps, M, D, n_tok, H, w.att3, np, s))) return rc;
+        if ((rc = launch_b1_qkv_attention(w.x16, b.qkv_w16, w.stats, eps, M, D, n_tok, H, w.att1, s))) return rc;
         if (stop && 4 * a + 1 >= stop) return MPL_OK;
-        if ((rc = launch_x3_gemm(w.att3, op(b, 1), false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, D, rpt,
-                                 MPL_EPI_BIAS_RESIDUAL, np, s)))
+        if ((rc = launch_b1_gemm(w.att1, b.proj_w16, false, nullptr, 0.f, x, D, x, D, w.x16, w.stats, M, D, D, rpt, MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
         if (stop && 4 * a + 2 >= stop) return MPL_OK;
-        // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
-        if ((rc = launch_x3_gemm(w.x3, op(b, 2), true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid3, nullptr, M, 2 * D, D, rpt,
-                                 MPL_EPI_BIAS_GELU, np, s)))
+        if ((rc = launch_b1_gemm(w.x16, b.fc1_w16, true, w.stats, eps, nullptr, 0, nullptr, 0, w.hid1, nullptr, M, 2 * D, D, rpt,
+                                 MPL_EPI_BIAS_GELU, s)))
             return rc;
         if (stop && 4 * a + 3 >= stop) return MPL_OK;
-        if ((rc = launch_x3_gemm(w.hid3, op(b, 3), false, nullptr, 0.f, x, D, x, D, w.x3, w.stats, M, D, 2 * D, rpt,
-                                 MPL_EPI_BIAS_RESIDUAL, np, s)))
+        if ((rc = launch_b1_gemm(w.hid1, b.fc2_w16, false, nullptr, 0.f, x, D, x, D, w.x16, w.stats, M, D, 2 * D, rpt,
+                                 MPL_EPI_BIAS_RESIDUAL, s)))
             return rc;
     }
     return MPL_OK;
@@ -302,7 +287,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
     // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
-    // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 / fp32x3 request keeps its engine
+    // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
     if ((np0 == 0 || np0 == 2) && sm_stack_enabled() && n_apps <= MPL_MAX_APPS) {
         int n_blocks = 0;
         for (int a = 0; a < n_apps; ++a) n_blocks = schedule[a] + 1 > n_blocks ? schedule[a] + 1 : n_blocks;
@@ -314,7 +299,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     }
     if (const int np = np0) {
         if (np == 2) return block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
-        return block_stack_x3(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, np, err_ws, s);
+        return block_stack_b1(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
     }
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
@@ -346,7 +331,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     }
     for (int a = 0; a < n_apps; ++a) {
         const mpl_block_weights& b = blocks[schedule[a]];
-            // packed operands (split fp32 / bf16) take the block_stack_x3 route above; here they cannot be used
+            // packed operands (fp16x2 / bf16) take the routes above; here they cannot be used
         if (b.qkv_w3 || b.proj_w3 || b.fc1_w3 || b.fc2_w3 || b.qkv_w16 || b.proj_w16 || b.fc1_w16 || b.fc2_w16 || b.qkv_h2 ||
             b.proj_h2 || b.fc1_h2 || b.fc2_h2)
             return MPL_E_UNSUPPORTED;
@@ -389,12 +374,12 @@ size_t stack_ws_bytes(size_t M, size_t D, int n_tok) {
         const size_t bs = sm_stack_ws_bytes((int)M, (int)D);
         b = bs > b ? bs : b;
     }
-    const int rpt = x3_rows_per_tile(n_tok);
-    if (rpt > 0 && n_tok <= 32 && x3_shape_ok((int)D, (int)(2 * D))) {
-        const size_t b3 = carve_x3_ws(nullptr, M, D, rpt).bytes;
-        b = b3 > b ? b3 : b;
+    const int rpt = h2_rows_per_tile(n_tok);
+    if (rpt > 0 && n_tok <= 32 && h2_shape_ok((int)D, (int)(2 * D))) {
         const size_t b2 = carve_h2_ws(nullptr, M, D, rpt).bytes;
         b = b2 > b ? b2 : b;
+        const size_t b1 = carve_b1_ws(nullptr, M, D, rpt).bytes;
+        b = b1 > b ? b1 : b;
     }
     return b;
 }
@@ -505,15 +490,6 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
                           (timing && !ln_w) ? stats : nullptr, s);
 }
 
-size_t mpl_split_bf16x3_bytes(int N, int K) { return x3_operand_bytes(N, K, 3); }
-
-int mpl_split_bf16x3(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst,
-                     void* stream) {
-    clear_stale_hip_error();
-    if (mpl_split_bf16x3_bytes(N, K) == 0) return MPL_E_INVALID;
-    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 3, (hipStream_t)stream);
-}
-
 size_t mpl_spt_pack_bytes(void) { return spt_pack_bytes(); }
 
 int mpl_spt_pack(const mpl_block_weights* block, uint16_t* dst, void* stream) {
@@ -526,13 +502,12 @@ int mpl_d32_pack(const mpl_block_weights* block, uint16_t* dst, void* stream) {
     return launch_spt_pack(block, dst, 0, (hipStream_t)stream);
 }
 
-size_t mpl_pack_bf16_bytes(int N, int K) { return x3_operand_bytes(N, K, 1); }
+size_t mpl_pack_bf16_bytes(int N, int K) { return h2_operand_bytes(N, K, 1); }
 
-int mpl_pack_bf16(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst,
-                  void* stream) {
+int mpl_pack_bf16(const float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, uint16_t* dst, void* stream) {
     clear_stale_hip_error();
     if (mpl_pack_bf16_bytes(N, K) == 0) return MPL_E_INVALID;
-    return launch_split_bf16x3(W, N, K, ln_w, ln_b, bias, dst, 1, (hipStream_t)stream);
+    return launch_pack_b1(W, N, K, ln_w, ln_b, bias, dst, (hipStream_t)stream);
 }
 
 size_t mpl_pack_h2_bytes(int N, int K) { return h2_operand_bytes(N, K); }
@@ -602,46 +577,14 @@ int mpl_x3_spin_limit(int log2_polls) {
     static const bool inject_ok = getenv("MPL_FAULT_INJECT") != nullptr && atoi(getenv("MPL_FAULT_INJECT")) != 0;
     if ((log2_polls >> 8) != 0 && !inject_ok) return MPL_E_UNSUPPORTED;
     g_spin_log2.store(log2_polls & 0xff);
-    x3_set_spin_log2(log2_polls & 0xff);
     h2_set_spin_log2(log2_polls & 0xff);
     set_fault_injection(log2_polls >> 8);
     return MPL_OK;
 }
 
 int mpl_x3_debug_buffer(void* device_buffer) {
-    x3_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
     h2_set_debug_buffer(reinterpret_cast<unsigned long long*>(device_buffer));
     return MPL_OK;
-}
-
-size_t mpl_ln_linear_x3_workspace_bytes(int M, int K) { return x3_act_bytes(M, K, 64, 3); }
-
-static int ln_linear_packed(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
-                            const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, int np,
-                            void* stream) {
-    clear_stale_hip_error();
-    if (!x || !W3 || !y || x3_operand_bytes(N, K, np) == 0 || M <= 0) return MPL_E_INVALID;
-    const size_t need = x3_act_bytes(M, K, 64, np);
-    if (!workspace || workspace_bytes < need) return MPL_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (has_ln) {
-        if (!stats) return MPL_E_INVALID;
-        if ((rc = launch_row_stats(x, M, K, K, stats, s))) return rc;
-    }
-    unsigned short* a3 = reinterpret_cast<unsigned short*>(workspace);
-    if ((rc = launch_split_rows(x, M, K, K, 64, a3, np, nullptr, nullptr, 0, s))) return rc;
-    return launch_x3_gemm(a3, W3, has_ln != 0, stats, eps, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, np, s);
-}
-
-int mpl_ln_linear_x3(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W3, int N, int epilogue,
-                     const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
-    return ln_linear_packed(x, M, K, has_ln, eps, W3, N, epilogue, residual, y, stats, workspace, workspace_bytes, 3, stream);
-}
-
-int mpl_ln_linear_bf16(const float* x, int M, int K, int has_ln, float eps, const uint16_t* W1, int N, int epilogue,
-                       const float* residual, float* y, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
-    return ln_linear_packed(x, M, K, has_ln, eps, W1, N, epilogue, residual, y, stats, workspace, workspace_bytes, 1, stream);
 }
 
 int mpl_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int heads, float* out, void* stream) {

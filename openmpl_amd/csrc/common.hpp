@@ -121,26 +121,6 @@ bool qkv_attention_fusable(int n_tok, int dim, int heads);
 int launch_ln_qkv_attention(const float* x, int M, int D, const float* stats, const float* ln_w, const float* ln_b,
                             float eps, const float* W, const float* bias, int n_tok, int heads, float* att,
                             hipStream_t s);
-// GEMMs on the bf16 matrix cores from packed operands in fragment order, x3_gemm.hip.  np = 3: fp32 arithmetic (every
-// operand the exact sum of three bf16 parts, six partial products per product); np = 1: bf16 operands, one product.
-bool x3_shape_ok(int N, int K);
-size_t x3_operand_bytes(int N, int K, int np);            // packed weights + fold vectors; 0 when the shape has no layout
-size_t x3_act_bytes(int M, int K, int rpt, int np);       // packed activations of M rows, K columns, rpt rows per row tile
-int x3_rows_per_tile(int n_tok);
-void x3_set_debug_buffer(unsigned long long* p);   // bench-only: per-wave phase stamps of every x3 GEMM launch
-bool x3_attention_fusable(int n_tok, int dim, int heads);
-int launch_split_bf16x3(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias,
-                        unsigned short* dst, int np, hipStream_t s);
-int launch_split_rows(const float* X, int M, int K, int ldx, int rpt, unsigned short* dst, int np, float* stats,
-                      unsigned* counters, int n_counters, hipStream_t s);
-int launch_x3_gemm(const unsigned short* A3, const unsigned short* W3, bool ln, const float* stats, float eps, const float* R,
-                   int ldr, float* C, int ldc, unsigned short* C3, float* stats_out, int M, int N, int K, int rpt, int epi, int np,
-                   hipStream_t s);
-// counters: one arrival counter per row tile, then ONE error word (index n_tiles) that the kernel sets when a hand-off
-// was lost; all n_tiles + 1 words zero before the launch (counters_zeroed: the entry kernel of the stack did it)
-int launch_x3_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
-                    unsigned short* x3, unsigned short* att3, unsigned short* hid3, float* stats, unsigned* counters, float eps,
-                    int stop_after, int np, bool counters_zeroed, hipStream_t s);
 // ---- device-side failures (a persistent kernel whose wait for a partner workgroup ran out) -------------------------
 // One sticky word per device in pinned, device-visible host memory: kernels set it (system scope), the host reads it
 // without any synchronisation at the start of the next API call and fails that call (MPL_E_DEVICE) until it is cleared.
@@ -155,22 +135,20 @@ int take_fault_injection();
 // device through a process-global event, which a capture would turn into a captured event (later eager launches on other
 // streams would then depend on a graph-internal node) and a graph replay would bypass altogether
 int refuse_stream_capture(hipStream_t s);
-void x3_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
-void h2_set_spin_log2(int log2_polls);
+void h2_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
 void h2_set_row_tiles(int rt);             // A/B switch of the block stack: 0 by shape, 1 / 2 row tiles per stage
-// The persistent block-stack kernels (x3_stack_kernel, h2_stack_kernel) need every workgroup resident: the library
+// The persistent block-stack kernels (h2_stack_kernel and its pair forms, sm_stack_kernel) need every workgroup resident: the library
 // serialises its own launches of them per device, whatever stream they are on -- each launch waits for the event recorded
 // behind the previous one (api.hip).  The event exists from the first call (waiting on a never-recorded event is a no-op).
 hipEvent_t stack_chain_event(int dev);
 std::mutex& stack_chain_mutex(int dev);
-int launch_x3_qkv_attention(const unsigned short* A3, const unsigned short* W3, const float* stats, float eps, int M, int D,
-                            int n_tok, int heads, unsigned short* att3, int np, hipStream_t s);
 // fp32 GEMMs on the fp16 matrix cores from operands split in TWO fp16 parts (three partial products), h2_gemm.hip: the
 // default engine of the FPT block stack
 bool h2_shape_ok(int N, int K);
-size_t h2_operand_bytes(int N, int K);                    // packed weights + {c, sc, sw, bound, so}[N] + meta[8]; 0 = no layout
+size_t h2_operand_bytes(int N, int K, int np = 2);        // packed weights + {c, sc, sw, bound, so}[N] + meta[8]; 0 = no layout.  np = 1:
+                                                          // the bf16 operand of b1_gemm.hip (pairs of k-tiles, trailer {c, s}[N])
 const float* h2_out_scale(const unsigned short* op, int N, int K);   // so[N] inside an operand: static per-column scales of its outputs
-size_t h2_act_bytes(int M, int K, int rpt);
+size_t h2_act_bytes(int M, int K, int rpt, int np = 2);
 int h2_rows_per_tile(int n_tok);
 bool h2_attention_fusable(int n_tok, int dim, int heads);
 void h2_set_debug_buffer(unsigned long long* p);
@@ -186,6 +164,21 @@ int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const floa
                             int heads, unsigned short* att2, hipStream_t s);
 int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
+                    hipStream_t s);
+// bf16 GEMMs (operands rounded to bf16, fp32 accumulation) on the same stage as the h2 engine, b1_gemm.hip: BASELINE configs[2].
+// A stage carries a PAIR of k-tiles; every A operand arrives packed (x too: the residual epilogues keep a bf16 copy x16 of
+// the fp32 rows); a LayerNorm in front of a Linear is folded (gain into W, mean / rstd applied by the epilogue).
+int launch_pack_b1(const float* W, int N, int K, const float* ln_w, const float* ln_b, const float* bias, unsigned short* dst,
+                   hipStream_t s);
+// entry of a bf16 stack, one launch: x -> x16 (packed, zero padded), LayerNorm slice partials, zeroed counters + error word
+int launch_b1_entry(const float* X, int M, int K, int ldx, int rpt, unsigned short* x16, float* stats, unsigned* counters,
+                    int n_counters, hipStream_t s);
+int launch_b1_gemm(const unsigned short* A1, const unsigned short* W1, bool ln, const float* stats, float eps, const float* R, int ldr,
+                   float* C, int ldc, unsigned short* C1, float* stats_out, int M, int N, int K, int rpt, int epi, hipStream_t s);
+int launch_b1_qkv_attention(const unsigned short* x16, const unsigned short* W1, const float* stats, float eps, int M, int D, int n_tok,
+                            int heads, unsigned short* att1, hipStream_t s);
+int launch_b1_stack(float* x, unsigned short* x16, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
+                    unsigned short* att1, unsigned short* hid1, float* stats, unsigned* counters, float eps, int stop_after,
                     hipStream_t s);
 // Block stack for at most 16 token rows (sm_stack.hip): every GEMM on the whole chip (one 16-column tile per workgroup, weights
 // read in place), grid barriers in between, exact fp32 on the matrix cores

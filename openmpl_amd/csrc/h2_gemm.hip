@@ -54,71 +54,24 @@
 #include <stdlib.h>
 
 #include <mutex>
-#include <type_traits>
 
-#include "gemm_common.hpp"
+#include "h2_phase.hpp"
 
 namespace mpl {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int H2_RG = 2 * 1024;              // A bytes per (row group, k-tile): hi | lo fragment
-constexpr int H2_A = 4 * H2_RG;              // A bytes per stage (64 rows)
-constexpr int H2_W = 18 * 1024;              // W bytes per k-tile of a 136-column group: 9 slots x {hi, lo}
-constexpr int H2_STAGE = H2_A + H2_W;        // 26624
-constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
-constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
-constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
-constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
-constexpr int H2_T0 = 5;
-constexpr int H2_MAX_WGS = 1024;
-constexpr int H2_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the generic attention epilogue
-constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (|z| <= sqrt(K): fine up to K = 2048)
-constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind the fragments: c | sc | sw | bound | so
-#ifndef H2_DBG
-#define H2_DBG 0
-#endif
-#ifndef H2_ABL
-#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier
-#endif
-#ifndef H2_WT_AUX
-#define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
-#endif
-#ifndef H2_WSPLIT
-#define H2_WSPLIT 1    // W pieces per stage and wave: 0 = 1 (waves 0..3) / 4 (waves 4, 5) / 3 (waves 6, 7); 1 = 2 / 3 / 2
-#endif
-#define H2_R2_WC0 1      // W pieces per wave role of the two-tile stage (the waves 0..3 carry four A pieces)
-#define H2_R2_WC1 4
-#define H2_R2_WC2 3
-#define H2_WC0 (H2_WSPLIT == 1 ? 2 : 1)
-#define H2_WC1 (H2_WSPLIT == 1 ? 3 : 4)
-#define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
-#ifndef H2_KPS2
-#define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
-                       // ring slot of slack); 0: a barrier in front of every stage, refill 6 stages ahead
-#endif
-
-__host__ __device__ constexpr int h2_slot_tile(int s) { return s < 4 ? s : (s == 4 ? 8 : s - 1); }
-__host__ __device__ inline int h2_col(int t, int kq, int j, int G) {
-    if (t < 4 * G) return 136 * (t >> 2) + 32 * (t & 3) + 16 * (j >> 2) + 4 * kq + (j & 3);
-    return 136 * (4 * (t - 4 * G) + kq) + 128 + j;
-}
 
 // A folded LayerNorm needs K <= 1088 (the kernel combines at most 8 slice partials per row; the static 2^10 scale of a normalised row, |z| <= sqrt(K) 2^10, would allow K <= 2048);
 // launch_pack_h2 checks that; the packed layout itself exists for every multiple of 544
 bool h2_shape_ok(int N, int K) { return N > 0 && K > 0 && N % BN == 0 && K % (4 * BN) == 0 && K <= 8704; }
 
-size_t h2_operand_bytes(int N, int K) {
-    if (!h2_shape_ok(N, K)) return 0;
-    return (size_t)(N / BN) * (K / BK) * H2_W + ((size_t)H2_TRV * N + 8) * sizeof(float);
+size_t h2_operand_bytes(int N, int K, int np) {
+    if (!h2_shape_ok(N, K) || (np != 1 && np != 2)) return 0;
+    return (size_t)(N / BN) * h2_ksteps(K, np) * H2_W + ((size_t)H2_TRV * N + 8) * sizeof(float);
 }
-size_t h2_act_bytes(int M, int K, int rpt) {
-    if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM) return 0;
+size_t h2_act_bytes(int M, int K, int rpt, int np) {
+    if (M <= 0 || K <= 0 || K % (4 * BN) || rpt <= 0 || rpt > BM || (np != 1 && np != 2)) return 0;
     // an even number of row tiles: the two-tile stage (h2_stack2_kernel) requests the strips of a pair, also of an absent partner
     const size_t tiles = ((((size_t)M + rpt - 1) / rpt) + 1) / 2 * 2;
-    return tiles * 4 * (K / BK) * H2_RG;
+    return tiles * 4 * h2_ksteps(K, np) * H2_RG;
 }
 int h2_rows_per_tile(int n_tok) { return (n_tok >= 1 && n_tok <= BM) ? (BM / n_tok) * n_tok : 0; }
 bool h2_attention_fusable(int n_tok, int dim, int heads) {
@@ -127,22 +80,6 @@ bool h2_attention_fusable(int n_tok, int dim, int heads) {
     if (BN % hd || (hd & 3)) return false;
     const int S = BM / n_tok, HP = BN / hd;
     return (size_t)(BM * H2_ATT_TS + S * HP * n_tok * n_tok) * sizeof(float) <= (size_t)H2_NST * H2_STAGE;
-}
-
-// 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept)
-__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
-}
-// largest power of two p with p * v <= 2^15 (v > 0, finite); 1 for v == 0
-__host__ __device__ inline float h2_window_scale(float v) {
-    if (!(v > 0.f)) return 1.0f;
-    int e;
-    (void)frexpf(32768.0f / v, &e);            // 32768 / v = m 2^e, m in [0.5, 1)  ->  2^(e-1) <= 32768 / v
-    e = e - 1 < -120 ? -120 : (e - 1 > 120 ? 120 : e - 1);   // both the scale and its reciprocal stay normal fp32 numbers
-    return ldexpf(1.0f, e);
 }
 
 // ---------------------------------------------------------------------------------------------- weight operand
@@ -296,11 +233,6 @@ int launch_pack_h2(const float* W, int N, int K, const float* ln_w, const float*
 // With `ops` (the stack's operands) block 0 also checks that every proj / fc2 operand was packed against the static scales its
 // producer applies (fingerprints in meta[6], meta[7], h2_meta_kernel): a mismatch sets the error words of the call -- the
 // poses come out NaN and the device reports MPL_E_DEVICE -- instead of multiplying under the wrong scales.
-struct H2Ops {
-    int n_apps, D;
-    unsigned* err_host;
-    const char* w[MPL_MAX_APPS][4];
-};
 __global__ __launch_bounds__(256) void h2_entry_kernel(const float* __restrict__ X, int M, int K, int ldx, float* __restrict__ stats,
                                                         unsigned* __restrict__ counters, int n_counters, const H2Ops ops) {
     if (blockIdx.x == 0 && counters) {
@@ -422,1143 +354,16 @@ int launch_h2_pack_rows(const float* X, int M, int K, int ldx, int rpt, unsigned
     return hip_check_launch();
 }
 
-// ---------------------------------------------------------------------------------------------- GEMM
-struct H2Args {
-    const char* A2;          // packed activations (GEMMs without LayerNorm); unused when LNF
-    const float* X;          // LNF: the fp32 rows, normalised and split in the k loop
-    int ldx;
-    const char* W2;          // packed weights (gamma folded for LNF)
-    const float* cvec;       // c per output column
-    const float* svec;       // sc per output column: 1 / (sa sw)
-    const float* stats;      // LNF: per-row slice partials of the K-wide input rows
-    const float* a_inv;      // !LNF: device scalar, reciprocal of the scale of A2 (NULL = 1)
-    const float* ovec;       // C2 != NULL: so per output column (absolute column index), the static scales of the packed output
-    const float* R;          // residual (fp32), EPI_RES
-    int ldr;
-    float* C;                // fp32 output (optional)
-    int ldc;
-    char* C2;                // packed output (optional): the next GEMM's operand
-    float* stats_out;        // residual epilogue: slice partials of the rows produced
-    int M, N, K, rpt;
-    int grid_m, grid_n;
-    float eps;
-    int att_ntok, att_hd;
-    unsigned long long* dbg;
-    unsigned* err_ws;        // chain mode: see x3_gemm.hip X3Args
-    unsigned* err_host;
-    int spin_log2;
-};
-
 static std::atomic<unsigned long long*> g_h2_dbg{nullptr};
 void h2_set_debug_buffer(unsigned long long* p) { g_h2_dbg.store(p); }
 static std::atomic<int> g_h2_spin_log2{23};
 static std::atomic<int> g_h2_rt{0};          // 0: by shape; 1 / 2: force the one- / two-tile stage (A/B switch)
 void h2_set_row_tiles(int rt) { g_h2_rt.store(rt); }
 void h2_set_spin_log2(int v) { g_h2_spin_log2.store(v & 0xff); }
+unsigned long long* h2_debug_buffer() { return g_h2_dbg.load(); }
+int h2_spin_log2() { return g_h2_spin_log2.load(); }
+int h2_row_tiles() { return g_h2_rt.load(); }
 
-enum { H2_EPI_BIAS = 0, H2_EPI_GELU = 1, H2_EPI_RES = 2, H2_EPI_ATT = 3 };
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ void h2_st16(bool wt, void* base, unsigned off, const u32x4& w) {
-    if (wt) __builtin_amdgcn_raw_buffer_store_b128(w, h2_rsrc(base), off, 0, H2_WT_AUX);
-    else __builtin_amdgcn_raw_buffer_store_b128(w, h2_rsrc(base), off, 0, 0);
-}
-__device__ __forceinline__ void h2_st8(bool wt, void* base, unsigned off, const u32x2& h) {
-    if (wt) __builtin_amdgcn_raw_buffer_store_b64(h, h2_rsrc(base), off, 0, H2_WT_AUX);
-    else __builtin_amdgcn_raw_buffer_store_b64(h, h2_rsrc(base), off, 0, 0);
-}
-__device__ __forceinline__ u32x4 h2_ld16_l2(const void* base, unsigned off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(h2_rsrc(base), off, 0, 16);
-}
-// pack 8 fp32 values (already multiplied by the output scale) of one fragment lane: k-tile t of the strip at `base`
-__device__ __forceinline__ void h2_emit_frag(bool wt, char* base, int t, unsigned lo_off, const float (&x)[8]) {
-    f16x8 hi, lo;
-    split2(x, hi, lo);
-    h2_st16(wt, base, (unsigned)(t * H2_RG) + lo_off, __builtin_bit_cast(u32x4, hi));
-    h2_st16(wt, base, (unsigned)(t * H2_RG + 1024) + lo_off, __builtin_bit_cast(u32x4, lo));
-}
-// the 4 values (8 bytes per part) a lane contributes to the shared tail k-tile
-__device__ __forceinline__ void h2_emit_tail(bool wt, char* base, int t, unsigned lo_off, const float (&x)[8]) {
-    f16x8 hi, lo;
-    split2(x, hi, lo);
-    const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
-    h2_st8(wt, base, (unsigned)(t * H2_RG) + lo_off, u32x2{h[0], h[1]});
-    h2_st8(wt, base, (unsigned)(t * H2_RG + 1024) + lo_off, u32x2{l[0], l[1]});
-}
-
-// Attention.forward :55-64 on the q | k | v tile T[64][H2_ATT_TS] (+bias, LayerNorm applied) of this workgroup's 136
-// channels, generic form (any n_tok <= 32, any head width that divides 136): S whole sequences of nt tokens; the output
-// is written as packed A2 of width Dq (column c scaled by so[c], the static scales of this workgroup's 136 v columns) for proj.  The 4-token shapes never come here (registers).
-__device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C2, int tile_m,
-                                             int g_out, int Dq, const float* so) {
-    const int hd4 = hd >> 2;
-    const int HP = BN / hd, nn = nt * nt;
-    const float scale = 1.0f / sqrtf((float)hd);
-    for (int t = tid; t < S * HP * nn; t += 512) {
-        const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
-        const float* q = T + (sq * nt + i) * H2_ATT_TS + hh * hd;
-        const float* k = T + (sq * nt + j) * H2_ATT_TS + BN + hh * hd;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int e = 0; e < hd4; ++e) {
-            const float4 a = ld4(q + 4 * e), b = ld4(k + 4 * e);
-            s0 = fmaf(a.x, b.x, s0);
-            s1 = fmaf(a.y, b.y, s1);
-            s2 = fmaf(a.z, b.z, s2);
-            s3 = fmaf(a.w, b.w, s3);
-        }
-        SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
-    }
-    __syncthreads();
-    for (int t = tid; t < S * HP * nt; t += 512) {
-        float* pr = SC + t * nt;
-        float mx = pr[0];
-        for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
-        float l = 0.f;
-        for (int j = 0; j < nt; ++j) {
-            const float e = __expf(pr[j] - mx);
-            pr[j] = e;
-            l += e;
-        }
-        const float inv = 1.0f / l;
-        for (int j = 0; j < nt; ++j) pr[j] *= inv;
-    }
-    __syncthreads();
-    const int Go = Dq / BN;
-    const int strip = (Dq / BK) * H2_RG;                         // bytes of one row group of the output operand
-    char* cbase = C2 + (size_t)tile_m * 4 * strip;
-    auto pv4 = [&](int row, int c) -> float4 {
-        float4 o = {0.f, 0.f, 0.f, 0.f};
-        if (row < S * nt) {
-            const int sq = row / nt, i = row - sq * nt;
-            const int hh = c / hd;
-            const float* pr = SC + ((sq * HP + hh) * nt + i) * nt;
-            const float* v = T + (sq * nt) * H2_ATT_TS + 2 * BN + c;
-            for (int j = 0; j < nt; ++j) {
-                const float4 vv = ld4(v + j * H2_ATT_TS);
-                const float pj = pr[j];
-                o.x = fmaf(pj, vv.x, o.x);
-                o.y = fmaf(pj, vv.y, o.y);
-                o.z = fmaf(pj, vv.z, o.z);
-                o.w = fmaf(pj, vv.w, o.w);
-            }
-        }
-        return o;
-    };
-    for (int t = tid; t < BM * 16; t += 512) {
-        const int li = t & 15, kq = (t >> 4) & 3, rg = (t >> 6) & 3, p = t >> 8;
-        const int row = rg * 16 + li;
-        const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
-        const float4 sa = ld4(so + 32 * p + 4 * kq), sb = ld4(so + 32 * p + 16 + 4 * kq);       // static scale per column
-        const float x[8] = {a.x * sa.x, a.y * sa.y, a.z * sa.z, a.w * sa.w, b.x * sb.x, b.y * sb.y, b.z * sb.z, b.w * sb.w};
-        h2_emit_frag(WT, cbase, 4 * g_out + p, (unsigned)(rg * strip + (kq * 16 + li) * 16), x);
-    }
-    for (int t = tid; t < BM * 2; t += 512) {
-        const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
-        const int row = rg * 16 + li;
-        const float4 a = pv4(row, 128 + 4 * kq);
-        const float4 sa = ld4(so + 128 + 4 * kq);
-        const float x[8] = {a.x * sa.x, a.y * sa.y, a.z * sa.z, a.w * sa.w, 0.f, 0.f, 0.f, 0.f};
-        h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(rg * strip + ((g_out & 3) * 16 + li) * 16 + kq * 8), x);
-    }
-}
-
-// One GEMM of one workgroup tile (tm, tn): everything a wave does for its NTW slots starting at slot `slot0`.
-// CHAIN = false: the GEMM is a launch of its own.  CHAIN = true: one phase of h2_stack_kernel (see there): `chain` counts
-// the arrivals of the team, the A operand (and the LayerNorm partials) may be read once it reaches `chain_need`, and this
-// workgroup arrives when its outputs are written.  Returns false when the wait timed out (error words set, nothing computed).
-// WC = W pieces this wave requests per stage (2 for the waves 0..3, 3 for the waves 4, 5, 2 for the waves 6, 7): a template
-// parameter, so that neither the requests nor the counted waits need a branch in the k loop.
-// RT = row tiles per workgroup.  RT = 2 (h2_stack2_kernel: teams that own two or more row tiles): the stage carries the A
-// pieces of TWO row tiles (8 row groups, 16 KiB) against the same 18 KiB of W -- 34 KiB for 54 MFMAs per SIMD instead of 26 KiB
-// for 27, the W fragments are read from LDS once for both tiles -- in a ring of 4 with one barrier per stage (a stage is as long
-// as two of the RT = 1 stages, so that IS the two-stage barrier period).  `tm` then counts pairs of row tiles.  The arithmetic of
-// every output element is the same in both forms (same k order, same product order per accumulator, same epilogue).
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1>
-__device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
-                                         unsigned* chain, unsigned chain_need, bool arrive = true) {
-    constexpr int ABYTES = RT * 4 * H2_RG;       // A bytes per stage
-    constexpr int STAGE = ABYTES + H2_W;
-    constexpr int NST = RT == 1 ? H2_NST : 4;
-    constexpr int APW = 2 * RT;                  // A pieces a wave 0..3 requests per A stage
-    static_assert(NST * STAGE <= H2_VEC, "ring too large");
-    static_assert(RT == 1 || (RT == 2 && EPI != H2_EPI_ATT && NPASS <= 2 && CHAIN), "two row tiles per stage: proj / fc1 / fc2 of a stack");
-    // P2: one barrier per TWO stages.  At the barrier in front of an even stage e every wave has its pieces of the stages
-    // <= e + 2 landed and has finished reading the fragments of the stages <= e, so stage e may refill the slot of stage e - 1
-    // and stage e + 1 the slot of stage e: a refill goes DIST = NST - 1 stages ahead.  Nothing but the DMA landing has to be
-    // published: the LayerNorm operand stays RAW in LDS and every wave that multiplies it normalises + splits its lane's eight
-    // values in registers (both waves of a row group do the same arithmetic; the in-place conversion by the requesting wave
-    // that this replaced needed every barrier and made the waves 0..3 the slow half of the stage).
-    constexpr bool P2 = H2_KPS2 != 0 && RT == 1;
-    constexpr int DIST = P2 ? NST - 1 : NST;
-    constexpr bool LEAD = NTW == H2_T0;          // waves 0..3 (slots 0..4): multiply first, load afterwards; bring the epilogue vectors
-    constexpr bool HAS_A = LEAD;                 // ... and the A pieces (the second row tile's pieces moved to the waves 4..7, with the
-                                                 // 2 / 3 / 2 W split: measured 0 at M = 8192, tools/ab_rt2.sh, and removed again)
-    constexpr bool WT = CHAIN;
-    const int lane = tid & 63;
-    const int rg = wave & 3;
-    const int li = lane & 15, kq = lane >> 4;
-    const int M = a.M, N = a.N, K = a.K;
-    const int m0 = tm * RT * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
-    const int Dq = N / 3;
-    const int KT = K / BK, G = K / BN;
-    const int T = NPASS * KT;                    // stages: stage u carries W of pass u % NPASS, and A when that pass is 0
-    auto colbase = [&](int pass) -> int { return NPASS == 3 ? pass * Dq + n0 : n0 + pass * BN; };
-    const unsigned long long t_entry = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-
-    const int row_l = rg * 16 + li;
-    bool row_ok[RT];
-    int row[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        row_ok[rt] = row_l < a.rpt && m0 + rt * a.rpt + row_l < M;
-        row[rt] = row_ok[rt] ? m0 + rt * a.rpt + row_l : (M - 1);
-    }
-
-    // ---- DMA pieces of this wave.  W (18 per stage): waves 4, 5 pieces 0..2 / 3..5, waves 6, 7 pieces 6, 7 / 8, 9, wave
-    // w < 4 pieces 10 + 2 w, 11 + 2 w (H2_WSPLIT 0: 4 / 4 / 3 / 3 and one each).  A (8 per A stage): waves 0..3 the two pieces
-    // of row group `wave`.  (Moving ALL W pieces to the waves 4..7 paid while the waves 0..3 also converted the LayerNorm
-    // operand in place, -3 %; it costs 1-5 % now.)
-    // RT = 2: the waves 0..3 carry four A pieces, so they take one W piece each and the waves 4..7 four / three (the 1 / 4 / 3 split)
-    constexpr bool WS1 = H2_WSPLIT == 1 && RT == 1;
-    const int w_first = WS1 ? (LEAD ? 10 + 2 * wave : (wave < 6 ? 3 * (wave - 4) : 6 + 2 * (wave - 6)))
-                            : (LEAD ? 14 + wave : (wave < 6 ? 4 * (wave - 4) : 8 + 3 * (wave - 6)));
-    static_assert(WS1 ? (LEAD ? WC == 2 : (WC == 3 || WC == 2)) : (LEAD ? WC == 1 : (WC == 3 || WC == 4)), "W pieces per wave");
-    constexpr int w_cnt = WC;
-    unsigned voW = (unsigned)(lane * 16 + w_first * 1024);
-    // A source offsets of this lane.  Packed operand: 16 B per lane and part.  fp32 rows (LNF): the lane's 4 + 4 columns of
-    // its row; full k-tiles start at column 4 kq (second piece +16 columns), tail k-tiles at 136 kq + 128 (second piece +4)
-    unsigned voA[RT], voT[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        voA[rt] = (unsigned)(lane * 16);
-        voT[rt] = 0;
-        if (LNF) {
-            voA[rt] = (unsigned)(((size_t)(row[rt] - m0) * a.ldx + 4 * kq) * 4);
-            voT[rt] = (unsigned)(((size_t)(row[rt] - m0) * a.ldx + 136 * kq + 128) * 4);
-        }
-        asm volatile("" : "+v"(voA[rt]), "+v"(voT[rt]));
-    }
-    asm volatile("" : "+v"(voW));
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    int iw_t = 0, iw_g = 0, ia_t = 0, ia_kt = 0;
-    unsigned iw_slot = 0, ia_slot = 0;
-    const char* is_w[NPASS];
-#pragma unroll
-    for (int g = 0; g < NPASS; ++g) is_w[g] = a.W2 + (size_t)(colbase(g) / BN) * KT * H2_W;
-    // packed operand: the strip of row group (wave & 3) of row tile tm RT + rt; fp32 rows: the first row of the (pair of) tile(s)
-    const char* is_a[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-        is_a[rt] = LNF ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
-                       : a.A2 + (((size_t)tm * RT + rt) * 4 + (wave & 3)) * KT * H2_RG;
-    auto w_pieces = [&](const char* src, unsigned dst) {
-        asm volatile(
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %0, %1"
-            :
-            : "v"(voW), "s"(src), "s"(dst)
-            : "memory");
-        if (w_cnt > 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voW), "s"(src) : "memory");
-        if (w_cnt > 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voW), "s"(src) : "memory");
-        if (w_cnt > 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voW), "s"(src) : "memory");
-    };
-    // the two A pieces of this wave's row group (of each of the RT row tiles) for A k-tile ia_kt into stage slot `slot` (waves
-    // 0..3; M0 is the caller's); row tile rt lives in the row groups 4 rt .. 4 rt + 3 of the stage
-    auto a_pieces = [&](unsigned slot) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const unsigned dst = lds0 + slot + (unsigned)(((wave & 3) + 4 * rt) * H2_RG);
-            if (!LNF) {
-                if (CHAIN)
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024 sc1"
-                                 : : "v"(voA[rt]), "s"(is_a[rt]), "s"(dst) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                                 : : "v"(voA[rt]), "s"(is_a[rt]), "s"(dst) : "memory");
-                is_a[rt] += H2_RG;
-            } else {
-                // raw fp32: the lane's columns j = 0..3 land in the first KiB (where the hi fragment will be), j = 4..7 in the second;
-                // the instruction offset would move BOTH addresses, so the second piece gets its own source base and M0
-                const bool full = ia_kt < 4 * G;
-                const char* src = full ? is_a[rt] + (size_t)(136 * (ia_kt >> 2) + 32 * (ia_kt & 3)) * 4 : is_a[rt] + (size_t)(136 * 4 * (ia_kt - 4 * G)) * 4;
-                const char* src2 = src + (full ? 64 : 16);
-                const unsigned vo = full ? voA[rt] : voT[rt];
-                if (CHAIN)
-                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1"
-                                 : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
-                else
-                    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                                 : : "v"(vo), "s"(src), "s"(src2), "s"(dst), "s"(dst + 1024u) : "memory");
-            }
-        }
-        ++ia_kt;
-    };
-    auto issue_w = [&]() {
-        const unsigned keep = dma_m0_save();
-#pragma unroll
-        for (int g = 0; g < NPASS; ++g)
-            if (g == iw_g) {
-                w_pieces(is_w[g], lds0 + iw_slot + (unsigned)(ABYTES + w_first * 1024));
-                is_w[g] += H2_W;
-            }
-        if (++iw_g == NPASS) iw_g = 0;
-        dma_m0_restore(keep);
-        ++iw_t;
-        iw_slot += STAGE;
-        if (iw_slot == NST * STAGE) iw_slot = 0;
-    };
-    auto issue_a = [&]() {
-        if ((ia_t % NPASS) == 0 && HAS_A) {
-            const unsigned keep = dma_m0_save();
-            a_pieces(ia_slot);
-            dma_m0_restore(keep);
-        }
-        ++ia_t;
-        ia_slot += STAGE;
-        if (ia_slot == NST * STAGE) ia_slot = 0;
-    };
-    // steady state: stage t + NST lives where stage t lived; NST is a multiple of NPASS, so the refilled stage has the pass of
-    // the current one (compile-time at the call site) and carries A exactly when the current one did
-    auto refill_fast = [&](auto wp_c, auto ai_c, unsigned slot) {
-        constexpr int g = decltype(wp_c)::value;
-        constexpr bool with_a = decltype(ai_c)::value;
-        const unsigned keep = dma_m0_save();
-        w_pieces(is_w[g], lds0 + slot + (unsigned)(ABYTES + w_first * 1024));
-        is_w[g] += H2_W;
-        if (with_a && HAS_A) a_pieces(slot);
-        dma_m0_restore(keep);
-    };
-    static_assert(NST % NPASS == 0, "ring depth must be a multiple of NPASS");
-
-    // ---- epilogue vectors c, sc of this workgroup's columns into the spare 4 KiB of LDS (front of the DMA queue), and behind
-    // them the static scales so of the columns that leave as a packed operand (attention: the v pass; else every pass)
-    constexpr int NSO = EPI == H2_EPI_ATT ? 1 : (EPI == H2_EPI_RES ? 0 : NPASS);
-    constexpr int VSO = NPASS * 2 * BN;                            // float offset of the so block inside the vector region
-    static_assert((NPASS * 2 + NSO) * BN * 4 <= 4092, "epilogue vectors overflow the spare LDS");
-    if (LEAD) {
-        constexpr int NV = NPASS * 2 * (BN / 4);                   // float4s: [pass][c | sc][34]
-        int idx = wave * 64 + lane;
-        const bool vec = idx < NV;
-        const bool on = vec || (idx < NV + NSO * (BN / 4) && a.ovec != nullptr);
-        const int q = idx - NV;                                    // so block: [pass (attention: the v pass only)][34]
-        idx = vec ? idx : 0;
-        const int vp = idx / (2 * (BN / 4)), which = (idx / (BN / 4)) & 1, c4 = idx % (BN / 4);
-        const float* src = (which ? a.svec : a.cvec) + colbase(vp) + 4 * c4;
-        if (!vec && on) src = a.ovec + colbase(EPI == H2_EPI_ATT ? 2 : q / (BN / 4)) + 4 * (q % (BN / 4));
-        if (on) dma16(src, lds0 + (unsigned)(H2_VEC + wave * 1024));
-    }
-    // ---- prologue.  Chain mode: W(0) does not depend on the other workgroups and is requested BEFORE the wait for them;
-    // the poll is the job of wave 7 (lane 0), its first look goes out before any DMA piece of the wave.
-    bool arrived = !CHAIN;
-    if (CHAIN && !LEAD && wave == 7)
-        arrived = __hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need;
-    issue_w();
-    if (CHAIN) {
-        if (!LEAD && wave == 7 && !arrived) {
-            const unsigned lim = 1u << a.spin_log2;
-            unsigned spin = 0;
-            for (; spin < lim; ++spin) {
-                if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (spin == lim && lane == 0) {     // a lost partner is an ERROR, never a licence to go on (x3_gemm.hip)
-                *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 1u;
-                if (a.err_ws) __hip_atomic_store(a.err_ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.err_host) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (*reinterpret_cast<volatile unsigned*>(smem + H2_FAIL)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return false;
-        }
-    }
-    const unsigned long long t_chain = (H2_DBG == 2 && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    issue_a();
-    // LNF: the row statistics (slice partials {mean, M2} written by the producers of x) of this wave's 16 rows, requested
-    // right behind A(0).  NPASS >= 2: by LDS-DMA (L1-bypassing in chain mode) into the A region of stage slot 1, which a
-    // pass-1 stage never uses -- an ordinary load here would make the compiler drain the WHOLE queue (it cannot see the
-    // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
-    // RT = 2: into the 20 KiB its ring of 4 x 34 KiB leaves free below the vector region (every stage of a one-pass GEMM carries A)
-    constexpr unsigned ST_LDS = RT == 2 ? NST * STAGE : STAGE;           // + 1 KiB per wave, + 8 KiB per row tile
-    constexpr bool ST_DMA = NPASS >= 2 || RT == 2;
-    static_assert(RT == 1 || ST_LDS + 16384 <= H2_VEC, "statistics rows overlap the epilogue vectors");
-    float4 st_raw[4];
-    if (LNF) {
-        const int ns = K / BN;
-        if constexpr (ST_DMA) {
-            // lane l brings the partials of slices 2q, 2q+1 (16 B) of row 16 wave + l / (ns / 2), q = l % (ns / 2)
-            const int hpr = ns >> 1;
-            if (lane < 16 * hpr) {
-                // lane / hpr by a multiplication (lane < 64, hpr <= 8: exact): a division by a run-time number costs a
-                // reciprocal sequence that the compiler hoists out of the phase loop and keeps alive (it spilled)
-                const unsigned inv = 65536u / (unsigned)hpr + 1u;
-                const int lq = (int)(((unsigned)lane * inv) >> 16);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    int r = m0 + rt * a.rpt + 16 * rg + lq;
-                    r = r < M ? r : M - 1;
-                    const float* g = a.stats + ((size_t)r * ns + 2 * (lane - lq * hpr)) * 2;
-                    unsigned keep;
-                    if (CHAIN)
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024 + rt * 8192)) : "memory");
-                    else
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(g), "s"(lds0 + ST_LDS + (unsigned)(wave * 1024 + rt * 8192)) : "memory");
-                }
-            }
-        } else {
-
-            const float* sp = a.stats + (size_t)row[0] * ns * 2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sp + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-#pragma unroll
-    for (int t = 1; t < DIST; ++t) {
-        issue_w();
-        issue_a();
-    }
-    const float ainv = (!LNF && a.a_inv) ? a.a_inv[0] : 1.0f;
-
-    // residual of this lane's outputs (fp32 rows this workgroup wrote itself two phases ago, or a previous launch wrote)
-    float4 rv[RT][NTW];
-    auto epilogue_operands = [&]() {
-        if (EPI == H2_EPI_RES) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    int c = 16 * h2_slot_tile(slot0 + n) + 4 * kq;
-                    c = c + 3 < BN ? c : 0;
-                    const float* rp = a.R + (size_t)row[rt] * a.ldr + n0 + c;
-                    if (CHAIN) rv[rt][n] = __builtin_bit_cast(float4, h2_ld16_l2(a.R + (size_t)m0 * a.ldr, (unsigned)((size_t)(rp - (a.R + (size_t)m0 * a.ldr)) * 4)));
-                    else rv[rt][n] = ld4(rp);
-                }
-        }
-    };
-
-    f32x4 acc[NPASS][RT][NTW];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[p][rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- LNF: z = x cv_a + cv_b = (x - mean) rstd 2^10 of this lane's row, applied when the raw values are taken out of LDS
-    float cv_a[RT], cv_b[RT];
-    float4 cvr0[RT], cvr1[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        cv_a[rt] = cv_b[rt] = 0.f;
-        cvr0[rt] = cvr1[rt] = float4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    f16x8 A0[RT][2], A1[RT][2];
-    f16x8 B0[NTW][2], B1[NTW][2];
-    // LNF: the lane's eight raw values of its row wait in cvr0 / cvr1 until
-    // finish_a() normalises and splits them at the end of the stage
-    auto read_a = [&](unsigned slot, f16x8 (&f)[RT][2]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if constexpr (LNF) {
-                const char* p = smem + slot + (rg + 4 * rt) * H2_RG + lane * 16;
-                cvr0[rt] = *reinterpret_cast<const float4*>(p);
-                cvr1[rt] = *reinterpret_cast<const float4*>(p + 1024);
-            } else {
-                const f16x8* as = reinterpret_cast<const f16x8*>(smem + slot + (rg + 4 * rt) * H2_RG) + lane;
-                f[rt][0] = as[0];
-                f[rt][1] = as[64];
-            }
-        }
-    };
-    auto finish_a = [&](f16x8 (&f)[RT][2]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            float z[8] = {cvr0[rt].x, cvr0[rt].y, cvr0[rt].z, cvr0[rt].w, cvr1[rt].x, cvr1[rt].y, cvr1[rt].z, cvr1[rt].w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                z[j] = fmaf(z[j], cv_a[rt], cv_b[rt]);
-                z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
-                if (!row_ok[rt]) z[j] = 0.f;
-            }
-            split2(z, f[rt][0], f[rt][1]);
-        }
-    };
-    auto read_b = [&](unsigned slot, f16x8 (&f)[NTW][2]) {
-        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot + ABYTES) + slot0 * 2 * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            f[n][0] = bs[(n * 2 + 0) * 64];
-            f[n][1] = bs[(n * 2 + 1) * 64];
-        }
-    };
-    auto slot_after = [&](unsigned sl) -> unsigned { return sl + STAGE == NST * STAGE ? 0u : sl + STAGE; };
-    // Three products, fixed order (A part . W part): lo.hi, hi.lo, hi.hi, each over the wave's NTW tiles.  The W fragment is
-    // the FIRST MFMA operand: lane (i, kq) then holds C[row i][4 consecutive columns 16 tile + 4 kq ..].
-    // (per accumulator; with RT = 2 the same W fragment serves both row tiles)
-    auto mfma_row = [&](f32x4 (&accp)[RT][NTW], const f16x8 (&af)[RT][2], int ap, const f16x8 (&bf)[NTW][2], int bp) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-                if (!(H2_ABL & 8)) accp[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[n][bp], af[rt][ap], accp[rt][n], 0, 0, 0);
-    };
-    // counted waits.  Per stage a wave of the waves 4..7 requests WC (4 or 3) pieces, a wave 0..3 one W piece plus two A
-    // pieces in the A stages (every NPASS-th).  One barrier per stage: the stages t+1 .. t+5 are in flight when stage t
-    // starts and stage t+1 is needed, so four stages may stay in flight -- at least 4 WC + 2 (A stages among four consecutive
-    // ones: 4, 2, 1 for NPASS 1, 2, 3) pieces of this wave.  P2: see the stage.
-    // In general (no P2): the stages t+2 .. t+NST-1 may stay in flight at the barrier in front of stage t.
-    unsigned long long t_land = 0;
-    {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
-        // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
-        if (HAS_A) {
-            // A stages among the stages 1 .. DIST - 1: every NPASS-th
-            constexpr int LATER = P2 ? 2 * WC + APW * (NPASS == 1 ? 2 : 1) : (DIST - 1) * WC + APW * ((DIST - 1) / NPASS);
-            static_assert(LATER < 64, "vmcnt is 6 bits");
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LATER) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2 ? 2 * WC : (DIST - 1) * WC) : "memory");
-        }
-        if (H2_DBG == 2 && a.dbg) t_land = __builtin_amdgcn_s_memtime();
-        {
-            if (LNF) {
-                // Chan's combination of the per-slice {mean, M2} partials (fixed order)
-                const int ns = K / BN;
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    if constexpr (ST_DMA) {
-                        const float* sl = reinterpret_cast<const float*>(smem + ST_LDS + wave * 1024 + rt * 8192) + li * ns * 2;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sl + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    float st[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        st[4 * i] = st_raw[i].x; st[4 * i + 1] = st_raw[i].y; st[4 * i + 2] = st_raw[i].z; st[4 * i + 3] = st_raw[i].w;
-                    }
-                    float msum = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) msum += (i < ns) ? st[2 * i] : 0.f;
-                    const float mean = msum / (float)ns;
-                    float m2 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float d = st[2 * i] - mean;
-                        m2 += (i < ns) ? fmaf((float)BN * d, d, st[2 * i + 1]) : 0.f;
-                    }
-                    const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
-                    cv_a[rt] = rs * H2_SA;
-                    cv_b[rt] = -mean * cv_a[rt];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_a(0, A0);
-        if (LNF) finish_a(A0);
-        read_b(0, B0);
-    }
-    const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    unsigned long long t_vm = 0, t_bar = 0, t_mm = 0;      // bench-only sums: counted DMA wait, lgkm + barrier, the MFMA rows of a stage
-    unsigned slot_c = 0;
-    // one stage: publish the landed stages (which frees a slot for the DMA of stage t + DIST), then the MFMAs of stage t and the
-    // fragment reads of stage t+1.  REM = 0: a stage of the steady state (t + NST < T); REM > 0: a stage of the tail with REM
-    // stages left including this one -- a compile-time number, so that the counted waits, the last refills and the end of the
-    // fragment reads need neither bookkeeping nor branches (a tail stage with run-time bookkeeping cost ~1500 cycles against
-    // ~800 of a steady-state one, and a quarter of all stages are tail stages).
-    auto stage = [&](auto rem_c, auto wp_c, f32x4 (&accp)[RT][NTW], const f16x8 (&a_cur)[RT][2], f16x8 (&a_nxt)[RT][2],
-                     const f16x8 (&b_cur)[NTW][2], f16x8 (&b_nxt)[NTW][2], auto nha_c, auto sync_c) {
-        constexpr int REM = decltype(rem_c)::value;
-        constexpr bool FAST = REM == 0;
-        constexpr bool SYNC = !(P2 && FAST) || decltype(sync_c)::value;      // P2: the odd fast stages run without a barrier
-        constexpr bool next_has_a = decltype(nha_c)::value;
-        constexpr bool more = FAST || REM > 1;
-        constexpr bool RF = FAST || REM > DIST;                              // this stage requests stage t + DIST
-        constexpr int g0 = decltype(wp_c)::value;                            // pass of this stage
-        // the ring position is opaque here: in the straight-line tail the compiler otherwise forms the LDS addresses of all the
-        // remaining stages up front (+40 VGPRs, spills)
-        asm volatile("" : "+s"(slot_c));
-        const unsigned slot_n = slot_after(slot_c);
-        const unsigned slot_p = slot_c == 0 ? (unsigned)((NST - 1) * STAGE) : slot_c - STAGE;   // ring slot of stage t - 1
-        unsigned long long w0 = 0, w1 = 0;
-        if (H2_DBG && a.dbg) w0 = __builtin_amdgcn_s_memtime();
-        if (more && SYNC) {
-            if (FAST) {
-                if (P2) {   // stages <= t + 2 landed; t + 3, t + 4 may stay in flight (the refills of this period come later)
-                    constexpr int na = ((g0 + 3) % NPASS == 0 ? 1 : 0) + ((g0 + 4) % NPASS == 0 ? 1 : 0);   // A stages among them
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC + APW * na) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WC) : "memory");
-                } else {    // stages <= t + 1 landed; t + 2 .. t + NST - 1 may stay in flight
-                    constexpr int na = ((g0 + 2) % NPASS == 0 ? 1 : 0) + ((g0 + 3) % NPASS == 0 ? 1 : 0) +
-                                       (NST > 4 ? ((g0 + 4) % NPASS == 0 ? 1 : 0) + ((g0 + 5) % NPASS == 0 ? 1 : 0) : 0);
-                    static_assert(NST == 4 || NST == 6, "in-flight stages of the one-barrier-per-stage form");
-                    static_assert((NST - 2) * WC + APW * na < 64, "vmcnt is 6 bits");
-                    if (HAS_A) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * WC + APW * na) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * WC) : "memory");
-                }
-            } else {
-                // tail (a barrier in front of every stage).  Requested so far: the stages <= min(T - 1, t + DIST - 1); needed:
-                // <= t + 1.  The stages in between may stay in flight, counted with the FEWEST pieces this wave has per stage
-                constexpr int ahead = (REM - 1 < DIST - 1 ? REM - 1 : DIST - 1) - 1;
-                constexpr int per = HAS_A ? WC + (NPASS == 1 ? APW : 0) : WC;
-                constexpr int allow = ahead > 0 ? ahead * per : 0;
-                static_assert(allow < 64, "vmcnt is 6 bits");
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow) : "memory");
-            }
-            if (H2_DBG && a.dbg) { w1 = __builtin_amdgcn_s_memtime(); t_vm += w1 - w0; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(H2_ABL & 32)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (H2_DBG && a.dbg) t_bar += __builtin_amdgcn_s_memtime() - w1;
-        }
-        const f16x8* bs = reinterpret_cast<const f16x8*>(smem + slot_n + ABYTES) + slot0 * 2 * 64 + lane;
-        auto rd_b = [&](int n) {
-            if (more && n < NTW && !(H2_ABL & 1)) {
-                b_nxt[n][0] = bs[(n * 2 + 0) * 64];
-                b_nxt[n][1] = bs[(n * 2 + 1) * 64];
-            }
-        };
-        auto loads = [&]() {
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
-            // the requested stage t + DIST has the pass (g + DIST) mod NPASS (= g when DIST = NST) and carries A when that is 0
-            constexpr int gr = (g0 + DIST) % NPASS;
-            if (RF && !(H2_ABL & 2))
-                refill_fast(std::integral_constant<int, gr>{}, std::integral_constant<bool, gr == 0>{}, P2 ? slot_p : slot_c);
-            if (REM == 4) epilogue_operands();
-        };
-        // The two waves of a SIMD run out of phase: the waves 0..3 multiply first and load afterwards, the waves 4..7 the other
-        // way round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe.
-        // (Interleaving rows, reads and requests -- down to one load operation behind every MFMA --, or reads first in both
-        // halves: +1 .. +11 % time)
-        __builtin_amdgcn_sched_barrier(0);
-        if (!LEAD) {
-            loads();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        unsigned long long m0 = 0;
-        if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
-        mfma_row(accp, a_cur, 1, b_cur, 0);             // lo . hi
-        mfma_row(accp, a_cur, 0, b_cur, 1);             // hi . lo
-        mfma_row(accp, a_cur, 0, b_cur, 0);             // hi . hi
-        __builtin_amdgcn_sched_barrier(0);
-        if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
-        if (LEAD) loads();
-        if (LNF && more && next_has_a && !(H2_ABL & 16)) finish_a(a_nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        slot_c = slot_n;
-    };
-    using W0 = std::integral_constant<int, 0>;
-    using W1 = std::integral_constant<int, 1>;
-    using W2 = std::integral_constant<int, 2>;
-    using YES = std::integral_constant<bool, true>;
-    using NO = std::integral_constant<bool, false>;
-    // Stage t = NPASS kt + j: pass j, carries A when j == 0; the fragment registers alternate per k-tile (A) and per stage (B);
-    // the last two arguments: the NEXT stage carries A / (P2) a barrier stands in front of this stage.  POS = t mod 2 NPASS
-    // picks the row of that table.
-    constexpr int U = 2 * NPASS;
-    auto step = [&](auto rem_c, auto pos_c) {
-        constexpr int POS = decltype(pos_c)::value;
-        if constexpr (NPASS == 1) {
-            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A1, B0, B1, YES{}, YES{});
-            else stage(rem_c, W0{}, acc[0], A1, A0, B1, B0, YES{}, NO{});
-        } else if constexpr (NPASS == 2) {
-            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, acc[1], A0, A1, B1, B0, YES{}, NO{});
-            else if constexpr (POS == 2) stage(rem_c, W0{}, acc[0], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W1{}, acc[1], A1, A0, B1, B0, YES{}, NO{});
-        } else {
-            // three stages per k-tile flip the B parity every k-tile
-            if constexpr (POS == 0) stage(rem_c, W0{}, acc[0], A0, A0, B0, B1, NO{}, YES{});
-            else if constexpr (POS == 1) stage(rem_c, W1{}, acc[1], A0, A0, B1, B0, NO{}, NO{});
-            else if constexpr (POS == 2) stage(rem_c, W2{}, acc[2], A0, A1, B0, B1, YES{}, YES{});
-            else if constexpr (POS == 3) stage(rem_c, W0{}, acc[0], A1, A1, B1, B0, NO{}, NO{});
-            else if constexpr (POS == 4) stage(rem_c, W1{}, acc[1], A1, A1, B0, B1, NO{}, YES{});
-            else stage(rem_c, W2{}, acc[2], A1, A0, B1, B0, YES{}, NO{});
-        }
-    };
-    auto tail = [&](auto self, auto rem_c, auto pos_c) -> void {
-        constexpr int REM = decltype(rem_c)::value, POS = decltype(pos_c)::value;
-        step(rem_c, pos_c);
-        if constexpr (REM > 1) self(self, std::integral_constant<int, REM - 1>{}, std::integral_constant<int, (POS + 1) % U>{});
-    };
-    using R0 = std::integral_constant<int, 0>;
-    // steady state: whole groups of U stages while the last of them still has a stage to request; what is left is NST or
-    // NST + NPASS stages (T = NPASS KT is 0 or NPASS modulo U), both starting at POS 0
-    int t = 0;
-    for (; t + U - 1 + NST < T; t += U) {
-        step(R0{}, std::integral_constant<int, 0>{});
-        step(R0{}, std::integral_constant<int, 1 % U>{});
-        if constexpr (NPASS >= 2) {
-            step(R0{}, std::integral_constant<int, 2 % U>{});
-            step(R0{}, std::integral_constant<int, 3 % U>{});
-        }
-        if constexpr (NPASS == 3) {
-            step(R0{}, std::integral_constant<int, 4 % U>{});
-            step(R0{}, std::integral_constant<int, 5 % U>{});
-        }
-    }
-    if (T - t == NST) tail(tail, std::integral_constant<int, NST>{}, std::integral_constant<int, 0>{});
-    else tail(tail, std::integral_constant<int, NST + NPASS>{}, std::integral_constant<int, 0>{});
-
-    // ------------------------------------------------------------------------------------------ epilogue
-    const unsigned long long t_epi = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    // acc[p][rt][n][r] = scaled C[row_l of row tile rt][colbase(p) + 16 tile(n) + 4 kq + r];   value = acc * sc_n (* 1 / a_scale) + c_n
-    auto tile_of = [&](int n) -> int { return h2_slot_tile(slot0 + n); };
-    auto value4 = [&](int p, int rt, int n, float (&v)[4]) {
-        const int cl = 16 * tile_of(n) + 4 * kq;
-        const bool ok = cl + 3 < BN;
-        const float* vecs = reinterpret_cast<const float*>(smem + H2_VEC) + p * 2 * BN + (ok ? cl : 0);
-        const float4 cv = ld4(vecs), sv = ld4(vecs + BN);
-        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
-        const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // explicit fused operations: the same roundings in every instantiation (chain phases and one-GEMM launches agree
-            // bitwise); sc_n, 1 / a_scale are powers of two: their product is exact
-            float t = fmaf(acc[p][rt][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
-            if (EPI == H2_EPI_GELU) t = gelu_as(t);
-            v[r] = ok ? t : 0.f;
-        }
-    };
-    // static scales of the 4 columns of tile n as they leave packed (so block p of the vector region)
-    auto oscale4 = [&](int p, int n, float (&o)[4]) {
-        const int cl = 16 * tile_of(n) + 4 * kq;
-        const float4 sv = ld4(reinterpret_cast<const float*>(smem + H2_VEC) + VSO + p * BN + (cl + 3 < BN ? cl : 0));
-        o[0] = sv.x; o[1] = sv.y; o[2] = sv.z; o[3] = sv.w;
-    };
-    unsigned long long t_st = 0;
-
-    if constexpr (EPI == H2_EPI_ATT) {
-      if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
-        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS (x3_gemm.hip): a
-        // sequence is the 4 lanes of a quad, k_j / v_j come by DPP quad broadcast, the q.k sums are reduced over the tiles of
-        // the wave, the 4 kq lanes and -- through 2 KiB of LDS -- the two waves of the row group.
-        float qv[NTW][4], kv[NTW][4], vv[NTW][4];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            value4(0, 0, n, qv[n]);
-            value4(1, 0, n, kv[n]);
-            value4(2, 0, n, vv[n]);
-        }
-        auto quad = [](float x, int j) -> float {
-            const int xi = __builtin_bit_cast(int, x);
-            int r;
-            switch (j) {
-                case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
-                case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
-                case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
-                default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
-            }
-            return __builtin_bit_cast(float, r);
-        };
-        const bool two_heads = a.att_hd == 68;
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float d = qv[n][0] * quad(kv[n][0], j);
-                d = fmaf(qv[n][1], quad(kv[n][1], j), d);
-                d = fmaf(qv[n][2], quad(kv[n][2], j), d);
-                d = fmaf(qv[n][3], quad(kv[n][3], j), d);
-                s0[j] += h1 ? 0.f : d;
-                s1[j] += h1 ? d : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = xor16_add(s0[j]); s0[j] = xor32_add(s0[j]);
-            s1[j] = xor16_add(s1[j]); s1[j] = xor32_add(s1[j]);
-        }
-        float* xs = reinterpret_cast<float*>(smem);        // [2 halves][64 rows][8]
-        const int half = slot0 ? 1 : 0;
-        __syncthreads();                                    // every wave is done reading the last stage
-        if (kq == 0) {
-            st4(xs + (half * BM + row_l) * 8, float4{s0[0], s0[1], s0[2], s0[3]});
-            st4(xs + (half * BM + row_l) * 8 + 4, float4{s1[0], s1[1], s1[2], s1[3]});
-        }
-        __syncthreads();
-        float p0[4], p1[4];
-        {
-            const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
-            const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
-            const float scale = 1.0f / sqrtf((float)a.att_hd);
-            const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
-            const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
-            auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
-                const float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
-                const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
-                const float inv = 1.0f / ((e0 + e1) + (e2 + e3));
-                pr[0] = e0 * inv; pr[1] = e1 * inv; pr[2] = e2 * inv; pr[3] = e3 * inv;
-            };
-            softmax4(t0, p0);
-            softmax4(t1, p1);
-        }
-        float ov[NTW][4];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
-            const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
-            float so4[4];
-            oscale4(0, n, so4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float o = pj[0] * quad(vv[n][c], 0);
-                o = fmaf(pj[1], quad(vv[n][c], 1), o);
-                o = fmaf(pj[2], quad(vv[n][c], 2), o);
-                o = fmaf(pj[3], quad(vv[n][c], 3), o);
-                ov[n][c] = o * so4[c];
-            }
-        }
-        const int Go = Dq / BN, g_out = n0 / BN;
-        char* cbase = a.C2 + ((size_t)tm * 4 + rg) * (Dq / BK) * H2_RG;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float x[8] = {ov[2 * q][0], ov[2 * q][1], ov[2 * q][2], ov[2 * q][3],
-                                ov[2 * q + 1][0], ov[2 * q + 1][1], ov[2 * q + 1][2], ov[2 * q + 1][3]};
-            h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
-        }
-        if (NTW == H2_T0 && kq < 2) {
-            const float x[8] = {ov[NTW - 1][0], ov[NTW - 1][1], ov[NTW - 1][2], ov[NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
-            h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
-        }
-      } else {
-        float* Tt = reinterpret_cast<float*>(smem);
-        float* SC = Tt + BM * H2_ATT_TS;
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const int cl = 16 * tile_of(n) + 4 * kq;
-                if (cl + 3 < BN) {
-                    float v[4];
-                    value4(p, 0, n, v);
-                    st4(Tt + row_l * H2_ATT_TS + p * BN + cl, float4{v[0], v[1], v[2], v[3]});
-                }
-            }
-        __syncthreads();
-        h2_attention(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm, n0 / BN, Dq,
-                     reinterpret_cast<const float*>(smem + H2_VEC) + VSO);
-      }
-    } else {
-        const int Go = N / BN;
-        float vals[RT][NTW][4];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            char* cbase = a.C2 + (((size_t)tm * RT + rt) * 4 + rg) * (N / BK) * H2_RG;
-#pragma unroll
-            for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
-                const int g_out = colbase(p) / BN;
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    value4(p, rt, n, vals[rt][n]);
-                    const int cl = 16 * tile_of(n) + 4 * kq;
-                    const bool ok = cl + 3 < BN;
-                    if (EPI == H2_EPI_RES) {
-                        vals[rt][n][0] += rv[rt][n].x; vals[rt][n][1] += rv[rt][n].y; vals[rt][n][2] += rv[rt][n].z; vals[rt][n][3] += rv[rt][n].w;
-                        if (!ok) vals[rt][n][0] = vals[rt][n][1] = vals[rt][n][2] = vals[rt][n][3] = 0.f;
-                    }
-                    if (a.C && ok && row_ok[rt]) {
-                        // fp32 rows: in chain mode the WHOLE team reads them (LayerNorm GEMM of the next phase): write-through
-                        const float4 o4 = {vals[rt][n][0], vals[rt][n][1], vals[rt][n][2], vals[rt][n][3]};
-                        h2_st16(WT, a.C + (size_t)m0 * a.ldc, (unsigned)(((size_t)(row[rt] - m0) * a.ldc + colbase(p) + cl) * 4),
-                                __builtin_bit_cast(u32x4, o4));
-                    }
-                }
-                if constexpr (NSO > 0) {
-                  if (a.C2) {
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
-                        float so4[4];
-                        oscale4(p, n, so4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vals[rt][n][r] *= so4[r];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float x[8] = {vals[rt][2 * q][0], vals[rt][2 * q][1], vals[rt][2 * q][2], vals[rt][2 * q][3],
-                                            vals[rt][2 * q + 1][0], vals[rt][2 * q + 1][1], vals[rt][2 * q + 1][2], vals[rt][2 * q + 1][3]};
-                        h2_emit_frag(WT, cbase, 4 * g_out + (slot0 ? 2 : 0) + q, (unsigned)(lane * 16), x);
-                    }
-                    if (NTW == H2_T0 && kq < 2) {
-                        const float x[8] = {vals[rt][NTW - 1][0], vals[rt][NTW - 1][1], vals[rt][NTW - 1][2], vals[rt][NTW - 1][3], 0.f, 0.f, 0.f, 0.f};
-                        h2_emit_tail(WT, cbase, 4 * Go + (g_out >> 2), (unsigned)(((g_out & 3) * 16 + li) * 16 + kq * 8), x);
-                    }
-                  }
-                }
-            }
-        }
-        if (H2_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
-        if constexpr (EPI == H2_EPI_RES) {
-            if (a.stats_out) {
-                // LayerNorm partials {mean, M2} of the 136-column slice of each row (x3_gemm.hip): two exchanges through LDS
-                constexpr int XR = RT * 64;
-                float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][RT x 64 rows]
-                const int half = slot0 ? 1 : 0;
-                float sum[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    sum[rt] = 0.f;
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) sum[rt] += (vals[rt][n][0] + vals[rt][n][1]) + (vals[rt][n][2] + vals[rt][n][3]);
-                    sum[rt] = xor16_add(sum[rt]);
-                    sum[rt] = xor32_add(sum[rt]);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    if (kq == 0) xch[half * XR + rt * 64 + row_l] = sum[rt];
-                __syncthreads();
-                float mean[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    mean[rt] = (xch[rt * 64 + row_l] + xch[XR + rt * 64 + row_l]) * (1.0f / (float)BN);
-                    float q = 0.f;
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
-                        const bool ok = 16 * tile_of(n) + 4 * kq + 3 < BN;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float d = vals[rt][n][r] - mean[rt];
-                            q = ok ? fmaf(d, d, q) : q;
-                        }
-                    }
-                    q = xor16_add(q);
-                    q = xor32_add(q);
-                    if (kq == 0) xch[2 * XR + half * XR + rt * 64 + row_l] = q;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    if (half == 0 && kq == 0 && row_ok[rt]) {
-                        const u32x2 h = {__builtin_bit_cast(unsigned, mean[rt]),
-                                         __builtin_bit_cast(unsigned, xch[2 * XR + rt * 64 + row_l] + xch[3 * XR + rt * 64 + row_l])};
-                        h2_st8(WT, a.stats_out + (size_t)m0 * Go * 2, (unsigned)(((row[rt] - m0) * Go + n0 / BN) * 8), h);
-                    }
-            }
-        }
-    }
-    if (CHAIN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0 && arrive) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (H2_DBG && a.dbg) {
-        if (!t_st) t_st = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {
-            unsigned long long* o = a.dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
-            o[0] = t_entry; o[1] = t_loop; o[2] = t_epi; o[3] = t_st; o[4] = t_end; o[5] = t_vm; o[6] = t_bar; o[7] = t_mm;
-            if (H2_DBG == 2) { o[5] = t_chain; o[6] = t_land; }      // prologue split: hand-off wait | first operands landed
-        }
-    }
-    return true;
-}
-
-template <int EPI, bool LNF, int NPASS>
-__global__ __launch_bounds__(512, 2) void h2_gemm_kernel(const H2Args a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tm, tn;
-    {
-        const int b = blockIdx.x;
-        if ((a.grid_m & 7) == 0) {
-            const int per = a.grid_m >> 3;
-            const int xcd = b & 7, i = b >> 3;
-            tm = xcd * per + (i % per);
-            tn = i / per;
-        } else {
-            tm = b % a.grid_m;
-            tn = b / a.grid_m;
-        }
-    }
-    if (wave < 4) h2_phase<EPI, LNF, NPASS, H2_T0, false, H2_WC0>(a, smem, tid, wave, 0, tm, tn, nullptr, 0u);
-    else if (wave < 6) h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, H2_WC1>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-    else h2_phase<EPI, LNF, NPASS, NT - H2_T0, false, H2_WC2>(a, smem, tid, wave, H2_T0, tm, tn, nullptr, 0u);
-}
-
-// ---------------------------------------------------------------------------------------------- whole block stack
-// ONE launch for all Block applications of a stack (the team protocol of x3_stack_kernel): G = D / 136 workgroups form a
-// team that walks one row tile through every GEMM of every application, synchronising only among themselves through a
-// monotonic arrival counter per row tile.
-struct H2StackArgs {
-    char *att2, *hid2;
-    float *x, *stats;
-    unsigned* counters;          // one per row tile (+ the error word), zeroed before the launch
-    int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
-    float eps;
-    unsigned long long* dbg;
-    unsigned *err_ws, *err_host;
-    int spin_log2;
-    int inject;
-    const char* w[MPL_MAX_APPS][4];   // per application: qkv (norm1 folded), proj, fc1 (norm2 folded), fc2 operands
-};
-
-__global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = s.G, D = s.D;
-    int team, tn;
-    {
-        const int b = blockIdx.x;
-        team = (b & 7) + 8 * ((b >> 3) / G);
-        tn = (b >> 3) % G;
-        if (team >= s.n_teams) return;
-    }
-    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
-    __syncthreads();
-    auto vecs = [&](const char* w2, int N, int K) -> const float* {
-        return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
-    };
-    for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
-        unsigned need = 0;
-        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
-            // the thread id is rebuilt from the wave index (a scalar) and the lane number every phase: kept in a register
-            // across the phases it was the one value the 256-register budget spilled to scratch
-            int wvp = wave_s, tile = tile0, tnp = tn;
-            asm volatile("" : "+s"(wvp), "+s"(tile), "+s"(tnp));
-            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(tidp));
-            const int wv = wvp;
-            unsigned* ctr = s.counters + tile;
-            const char* const* w = s.w[ph >> 2];
-            bool ok = true;
-            if (s.inject > 0 && ph == s.inject && tile == 0 && tnp == 0) return;     // fault injection (test hook)
-            switch (ph & 3) {
-                case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
-                    const float* v = vecs(w[0], 3 * D, D);
-                    const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D, nullptr, 0, nullptr, 0, s.att2,
-                                   nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
-                                   s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    break;
-                }
-                case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
-                    const float* v = vecs(w[2], 2 * D, D);
-                    const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
-                                   nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    break;
-                }
-                default: {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both
-                    const bool fc2 = (ph & 3) == 3;
-                    const int K = fc2 ? 2 * D : D;
-                    const char* w2 = fc2 ? w[3] : w[1];
-                    const float* v = vecs(w2, D, K);
-                    // the operand arrives under the producer's per-column static scales, which these weights were packed
-                    // against (mpl_pack_h2_scaled; h2_entry_kernel checks the fingerprints): nothing to take out here
-                    const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, nullptr, s.stats,
-                                   s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                    if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
-                    else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
-                    break;
-                }
-            }
-            if (!ok) return;
-        }
-    }
-}
-
-// The same stack for teams that own TWO OR MORE row tiles (M > 64 x the number of teams the chip holds: the FULL flag set at
-// B = 1024, eight views, B >= 2048): a team walks PAIRS of row tiles.  proj, fc1 and fc2 run the two-tile stage (h2_phase RT = 2:
-// every W k-tile is fetched and read once for both tiles); the qkv + attention phase, whose three accumulator sets leave no
-// registers for a second row tile, runs the one-tile form for the two tiles one after the other.  Bitwise the same poses as
-// h2_stack_kernel (tested: the batch-split and shard equalities of tests/test_gpu_parity.py cross the switch).
-__global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = s.G, D = s.D;
-    int team, tn;
-    {
-        const int b = blockIdx.x;
-        team = (b & 7) + 8 * ((b >> 3) / G);
-        tn = (b >> 3) % G;
-        if (team >= s.n_teams) return;
-    }
-    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
-    __syncthreads();
-    auto vecs = [&](const char* w2, int N, int K) -> const float* {
-        return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
-    };
-    const int n_pairs = (s.n_tiles + 1) >> 1;
-    for (int pair0 = team; pair0 < n_pairs; pair0 += s.n_teams) {
-        unsigned need = 0;
-        // six steps per block application: qkv of the first / the second row tile of the pair, proj, fc1 of the workgroup's
-        // first / second column group, fc2.  A step that has a partner step waits for the team only in the first and arrives
-        // only in the second of the two.
-        for (int e = 0; e < 6 * s.n_apps; ++e) {
-            int wvp = wave_s, pair = pair0, tnp = tn;
-            asm volatile("" : "+s"(wvp), "+s"(pair), "+s"(tnp));
-            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(tidp));
-            const int wv = wvp;
-            const int app = e / 6, k = e - 6 * app;
-            const int ph = 4 * app + (k < 2 ? 0 : (k == 2 ? 1 : (k < 5 ? 2 : 3)));      // the GEMM this step belongs to
-            if (ph >= s.n_phases) break;
-            const bool two = 2 * pair + 1 < s.n_tiles;
-            if (k == 1 && !two) continue;
-            const bool second = k == 1 || k == 4;
-            const bool arr = !((k == 0 && two) || k == 3);
-            const unsigned nd = second ? 0u : need;
-            unsigned* ctr = s.counters + 2 * pair;       // the arrival counter of the pair = the one of its first row tile
-            const char* const* w = s.w[app];
-            bool ok = true;
-            if (s.inject > 0 && ph == s.inject && !second && pair == 0 && tnp == 0) return;     // fault injection (test hook)
-            if (k < 2) {   // x = x + proj(attn(qkv(norm1(x)))): one row tile at a time
-                const float* v = vecs(w[0], 3 * D, D);
-                const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D, nullptr, 0, nullptr, 0, s.att2,
-                               nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
-                               s.spin_log2};
-                const int tile = 2 * pair + k;
-                if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, nd, arr);
-                else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, nd, arr);
-                else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC2>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, nd, arr);
-            } else if (k == 3 || k == 4) {   // fc1 + GELU: the workgroup's two column groups one after the other (two accumulator sets
-                                             // for two row tiles do not fit the register file beside the double-buffered fragments)
-                const float* v = vecs(w[2], 2 * D, D);
-                const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
-                               nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                const int cg = 2 * tnp + (k - 3);
-                if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, cg, ctr, nd, arr);
-                else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, cg, ctr, nd, arr);
-                else ok = h2_phase<H2_EPI_GELU, true, 1, NT - H2_T0, true, H2_R2_WC2, 2>(a, smem, tidp, wv, H2_T0, pair, cg, ctr, nd, arr);
-            } else {  // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D)
-                const bool fc2 = k == 5;
-                const int K = fc2 ? 2 * D : D;
-                const char* w2 = fc2 ? w[3] : w[1];
-                const float* v = vecs(w2, D, K);
-                const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, nullptr, s.stats,
-                               s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
-                if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, tnp, ctr, nd, arr);
-                else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
-                else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC2, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
-            }
-            if (!ok) return;
-            if (arr) need += G;
-        }
-    }
-}
 
 template <int EPI, bool LNF, int NPASS>
 static int launch_h2(const H2Args& a, hipStream_t s) {
@@ -1625,72 +430,7 @@ int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const floa
 int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
                     hipStream_t s) {
-    if (!x || !ops || !att2 || !hid2 || !stats || !counters || M <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS ||
-        !h2_attention_fusable(n_tok, D, heads) || !h2_shape_ok(D, 2 * D) || M % n_tok)
-        return MPL_E_INVALID;
-    static std::atomic<int> resident[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
-    if (!resident[dev].load(std::memory_order_acquire)) {
-        int cus = 0, per_cu = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
-        if (hipFuncSetAttribute((const void*)h2_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
-            return MPL_E_LAUNCH;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h2_stack_kernel, 512, H2_LDS_BYTES) != hipSuccess || per_cu < 1)
-            return MPL_E_UNSUPPORTED;
-        if (hipFuncSetAttribute((const void*)h2_stack2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
-            return MPL_E_LAUNCH;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h2_stack2_kernel, 512, H2_LDS_BYTES) != hipSuccess || per_cu < 1)
-            return MPL_E_UNSUPPORTED;
-        resident[dev].store(cus, std::memory_order_release);
-    }
-    H2StackArgs a;
-    a.att2 = reinterpret_cast<char*>(att2);
-    a.hid2 = reinterpret_cast<char*>(hid2);
-    a.x = x;
-    a.stats = stats;
-    a.counters = counters;
-    a.M = M; a.D = D; a.n_tok = n_tok; a.heads = heads;
-    a.rpt = h2_rows_per_tile(n_tok);
-    a.n_tiles = (M + a.rpt - 1) / a.rpt;
-    a.G = D / BN;
-    const int cap = resident[dev].load() / a.G;
-    if (cap < 1) return MPL_E_UNSUPPORTED;
-    // more row tiles than teams the chip holds: teams walk PAIRS of row tiles with the two-tile stage (by the shape of the launch
-    // only; the poses are bitwise the same in both forms).  g_h2_rt: A/B switch (mpl_x3_stack_mode bits 1, 2)
-    const int force = g_h2_rt.load();
-    const bool pairs = force == 2 || (force == 0 && a.n_tiles > cap);
-    const int n_units = pairs ? (a.n_tiles + 1) / 2 : a.n_tiles;
-    a.n_teams = n_units < cap ? n_units : cap;
-    if (a.n_teams * a.G > H2_MAX_WGS) a.n_teams = H2_MAX_WGS / a.G;
-    a.n_apps = n_apps;
-    a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
-    a.eps = eps;
-    a.dbg = g_h2_dbg.load();
-    a.err_ws = counters + a.n_tiles;
-    a.err_host = device_error_word(dev);
-    a.spin_log2 = g_h2_spin_log2.load();
-    a.inject = take_fault_injection();
-    for (int i = 0; i < n_apps; ++i)
-        for (int j = 0; j < 4; ++j) {
-            if (!ops[4 * i + j]) return MPL_E_INVALID;
-            a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
-        }
-    // the library serialises ITS OWN persistent launches per device (see x3_gemm.hip launch_stack_np); not under graph capture
-    if (int rc = refuse_stream_capture(s)) return rc;
-    hipEvent_t ev = stack_chain_event(dev);
-    if (!ev) return MPL_E_LAUNCH;
-    std::lock_guard<std::mutex> g(stack_chain_mutex(dev));
-    if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) return MPL_E_LAUNCH;
-    int rc;
-    {
-        ProfScope prof(MPL_K_GEMM, s);
-        if (pairs) hipLaunchKernelGGL(h2_stack2_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL(h2_stack_kernel, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
-        rc = hip_check_launch();
-    }
-    if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;
-    return rc;
+    return h2_launch_stack<2>(x, nullptr, M, D, n_tok, heads, ops, n_apps, att2, hid2, stats, counters, eps, stop_after, s);
 }
 
 }  // namespace mpl

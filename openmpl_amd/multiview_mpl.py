@@ -268,25 +268,23 @@ class MultiView_MPL(nn.Module):
             view-token model) the products are formed on the fp16 matrix cores from operands split into two fp16 terms under
             exact power-of-two scales, three partial products per product (csrc/h2_gemm.hip: as accurate as an fp32 GEMM,
             1/5 of its matrix-pipe time on gfx950); other widths (KPTOK, D = 32) use the native fp32 MFMA kernels;
-        "fp32x3" -- the round-2 engine: operands split exactly into three bf16 terms, six partial products
-            (csrc/x3_gemm.hip); slower than "fp32", kept as the reference point of the split-operand arithmetic;
         "fp32_mfma" -- native fp32 matrix instructions (v_mfma_f32_16x16x4_f32) everywhere;
-        "bf16" -- the x3 engine with ONE bf16 per operand element: operands rounded to bf16 (activations when a GEMM
-            epilogue hands them to the next GEMM, weights with the LayerNorm gain folded in), exact products, fp32
+        "bf16" -- the same stage with ONE bf16 per operand element (csrc/b1_gemm.hip): operands rounded to bf16 (activations
+            when a GEMM epilogue hands them to the next GEMM, weights with the LayerNorm gain folded in), exact products, fp32
             accumulation; statistics, softmax, GELU and the residual stream stay fp32: BASELINE.json configs[2].
         The packed weight copies are derived data, rebuilt whenever a parameter's storage or version changes."""
-        if precision not in ("fp32", "fp32x3", "fp32_mfma", "bf16"):
-            raise ValueError("matmul precision must be 'fp32', 'fp32x3', 'fp32_mfma' or 'bf16'")
-        if precision in ("bf16", "fp32x3") and not self._x3_supported():
+        if precision not in ("fp32", "fp32_mfma", "bf16"):
+            raise ValueError("matmul precision must be 'fp32', 'fp32_mfma' or 'bf16'")
+        if precision == "bf16" and not self._x3_supported():
             raise NotImplementedError("the %s engine covers the view-token FPT blocks (widths 544 / 1088, up to 32 views)" % precision)
         self.matmul_precision = precision
         self._hip_cache = {}
         return self
 
     def _x3_supported(self) -> bool:
-        """The packed-operand engines (h2 / x3 / bf16) need every FPT Linear shape to have a packed layout (out features a
+        """The packed-operand engines (fp16x2 / bf16) need every FPT Linear shape to have a packed layout (out features a
         multiple of 136, in features of 544: widths 544 and 1088, i.e. every view-token model at DIM 32;
-        mpl_split_bf16x3_bytes / mpl_pack_h2_bytes decide) and fuse the attention for up to 32 tokens per sequence."""
+        mpl_pack_bf16_bytes / mpl_pack_h2_bytes decide) and fuse the attention for up to 32 tokens per sequence."""
         c = self.__dict__.get("_x3_ok")
         if c is not None and c[0] == _STRUCT_GEN[0] and _HOOKS_OK:
             return c[1]
@@ -294,7 +292,7 @@ class MultiView_MPL(nn.Module):
         if not (self.no_transformer_fpt or len(self.blocks) == 0 or self.FPT_blocks_view_keypoint_tokens or self.num_views > 32):
             lib = cabi.load()
             b = self.blocks[0]
-            ok = all(lib.mpl_split_bf16x3_bytes(int(t.shape[0]), int(t.shape[1])) > 0 and
+            ok = all(lib.mpl_pack_bf16_bytes(int(t.shape[0]), int(t.shape[1])) > 0 and
                      lib.mpl_pack_h2_bytes(int(t.shape[0]), int(t.shape[1])) > 0
                      for t in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight))
         self.__dict__["_x3_ok"] = (_STRUCT_GEN[0], ok)
@@ -306,18 +304,32 @@ class MultiView_MPL(nn.Module):
         DataParallel are fresh objects with plain tensor attributes on every forward: never cached."""
         c = self.__dict__.get("_tl_cache")
         if c is not None and c[0] == _STRUCT_GEN[0] and _HOOKS_OK and not self._dp_replica:
-            return c[1]
+            # torch.func.functional_call / stateless reparametrisation write module._parameters[...] directly (no hook): a few
+            # identity probes (first / last FPT block, the head, the embedding) catch a swapped tensor set and rebuild the lists
+            if all(a is b for a, b in zip(c[2], self._tl_probe())):
+                return c[1]
         fpt = [t for b in self.blocks for t in self._block_ptrs(b)]
         stacks = self.Spatial_blocks if self.multiple_spatial_blocks else [self.Spatial_blocks]
         spt = [t for st in stacks for b in st for t in self._block_ptrs(b)]
         tl = (self._param_list(), fpt, spt)
         if not self._dp_replica:
-            self.__dict__["_tl_cache"] = (_STRUCT_GEN[0], tl)
+            self.__dict__["_tl_cache"] = (_STRUCT_GEN[0], tl, self._tl_probe())
         return tl
+
+    def _tl_probe(self):
+        """A handful of live parameter objects (identity, not value) that any wholesale swap of the parameters would change."""
+        out = [self.Spatial_norm.weight, self.View_norm.bias, self.weighted_mean.weight]
+        if len(self.blocks) > 0:
+            out += [self.blocks[0].attn.qkv.weight, self.blocks[-1].mlp.fc2.weight]
+        return out
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _apply(self, fn, *a, **k):
+        # .to() / .cuda() / .half(): under torch.__future__.set_overwrite_module_params_on_conversion the parameters are REPLACED
+        # without any registration hook firing, so every cache that holds tensors goes, not only the packed operands
         self._hip_cache = {}
+        self.__dict__.pop("_tl_cache", None)
+        self.__dict__.pop("_x3_ok", None)
         return super()._apply(fn, *a, **k)
 
     def _replicate_for_data_parallel(self):
@@ -385,13 +397,13 @@ class MultiView_MPL(nn.Module):
         out += [b for n, b in self.head.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
         return out
 
-    def _derived_key(self, h2, x3, bf16, spt3, d32):
+    def _derived_key(self, h2, bf16, spt3, d32):
         """What the packed operands were built from: engine selection + storage and version of every SOURCE tensor they fold
         (norm1 / norm2, weights and biases of each block).  A replica looks at the module it was replicated from."""
         src = self._dp_src if self._dp_replica else self
         _, fpt, spt = src._tensor_lists()
-        ts = (fpt if (h2 or x3 or bf16 or d32) else []) + (spt if spt3 else [])
-        return (self.matmul_precision, h2, x3, bf16, spt3, d32) + tuple([(t.data_ptr(), t._version) for t in ts])
+        ts = (fpt if (h2 or bf16 or d32) else []) + (spt if spt3 else [])
+        return (self.matmul_precision, h2, bf16, spt3, d32) + tuple([(t.data_ptr(), t._version) for t in ts])
 
     def _marshal(self, device: torch.device):
         """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the struct stays valid
@@ -400,7 +412,6 @@ class MultiView_MPL(nn.Module):
         plist = self._tensor_lists()[0]
         x3ok = self._x3_supported()
         bf16 = self.matmul_precision == "bf16" and x3ok
-        x3 = self.matmul_precision == "fp32x3" and x3ok
         h2 = self.matmul_precision == "fp32" and x3ok
         # the SPT Linear layers also run from split operands (fp32 arithmetic on the fp16 matrix cores) unless the native
         # fp32 matrix instructions were asked for
@@ -408,7 +419,7 @@ class MultiView_MPL(nn.Module):
         # keypoint-token FPT blocks (width 32 = the SPT block's shapes) run from the same kind of split operand (mpl_d32_pack)
         d32 = self.matmul_precision == "fp32" and self.FPT_blocks_view_keypoint_tokens \
             and not self.no_transformer_fpt and len(self.blocks) > 0 and tuple(self.blocks[0].attn.qkv.weight.shape) == (96, 32)
-        dkey = self._derived_key(h2, x3, bf16, spt3, d32)
+        dkey = self._derived_key(h2, bf16, spt3, d32)
         key = tuple([t.data_ptr() for t in plist]) + dkey
         ent = self._hip_cache.get(device.index)
         if ent is not None and ent["key"] == key:
@@ -458,15 +469,13 @@ class MultiView_MPL(nn.Module):
         fpt = (cabi.BlockWeights * max(1, len(self.blocks)))()
         for l, b in enumerate(self.blocks):
             ptrs = [_ptr(t) for t in self._block_ptrs(b)]
-            if bf16 or x3 or h2:
+            if bf16 or h2:
                 ops = derived["fpt"].get(l)
                 if ops is None:
-                    ops = self._pack_block(lib, b, device, st, bf16, x3, h2)
+                    ops = self._pack_block(lib, b, device, st, bf16)
                     derived["fpt"][l] = ops
-                if x3:
-                    ptrs += [0, 0, 0, 0]
                 if h2:
-                    ptrs += [0] * 8
+                    ptrs += [0] * 8           # behind the *_w16 and *_w3 fields
                 ptrs += [c3.data_ptr() for c3 in ops]
             fpt[l] = cabi.BlockWeights(*ptrs)
             if d32:
@@ -500,14 +509,18 @@ class MultiView_MPL(nn.Module):
         new["ready"] = torch.cuda.Event()
         new["ready"].record(torch.cuda.current_stream(device))
         new["ready_stream"] = st
+        if fresh:
+            # the packing kernels ran on THIS stream: the event and the stream stay with the derived operands, which outlive the
+            # struct when only addresses change (DataParallel replicas) -- a later forward on another stream waits for it too
+            derived["ready"], derived["stream"] = new["ready"], st
         self._hip_cache[device.index] = new
         return new
 
     @staticmethod
-    def _pack_block(lib, b, device, st, bf16, x3, h2):
+    def _pack_block(lib, b, device, st, bf16):
         """The four packed Linear operands {qkv (norm1 folded), proj, fc1 (norm2 folded), fc2} of one FPT block."""
-        nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else \
-            ((lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3) if x3 else (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2))
+        h2 = not bf16
+        nbytes, pack = (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16) if bf16 else (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2)
         ops = []
         in_scale = 0        # h2: static scales (device vector) of the columns the NEXT plain Linear consumes
         for lin, ln in ((b.attn.qkv, b.norm1), (b.attn.proj, None), (b.mlp.fc1, b.norm2), (b.mlp.fc2, None)):
@@ -584,6 +597,9 @@ class MultiView_MPL(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if stream != ent["ready_stream"]:
                 torch.cuda.current_stream(dev).wait_event(ent["ready"])
+            dv = ent["derived"]
+            if dv.get("stream", stream) != stream:
+                torch.cuda.current_stream(dev).wait_event(dv["ready"])
             if self.linear_weighted_mean or self.deep_head or self.head_kadkhod:
                 return self._forward_staged(lib, ent, inp, B, dev, stream)
             ws_bytes = lib.mpl_forward_workspace_bytes(C.byref(cfg), B)

@@ -1,19 +1,21 @@
-"""CPU restatement of the split-operand layout and arithmetic of openmpl_amd/csrc/x3_gemm.hip (engine v2).
+"""CPU restatement of the packed-operand layouts and arithmetic of the FPT GEMM engines (openmpl_amd/csrc/h2_phase.hpp):
+the fp16x2 operands of the default fp32 engine (h2_gemm.hip, second half of this file) and the bf16 operands of the bf16
+engine (b1_gemm.hip, first half).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): used by tests/ to check (a) that the three bf16 parts written by
-mpl_split_bf16x3 are byte-for-byte what the definition says, in MFMA fragment order, with the fold vectors behind them,
-and (b) that the six-product sum the kernels accumulate is at least as accurate as an fp32 product.  This is not a
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): used by tests/ to check that the packed operands written by
+mpl_pack_h2 / mpl_pack_bf16 are byte-for-byte what the definition says, in MFMA fragment order, with their trailer vectors
+behind them, and that the three-product sum of the fp16x2 engine is as accurate as an fp32 product.  This is not a
 restatement of the reference (the reference is plain fp32 PyTorch, oracle/mpl_oracle.py); it pins the build's own
-derived operand.
+derived operands.
 
-    x = hi + mid + lo,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (round to nearest even)
     K = 136 G columns (G a multiple of 4), KT = K / 32 k-tiles, k-permuted so that a producer's two adjacent 16-column
     output tiles are one consumer fragment:
         k-tile t < 4G:        lane quarter kq, element j  <->  column 136 (t//4) + 32 (t%4) + 16 (j//4) + 4 kq + j%4
         k-tile t = 4G + u:    lane quarter kq, element j  <->  column 136 (4u + kq) + 128 + j     (the 8-column tails)
-    W3[N/136 groups][KT][9 slots][3 parts][64 lanes][8 bf16], slot s = column tile (0,1,2,3,8,4,5,6,7)[s];
-    lane = 16 kq + li holds (gamma o W)[g*136 + tile*16 + li][col(t, kq, j)] (zero where tile*16 + li >= 136);
-    then c[N] = bias + W . beta and s[N] = sum_k fl32(gamma_k W_nk) as fp32 (both from fp64 sums).
+    bf16 operand: W1[N/136 groups][KS = ceil(KT / 2)][9 slots][2 k-tiles][64 lanes][8 bf16], slot s = column tile
+    (0,1,2,3,8,4,5,6,7)[s]; lane = 16 kq + li holds bf16(gamma o W)[g*136 + tile*16 + li][col(2 ks + par, kq, j)] (zero where
+    tile*16 + li >= 136 or the k-tile pads an odd KT); then fp32 c[N] = bias + W . beta and s[N] = sum_k bf16(gamma_k W_nk)
+    (both from fp64 sums), and unused space up to the trailer size of an fp16x2 operand (5 N + 8 floats).
 """
 import numpy as np
 import torch
@@ -22,15 +24,6 @@ import torch
 def bf16_round(x: np.ndarray) -> np.ndarray:
     """fp32 -> bf16 (RNE) -> fp32."""
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
-
-
-def split3(x: np.ndarray):
-    x = np.asarray(x, dtype=np.float32)
-    hi = bf16_round(x)
-    r = (x - hi).astype(np.float32)
-    mid = bf16_round(r)
-    lo = bf16_round((r - mid).astype(np.float32))
-    return hi, mid, lo
 
 
 def bf16_bits(x: np.ndarray) -> np.ndarray:
@@ -56,60 +49,35 @@ def k_permutation(K: int) -> np.ndarray:
     return cols
 
 
-def split_operand(W: np.ndarray, gamma: np.ndarray = None) -> np.ndarray:
-    """uint16 array of the W3 bytes mpl_split_bf16x3 must produce for an nn.Linear weight W[N][K] (gamma folded)."""
+def b1_operand(W: np.ndarray, gamma: np.ndarray = None) -> np.ndarray:
+    """uint16 array of the fragment bytes mpl_pack_bf16 must produce for an nn.Linear weight W[N][K] (gamma folded)."""
     N, K = W.shape
     assert N % 136 == 0 and K % 544 == 0
     Gn, KT = N // 136, K // 32
+    KS = (KT + 1) // 2
     Wf = np.asarray(W, dtype=np.float32)
     if gamma is not None:
         Wf = (Wf * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)
     Wp = np.zeros((Gn, 144, K), dtype=np.float32)
     Wp[:, :136] = Wf.reshape(Gn, 136, K)
     cols = k_permutation(K)                              # [KT][4][8]
-    out = np.zeros((Gn, KT, 9, 3, 64, 8), dtype=np.uint16)
-    for p, part in enumerate(split3(Wp)):                # each [Gn][144][K]
-        b = bf16_bits(part)[:, :, cols]                  # [g][c][kt][kq][j]
-        b = b.reshape(Gn, 9, 16, KT, 4, 8)               # [g][tile][li][kt][kq][j]
-        b = b.transpose(0, 3, 1, 4, 2, 5).reshape(Gn, KT, 9, 64, 8)   # lane = kq*16 + li
-        out[:, :, :, p] = b[:, :, list(SLOT_TILE)]
-    return out
+    b = bf16_bits(bf16_round(Wp))[:, :, cols]            # [g][c][kt][kq][j]
+    b = b.reshape(Gn, 9, 16, KT, 4, 8)                   # [g][tile][li][kt][kq][j]
+    b = b.transpose(0, 3, 1, 4, 2, 5).reshape(Gn, KT, 9, 64, 8)[:, :, list(SLOT_TILE)]   # [g][kt][slot][lane][j]
+    out = np.zeros((Gn, 2 * KS, 9, 64, 8), dtype=np.uint16)
+    out[:, :KT] = b
+    return out.reshape(Gn, KS, 2, 9, 64, 8).transpose(0, 1, 3, 2, 4, 5)      # [g][ks][slot][par][lane][j]
 
 
-def fold_vectors(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None):
-    """(c, s) fp32 vectors stored behind W3."""
+def b1_fold_vectors(W: np.ndarray, bias: np.ndarray, gamma: np.ndarray = None, beta: np.ndarray = None):
+    """(c, s) fp32 vectors stored behind the bf16 fragments: s sums the ROUNDED weights the operand holds."""
     W = np.asarray(W, dtype=np.float32)
     c = np.asarray(bias, dtype=np.float64).copy()
     s = np.zeros(W.shape[0], dtype=np.float64)
     if gamma is not None:
         c += W.astype(np.float64) @ np.asarray(beta, dtype=np.float64)
-        s = (W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32).astype(np.float64).sum(1)
+        s = bf16_round((W * np.asarray(gamma, dtype=np.float32)[None, :]).astype(np.float32)).astype(np.float64).sum(1)
     return c.astype(np.float32), s.astype(np.float32)
-
-
-def split_rows(X: np.ndarray, rpt: int = 64) -> np.ndarray:
-    """uint16 A3 operand [tiles][4 row groups][KT][3][64][8] of fp32 rows X[M][K] (rows >= rpt of a tile are zero)."""
-    M, K = X.shape
-    KT = K // 32
-    tiles = -(-M // rpt)
-    Xp = np.zeros((tiles, 64, K), dtype=np.float32)
-    for t in range(tiles):
-        n = min(rpt, M - t * rpt)
-        Xp[t, :n] = X[t * rpt: t * rpt + n]
-    cols = k_permutation(K)
-    out = np.zeros((tiles, 4, KT, 3, 64, 8), dtype=np.uint16)
-    for p, part in enumerate(split3(Xp)):
-        b = bf16_bits(part)[:, :, cols]                  # [tile][row][kt][kq][j]
-        b = b.reshape(tiles, 4, 16, KT, 4, 8)            # [tile][rg][li][kt][kq][j]
-        out[:, :, :, p] = b.transpose(0, 1, 3, 4, 2, 5).reshape(tiles, 4, KT, 64, 8)
-    return out
-
-
-def six_product_matmul(A: np.ndarray, W: np.ndarray) -> np.ndarray:
-    """A . W^T from the six partial products the kernels accumulate (here in fp64, to isolate the split error)."""
-    ah, am, al = (t.astype(np.float64) for t in split3(A))
-    wh, wm, wl = (t.astype(np.float64) for t in split3(W))
-    return al @ wh.T + ah @ wl.T + am @ wm.T + am @ wh.T + ah @ wm.T + ah @ wh.T
 
 
 # ---------------------------------------------------------------------------------------------------------------------

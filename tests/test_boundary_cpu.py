@@ -124,27 +124,20 @@ def test_workspace_query_and_struct_sizes_without_gpu():
     cfg = cabi.Config(17, 32, 12, 8, 4, 2, cabi.F_POS3D_LEARN, 0)
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 544
     M, D = 1024 * 4, 544
-    # fp32-MFMA engine: xs | qkv | att | hid | LN partials;  packed-operand engines: xs | x3 | att3 | hid3 (6 B per
-    # element, 64-row tiles) | LN partials | one arrival counter per row tile (+ 1024 spare words): the larger one
+    # fp32-MFMA engine: xs | qkv | att | hid | LN partials -- larger than the layouts of the packed-operand engines (fp16x2: xs |
+    # att2 | hid2 at 4 B per element | partials | counters; bf16: xs | x16 | att1 | hid1 at 2 B per element | ...): sized for it
     want32 = M * D * 4 + M * 3 * D * 4 + M * D * 4 + M * 2 * D * 4 + M * 2 * (D // 136) * 4
-    want3 = M * D * 4 + 4 * M * D * 6 + M * 2 * (D // 136) * 4 + (M // 64 + 1024) * 4
-    assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == max(want32, want3)
+    assert lib.mpl_forward_workspace_bytes(ctypes.byref(cfg), 1024) == want32
     cfg.flags |= cabi.F_RAYS_TOKEN
     assert lib.mpl_fpt_width(ctypes.byref(cfg)) == 1088
     assert ctypes.sizeof(cabi.BlockWeights) == 192 and ctypes.sizeof(cabi.SptSet) == 48
     assert ctypes.sizeof(cabi.Inputs) == 8 + 3 * 32 * 8
-    # split operands of the fp32-on-bf16-cores GEMMs: 27 KiB per (136-column group, 32-deep k-tile) + the two fold
-    # vectors (c, s: N floats each); 0 = unsupported
-    assert lib.mpl_split_bf16x3_bytes(1632, 544) == 12 * 17 * 27 * 1024 + 8 * 1632
-    assert lib.mpl_split_bf16x3_bytes(544, 1088) == 4 * 34 * 27 * 1024 + 8 * 544
-    assert lib.mpl_split_bf16x3_bytes(96, 32) == 0 and lib.mpl_split_bf16x3_bytes(544, 48) == 0
-    assert lib.mpl_split_bf16x3_bytes(544, 64) == 0       # K must be a multiple of 544 (4 column groups of 136)
-    # split activations: 3 KiB per (16-row group, k-tile), row tiles padded to 64 rows
-    assert lib.mpl_ln_linear_x3_workspace_bytes(4096, 544) == 64 * 4 * 17 * 3072
-    assert lib.mpl_ln_linear_x3_workspace_bytes(65, 1088) == 2 * 4 * 34 * 3072
-    # bf16 operands: one bf16 per element, K padded to whole stages of three k-tiles (544 -> 18 k-tiles = 6 stages)
-    assert lib.mpl_pack_bf16_bytes(1632, 544) == 12 * 6 * 27 * 1024 + 8 * 1632
-    assert lib.mpl_pack_bf16_bytes(544, 1088) == 4 * 12 * 27 * 1024 + 8 * 544 and lib.mpl_pack_bf16_bytes(544, 100) == 0
+    # packed operands of the FPT GEMM engines: 18 KiB per (136-column group, stage) + the trailer (5 N + 8 floats); a stage is one
+    # 32-deep k-tile of fp16 hi | lo (fp32 engine) or two k-tiles of bf16 (544 -> 17 k-tiles -> 9 stages); 0 = unsupported
+    assert lib.mpl_pack_h2_bytes(1632, 544) == 12 * 17 * 18 * 1024 + (5 * 1632 + 8) * 4
+    assert lib.mpl_pack_bf16_bytes(1632, 544) == 12 * 9 * 18 * 1024 + (5 * 1632 + 8) * 4
+    assert lib.mpl_pack_bf16_bytes(544, 1088) == 4 * 17 * 18 * 1024 + (5 * 544 + 8) * 4 and lib.mpl_pack_bf16_bytes(544, 100) == 0
+    assert lib.mpl_pack_bf16_bytes(96, 32) == 0 and lib.mpl_pack_bf16_bytes(544, 64) == 0    # K: a multiple of 544 (4 column groups of 136)
 
 
 def test_detrng_is_stable():

@@ -428,7 +428,7 @@ def test_spt_split_operands_follow_the_weight_magnitudes(scales):
     _assert_close(out, mpl_oracle.forward(sd, g["flags"], cp, cr, cc, dtype=torch.float64), "SPT weights at unusual magnitudes")
 
 
-# ----------------------------------------------------------------------------- fp32 on the bf16 matrix cores (split operands)
+# ----------------------------------------------------------------------------- fp64 evaluation of one fused GEMM (also tests/test_h2_gpu.py)
 def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
     a = A.double()
     if ln:
@@ -441,103 +441,20 @@ def _fp64_linear(A, W, b, R, gam, bet, epi, ln):
     return y
 
 
-def _x3_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln):
-    nbytes = lib.mpl_split_bf16x3_bytes(N, K)
-    assert nbytes == (N // 136) * (K // 32) * 27 * 1024 + 8 * N
-    W3 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None,
-                                    bed.data_ptr() if ln else None, N, K, W3.data_ptr(), _stream()), "mpl_split_bf16x3")
-    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
-    wsb = lib.mpl_ln_linear_x3_workspace_bytes(M, K)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-    Y = torch.full((M, N), float("nan"), device=DEV)
-    cabi.check(lib.mpl_ln_linear_x3(Ad.data_ptr(), M, K, 1 if ln else 0, 1e-6, W3.data_ptr(), N, epi,
-                                    Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None, Y.data_ptr(),
-                                    so.data_ptr() if ln else None, ws.data_ptr(), wsb, _stream()), "mpl_ln_linear_x3")
-    return Y
-
-
-@pytest.mark.parametrize("M,K,N,epi,ln", [
-    (4096, 544, 1632, cabi.EPI_BIAS, True),
-    (4096, 544, 544, cabi.EPI_BIAS_RESIDUAL, False),
-    (1000, 544, 1088, cabi.EPI_BIAS_GELU, True),
-    (77, 1088, 544, cabi.EPI_BIAS_RESIDUAL, False),
-    (3, 544, 544, cabi.EPI_BIAS, False),
-    (130, 1088, 3264, cabi.EPI_BIAS, True),
-    (640, 2176, 1088, cabi.EPI_BIAS_RESIDUAL, False),
-    (8192, 544, 1088, cabi.EPI_BIAS_GELU, True),
-])
-def test_split_operand_linear_is_fp32_accurate(M, K, N, epi, ln):
-    """mpl_split_bf16x3 + mpl_ln_linear_x3 against an fp64 evaluation: the split-operand GEMM (with the LayerNorm
-    folded into the weight operand) must be as accurate as fp32 arithmetic -- its error may not exceed the native fp32
-    MFMA kernel's (which normalises first, like the reference) by more than rounding noise."""
+# ----------------------------------------------------------------------------- packed bf16 operands (b1_gemm.hip)
+def test_bf16_operand_shapes_are_validated():
     lib = cabi.load()
-    g = torch.Generator().manual_seed(M * 7 + N)
-    A = torch.randn(M, K, generator=g) * 1.7 + 0.3
-    W = torch.randn(N, K, generator=g) * K ** -0.5
-    b, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
-    ref = _fp64_linear(A, W, b, R, gam, bet, epi, ln)
-    Ad, Wd, bd, Rd, gd, bed = (t.to(DEV) for t in (A, W, b, R, gam, bet))
-    errs = {}
-    Y = _x3_linear(lib, Ad, Wd, bd, gd, bed, Rd, M, K, N, epi, ln)
-    torch.cuda.synchronize()
-    assert torch.isfinite(Y).all()
-    errs["x3"] = mpl_oracle.rel_errors(Y.cpu(), ref)
-    Y2 = torch.full((M, N), float("nan"), device=DEV)
-    so = torch.zeros(M, max(1, K // 136), 2, device=DEV)
-    cabi.check(lib.mpl_ln_linear(Ad.data_ptr(), M, K, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-6,
-                                 Wd.data_ptr(), bd.data_ptr(), N, epi, Rd.data_ptr() if epi == cabi.EPI_BIAS_RESIDUAL else None,
-                                 Y2.data_ptr(), so.data_ptr() if ln else None, _stream()), "mpl_ln_linear")
-    torch.cuda.synchronize()
-    errs["mfma"] = mpl_oracle.rel_errors(Y2.cpu(), ref)
-    print("M=%d K=%d N=%d: split %.2e/%.2e  fp32 MFMA %.2e/%.2e" % ((M, K, N) + errs["x3"] + errs["mfma"]))
-    assert errs["x3"][0] <= 3e-6 and errs["x3"][1] <= 1e-6
-    assert errs["x3"][1] <= 1.5 * errs["mfma"][1] + 1e-8, "split-operand GEMM is less accurate than the fp32 MFMA GEMM"
-
-
-@pytest.mark.parametrize("shift,scale", [(0.0, 1.0), (5.0, 1.0), (-40.0, 2.0), (0.0, 1e-20), (0.0, 1e15)])
-def test_folded_layernorm_is_robust_to_offset_and_scale(shift, scale):
-    """The LayerNorm folded into the split GEMM computes rstd * (x.W'^T - mean * s) + c: rows whose mean dwarfs their
-    spread lose sqrt(1 + (mean/sigma)^2) of precision to the cancellation -- the result must stay inside the 1e-4
-    contract even for |mean| = 40 sigma -- and operand magnitudes from 1e-20 to 1e15 (split parts far from the bf16
-    subnormal / overflow range, x3_gemm.hip header) must not change the accuracy at all."""
-    lib = cabi.load()
-    M, K, N = 256, 544, 1632
-    g = torch.Generator().manual_seed(11)
-    A = (torch.randn(M, K, generator=g) + shift) * scale
-    W = torch.randn(N, K, generator=g) * K ** -0.5
-    b = torch.randn(N, generator=g)
-    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
-    ref = _fp64_linear(A, W, b, None, gam, bet, cabi.EPI_BIAS, True) if scale > 1e-10 else None
-    if ref is None:   # eps = 1e-6 dominates the variance of 1e-20-sized rows: compare to the same formula in fp64
-        a = A.double()
-        a = (a - a.mean(-1, keepdim=True)) / torch.sqrt(a.var(-1, unbiased=False, keepdim=True) + 1e-6) * gam.double() + bet.double()
-        ref = a @ W.double().T + b.double()
-    Ad, Wd, bd, gd, bed = (t.to(DEV) for t in (A, W, b, gam, bet))
-    Y = _x3_linear(lib, Ad, Wd, bd, gd, bed, None, M, K, N, cabi.EPI_BIAS, True)
-    torch.cuda.synchronize()
-    mx, nw = mpl_oracle.rel_errors(Y.cpu(), ref)
-    amp = (1.0 + abs(shift) ** 2) ** 0.5
-    print("shift %g scale %g: %.2e / %.2e (amplification bound %.1f)" % (shift, scale, mx, nw, amp))
-    assert mx <= 3e-6 * amp and nw <= 1e-6 * amp and mx < 1e-4
-
-
-def test_split_operand_shapes_are_validated():
-    lib = cabi.load()
-    assert lib.mpl_split_bf16x3_bytes(544, 544) == 4 * 17 * 27 * 1024 + 8 * 544
+    # 9 stages of two k-tiles (17 k-tiles + one of zeros) of 18 KiB per 136-column group, then the trailer of an fp16x2 operand
+    assert lib.mpl_pack_bf16_bytes(544, 544) == 4 * 9 * 18 * 1024 + (5 * 544 + 8) * 4
+    assert lib.mpl_pack_bf16_bytes(544, 1088) == 4 * 17 * 18 * 1024 + (5 * 544 + 8) * 4
     for n, k in ((100, 544), (544, 40), (136, 32), (0, 544), (544, -544), (544, 272), (544, 136)):
-        assert lib.mpl_split_bf16x3_bytes(n, k) == 0
+        assert lib.mpl_pack_bf16_bytes(n, k) == 0
     x = torch.zeros(64, 544, device=DEV)
-    cabi_rc = lib.mpl_split_bf16x3(x.data_ptr(), x.data_ptr(), None, None, 100, 544, x.data_ptr(), _stream())
-    assert cabi_rc != 0
+    assert lib.mpl_pack_bf16(x.data_ptr(), x.data_ptr(), None, None, 100, 544, x.data_ptr(), _stream()) != 0
     # a LayerNorm needs both its vectors
-    big = torch.zeros(lib.mpl_split_bf16x3_bytes(544, 544), dtype=torch.uint8, device=DEV)
+    big = torch.zeros(lib.mpl_pack_bf16_bytes(544, 544), dtype=torch.uint8, device=DEV)
     W = torch.zeros(544, 544, device=DEV)
-    assert lib.mpl_split_bf16x3(W.data_ptr(), x.data_ptr(), x.data_ptr(), None, 544, 544, big.data_ptr(), _stream()) != 0
-    # workspace too small
-    assert lib.mpl_ln_linear_x3(x.data_ptr(), 64, 544, 0, 1e-6, big.data_ptr(), 544, 0, None, W.data_ptr(), None,
-                                W.data_ptr(), 16, _stream()) == -3
+    assert lib.mpl_pack_bf16(W.data_ptr(), x.data_ptr(), x.data_ptr(), None, 544, 544, big.data_ptr(), _stream()) != 0
 
 
 def test_batch_rows_beyond_32bit_offsets_are_refused_not_wrapped():
@@ -593,8 +510,9 @@ def test_fp32_paths_agree_and_are_both_batch_invariant():
         m.set_matmul_precision("tf32")
 
 
-def test_split_operand_bytes_match_the_definition():
-    """mpl_split_bf16x3 against oracle/split_oracle.py: every bf16 part, in MFMA fragment order, byte for byte."""
+def test_bf16_operand_bytes_match_the_definition():
+    """mpl_pack_bf16 against oracle/split_oracle.py: every bf16 word in MFMA fragment order (two k-tiles per fragment slot, the
+    zero k-tile that pads an odd count), byte for byte, then the fold vectors."""
     from oracle import split_oracle
     lib = cabi.load()
     g = torch.Generator().manual_seed(3)
@@ -604,19 +522,43 @@ def test_split_operand_bytes_match_the_definition():
         bias = torch.randn(N, generator=g)
         gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
         Wd, bd, gd, bed = (t.to(DEV) for t in (W, bias, gam, bet))
-        dst = torch.zeros(lib.mpl_split_bf16x3_bytes(N, K), dtype=torch.uint8, device=DEV)
-        cabi.check(lib.mpl_split_bf16x3(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None,
-                                        bed.data_ptr() if ln else None, N, K, dst.data_ptr(), _stream()), "mpl_split_bf16x3")
+        dst = torch.zeros(lib.mpl_pack_bf16_bytes(N, K), dtype=torch.uint8, device=DEV)
+        cabi.check(lib.mpl_pack_bf16(Wd.data_ptr(), bd.data_ptr(), gd.data_ptr() if ln else None,
+                                     bed.data_ptr() if ln else None, N, K, dst.data_ptr(), _stream()), "mpl_pack_bf16")
         torch.cuda.synchronize()
         raw = dst.cpu().numpy()
-        nw3 = (N // 136) * (K // 32) * 27 * 1024
-        got = raw[:nw3].view(np.uint16)
-        want = split_oracle.split_operand(W.numpy(), gam.numpy() if ln else None).reshape(-1)
+        nw1 = (N // 136) * ((K // 32 + 1) // 2) * 18 * 1024
+        got = raw[:nw1].view(np.uint16)
+        want = split_oracle.b1_operand(W.numpy(), gam.numpy() if ln else None).reshape(-1)
         assert got.shape == want.shape
         assert np.array_equal(got, want), "N=%d K=%d: %d of %d bf16 words differ" % (N, K, int((got != want).sum()), want.size)
-        c, sv = split_oracle.fold_vectors(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
-        vec = raw[nw3:].view(np.float32)
-        assert np.array_equal(vec[:N], c) and np.array_equal(vec[N:], sv), "fold vectors differ"
+        c, sv = split_oracle.b1_fold_vectors(W.numpy(), bias.numpy(), gam.numpy() if ln else None, bet.numpy() if ln else None)
+        vec = raw[nw1:].view(np.float32)
+        assert np.array_equal(vec[:N], c) and np.array_equal(vec[N:2 * N], sv), "fold vectors differ"
+
+
+@pytest.mark.parametrize("name,B", [("chosen_v8_b4_l2", 200), ("chosen_v4_b8_l2", 1030), ("chosen_v5_b19_l2", 40), ("full_v4_b8_l2", 70)])
+def test_bf16_launch_forms_are_bitwise_the_same(name, B):
+    """The bf16 stack has three forms of the same arithmetic: the persistent launch with one row tile per team step (default),
+    the pair form of every phase (h2_stackp_kernel: built and measured in round 5, not faster, kept behind the A/B switch) and
+    one launch per GEMM.  Same k order, same product order, same epilogue: the poses must agree bit for bit -- also across
+    ragged last tiles, an odd tile count (a pair without its second tile) and the 60-row tiles of five views."""
+    lib = cabi.load()
+    m, g = _model(name)
+    m.set_matmul_precision("bf16")
+    P, R, Cn = _big_inputs(B, g["flags"]["num_views"], 21)
+    outs = {}
+    try:
+        with torch.no_grad():
+            for tag, mode in (("one", 1 << 1), ("pair", 2 << 1), ("gemm", 1), ("default", 0)):
+                lib.mpl_x3_stack_mode(mode | 8)
+                outs[tag] = m(P, rays=R, centers=Cn).clone()
+    finally:
+        lib.mpl_x3_stack_mode(0)
+        m.set_matmul_precision("fp32")
+    assert torch.isfinite(outs["one"]).all()
+    for tag in ("pair", "gemm", "default"):
+        assert torch.equal(outs["one"], outs[tag]), tag
 
 
 def test_split_operands_follow_in_place_weight_updates():
@@ -647,7 +589,7 @@ def test_split_operands_follow_in_place_weight_updates():
 
 def test_spt_engines_agree_and_packs_are_used():
     """The SPT stage has two engines: the fp32 matrix instructions on the nn.Linear weights in place ("fp32_mfma",
-    DataParallel replicas) and fp32 arithmetic on the bf16 matrix cores from operands split by mpl_spt_pack (default).
+    DataParallel replicas) and fp32 arithmetic on the fp16 matrix cores from operands split by mpl_spt_pack (default).
     Both must reproduce the reference's FPT input tap; the packed one must actually be selected by default."""
     lib = cabi.load()
     assert lib.mpl_spt_pack_bytes() == 48 * 1024

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from openmpl_amd import cabi, detrng
 from oracle import mpl_oracle, split_oracle
-from tests.test_gpu_parity import DEV, _assert_close, _big_inputs, _fp64_linear, _model, _stream, _x3_linear
+from tests.test_gpu_parity import DEV, _assert_close, _big_inputs, _fp64_linear, _model, _stream
 
 pytestmark = pytest.mark.gpu
 
@@ -199,13 +199,13 @@ def test_h2_shapes_are_validated():
                                 W.data_ptr(), 16, _stream()) == -3
 
 
-def test_h2_is_the_default_engine_and_the_older_engines_still_agree():
-    """"fp32" packs fp16x2 operands; "fp32x3" (three bf16 parts) and "fp32_mfma" give the same poses to rounding; every engine is
-    bitwise independent of the batch size."""
+def test_h2_is_the_default_engine_and_the_native_fp32_engine_agrees():
+    """"fp32" packs fp16x2 operands; "fp32_mfma" gives the same poses to rounding; "bf16" packs bf16 operands into the *_w16
+    fields; every engine is bitwise independent of the batch size."""
     m, g = _model("chosen_v4_b8_l12")
     P, R, Cn = _big_inputs(512, 4, 5)
     outs = {}
-    for prec in ("fp32", "fp32x3", "fp32_mfma"):
+    for prec in ("fp32", "bf16", "fp32_mfma"):
         m.set_matmul_precision(prec)
         with torch.no_grad():
             full = m(P, rays=R, centers=Cn)
@@ -214,23 +214,14 @@ def test_h2_is_the_default_engine_and_the_older_engines_still_agree():
         assert torch.equal(full[100:400], part), prec + ": batch slice changed results"
         outs[prec] = full
         blk = m._hip_cache[0]["fpt_blocks"][0]
-        assert bool(blk.qkv_h2) == (prec == "fp32") and bool(blk.qkv_w3) == (prec == "fp32x3")
-    for other in ("fp32x3", "fp32_mfma"):
-        mx, nw = mpl_oracle.rel_errors(outs["fp32"].cpu(), outs[other].cpu())
-        assert 0 < mx < 5e-6 and nw < 5e-6, (other, mx, nw)
+        assert bool(blk.qkv_h2) == (prec == "fp32") and bool(blk.qkv_w16) == (prec == "bf16") and not blk.proj_w3
+    mx, nw = mpl_oracle.rel_errors(outs["fp32"].cpu(), outs["fp32_mfma"].cpu())
+    assert 0 < mx < 5e-6 and nw < 5e-6, (mx, nw)
+    mx, nw = mpl_oracle.rel_errors(outs["fp32"].cpu(), outs["bf16"].cpu())
+    assert 1e-5 < mx < 5e-2, (mx, nw)
     m.set_matmul_precision("fp32")
-
-
-@pytest.mark.parametrize("name", ["chosen_v4_b8_l12", "full_v4_b8_l2", "chosen_v8_b4_l2", "chosen_v5_b19_l2", "chosen_v31_b2_l12", "chosen_v2_b1_l12"])
-def test_x3_engine_still_matches_goldens(name):
-    """The round-2 engine stays selectable ("fp32x3") and stays green against the reference goldens."""
-    m, g = _model(name)
-    m.set_matmul_precision("fp32x3")
-    from tests.util import golden_inputs
-    P, R, Cn = golden_inputs(g, DEV)
-    with torch.no_grad():
-        out = m(P, rays=R, centers=Cn)
-    _assert_close(out, torch.from_numpy(g["out"]), name + " fp32x3")
+    with pytest.raises(ValueError):
+        m.set_matmul_precision("fp32x3")            # the round-2 three-part engine is gone (round 5)
 
 
 def _kinds(fn):

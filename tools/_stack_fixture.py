@@ -1,5 +1,5 @@
 """Shared fixture of the block-stack tools: one FPT block with packed operands of the chosen engine.
-ENGINE=h2 (default: fp16x2, h2_gemm.hip) | x3 (bf16x3, x3_gemm.hip) in the environment."""
+ENGINE=h2 (default: fp16x2, h2_gemm.hip) | b1 (bf16, b1_gemm.hip) in the environment."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 
 def make_block(D, seed=0):
     g = torch.Generator().manual_seed(seed)
-    nbytes, pack = (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2) if ENGINE == "h2" else (lib.mpl_split_bf16x3_bytes, lib.mpl_split_bf16x3)
+    nbytes, pack = (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2) if ENGINE == "h2" else (lib.mpl_pack_b1_bytes, lib.mpl_pack_b1)
 
     def operand(N, K, ln, in_scale=None):
         W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
@@ -34,5 +34,5 @@ def make_block(D, seed=0):
     if ENGINE == "h2":
         blk.qkv_h2, blk.proj_h2, blk.fc1_h2, blk.fc2_h2 = (k.data_ptr() for k in keep)
     else:
-        blk.qkv_w3, blk.proj_w3, blk.fc1_w3, blk.fc2_w3 = (k.data_ptr() for k in keep)
+        blk.qkv_w16, blk.proj_w16, blk.fc1_w16, blk.fc2_w16 = (k.data_ptr() for k in keep)
     return (cabi.BlockWeights * 1)(blk), keep, g

@@ -1,6 +1,20 @@
+#!/bin/bash
+# A/B of prebuilt library variants inside ONE gpurun call (boxes differ by a few per cent, so only same-call numbers compare):
+#   bash tools/build_variants.sh [-f file.hip] base="" x="-DH2_WT_AUX=0" ...        (here, no GPU: -> build_tmp/lib_<tag>.so)
+#   gpurun -- 'bash tools/ab.sh "<command>" [-r rounds] base x ...'                  (on the GPU box)
+# Installs build_tmp/lib_<tag>.so as the library (the source-hash stamp stays valid, so nothing rebuilds), runs <command>,
+# prefixes every output line with the tag; `rounds` alternations (default 2).  The installed library is restored at the end.
 export TMPDIR=/tmp
-timeout 300 python tools/chain_check.py 2>&1 | tail -6
-timeout 300 python bench.py --no-extra --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(j['value'], j['ms_per_step'], j['roofline']['kernel_ms_per_step'], j['parity'])"
+cd "$(dirname "$0")/.."
+CMD=$1; shift
+R=2
+if [ "$1" = "-r" ]; then R=$2; shift 2; fi
+L=openmpl_amd/lib/libmpl_hip.so
+cp $L /tmp/libmpl_hip.keep.so
+for r in $(seq 1 $R); do
+  for tag in "$@"; do
+    cp build_tmp/lib_$tag.so $L
+    timeout 600 bash -c "$CMD" 2>&1 | sed "s/^/[$tag] /"
+  done
+done
+cp /tmp/libmpl_hip.keep.so $L

@@ -12,7 +12,7 @@ mkdir -p build_tmp/obj
 SRCS=$(python -c "from openmpl_amd import build; print(' '.join(build.SOURCES))")
 for s in $SRCS; do
   o=build_tmp/obj/${s%.hip}.o
-  if [ "$s" != "$F" ] && { [ ! -f $o ] || [ openmpl_amd/csrc/$s -nt $o ] || [ openmpl_amd/csrc/common.hpp -nt $o ] || [ openmpl_amd/csrc/gemm_common.hpp -nt $o ] || [ include/mpl_hip.h -nt $o ]; }; then
+  if [ "$s" != "$F" ] && { [ ! -f $o ] || [ openmpl_amd/csrc/$s -nt $o ] || [ openmpl_amd/csrc/common.hpp -nt $o ] || [ openmpl_amd/csrc/gemm_common.hpp -nt $o ] || [ openmpl_amd/csrc/h2_phase.hpp -nt $o ] || [ include/mpl_hip.h -nt $o ]; }; then
     $CC -c openmpl_amd/csrc/$s -o $o &
   fi
 done

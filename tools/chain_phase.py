@@ -1,6 +1,6 @@
 """Per-phase time line of the persistent stack kernel (chain mode) at the headline shape: the stack is stopped after
 phase p (mpl_x3_stack_mode) so that the per-wave stamps of mpl_x3_debug_buffer are those of phase p.
-[ENGINE=h2|x3] python tools/chain_phase.py [D] [n_blocks] [M]   (library built with -DH2_DBG=1 / -DX3_DBG=1)"""
+[ENGINE=h2|b1] python tools/chain_phase.py [D] [n_blocks] [M] [n_tok]   (library built with -DH2_DBG=1)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,15 +10,16 @@ from tools._stack_fixture import lib, dev, st, make_block, ENGINE
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 544
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+NTOK = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 blks, keep, g = make_block(D)
 x = torch.randn(M, D, generator=g).to(dev)
-wsb = lib.mpl_block_stack_workspace_bytes(M // 4, 4, D)
+wsb = lib.mpl_block_stack_workspace_bytes(M // NTOK, NTOK, D)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 dbg = torch.zeros(8 * 8 * 1024, dtype=torch.int64, device=dev)
 names = ["qkv+att", "proj+res", "fc1+gelu", "fc2+res"]
 sched = (C.c_uint8 * NB)(*([0] * NB))
 def run():
-    cabi.check(lib.mpl_block_stack(x.data_ptr(), M // 4, 4, D, 8, blks, sched, NB, ws.data_ptr(), wsb, st()), "stack")
+    cabi.check(lib.mpl_block_stack(x.data_ptr(), M // NTOK, NTOK, D, 8, blks, sched, NB, ws.data_ptr(), wsb, st()), "stack")
 for _ in range(3): run()
 torch.cuda.synchronize()
 prev_end = None
@@ -31,8 +32,11 @@ for stop in range(4 * (NB - 1) - 1, 4 * NB + 1):
     ph = (stop - 1) & 3
     # teams that own >= 2 row tiles run the two-tile stage (h2_stack2_kernel): fc1 is then two one-pass steps of D / 32 stages
     # (the stamps are those of the second), qkv two one-tile steps
-    pairs = ENGINE == "h2" and (M + 63) // 64 > 256 // (D // 136)
-    nst = {0: 3, 1: 1, 2: 1 if pairs else 2, 3: 2}[ph] * (D // 32)
+    pairs = (M + 63) // 64 > 256 // (D // 136)
+    if ENGINE == "h2":
+        nst = {0: 3, 1: 1, 2: 1 if pairs else 2, 3: 2}[ph] * (D // 32)
+    else:       # bf16: a stage is a pair of k-tiles; every phase runs the pair form
+        nst = {0: 3, 1: 1, 2: 2, 3: 1}[ph] * ((D // 32 + 1) // 2) if ph != 3 else (2 * D // 32 + 1) // 2
     ent, loop, epi, sto, end = (t[:, i] for i in range(5))
     print("stop %2d %-9s waves %4d | entry->loop %6.0f (min %6.0f max %6.0f) | k loop %7.0f (%5.0f/stage, %d stages) | epilogue %6.0f | drain %5.0f | total %7.0f | DMA wait/stage %4.0f  bar/stage %4.0f"
           % (stop, names[ph], len(t), (loop - ent).mean(), (loop - ent).min(), (loop - ent).max(), (epi - loop).mean(), (epi - loop).mean() / nst, nst,

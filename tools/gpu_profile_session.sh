@@ -5,7 +5,7 @@
 #   1. bench line (N=1)                                             -> gpurun_out/prof_$TAG[_$SUF]/bench.json
 #   2. rocprofv3 kernel trace + stats of the SAME command           -> .../trace/
 #   3. rocprofv3 PMC passes (each its own run, --kernel-trace only) over the same command: the kernels profiled are
-#      the ones the forward runs (x3_stack_kernel, spt3_kernel, fuse_head_kernel, ...)
+#      the ones the forward runs (h2_stack_kernel, spt3_kernel, fuse_head_kernel, ...)
 # tools/make_profiles.py $TAG [$SUF] turns the outputs into profiles/$TAG_*.
 TAG=${1:-r03}
 SUF=$2
@@ -14,6 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG${SUF:+_$SUF}
 mkdir -p $O; export TMPDIR=/tmp
 cd $R
+python -c "from openmpl_amd import build; print(build.source_hash())" > $O/srchash.txt
 if [ -z "$SUF" ]; then
   python bench.py > $O/bench.log 2>&1
 else

@@ -127,6 +127,8 @@ if cands:
          "fetch_bytes_per_launch": m["fetch_bytes"], "write_bytes_per_launch": m["write_bytes"],
          "traffic_bytes_per_launch": m["traffic_bytes"], "algorithmic_bytes_per_launch": alg,
          "traffic_ratio": (m["traffic_bytes"] / alg) if alg else None, "tcc_hit_rate": m.get("tcc_hit_rate"),
+         # the library the passes ran on: bench.py reports roofline.traffic only while the sources still hash to this
+         "srchash": (open("%s/srchash.txt" % G).read().strip() if os.path.exists("%s/srchash.txt" % G) else None),
          "source": "%spmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the bench command itself, HEADLINE "
                    "launch group only, FETCH_SIZE x2 gfx950 correction)" % stem}
     json.dump(j, open(stem + "gemm_traffic.json", "w"), indent=1)
