@@ -61,6 +61,11 @@ extern "C" {
 #define MPL_F_NO_FPT (1u << 9)          /* no_transformer_fpt */
 #define MPL_F_CONF_IN_FPT (1u << 10)    /* confidence_in_FPT */
 #define MPL_F_KPTOK (1u << 11)          /* FPT_blocks_view_keypoint_tokens: FPT blocks of width d over 17*V tokens */
+/* not a constructor kwarg: engine selection of the FPT block stack.  Stacks of at most 32 token rows (a single frame, a few
+ * persons) normally run the small-batch engine (csrc/sm_stack.hip: exact fp32 MFMA, the whole chip per GEMM), larger ones the
+ * team kernels (fp16x2 operands): two fp32 engines that agree to ~1e-7 but not bit for bit.  With this flag the team kernels
+ * run for EVERY batch size, so that a pose carries the same bits whatever batch or shard it arrives in. */
+#define MPL_F_NO_SMALL_STACK (1u << 12)
 
 /* epilogues of mpl_ln_linear */
 #define MPL_EPI_BIAS 0          /* y = a W^T + b                       (attn.qkv) */
@@ -168,6 +173,9 @@ int mpl_spt_tokens(const mpl_config *cfg, const mpl_weights *w, const mpl_inputs
 size_t mpl_block_stack_workspace_bytes(int n_seq, int n_tok, int dim);
 int mpl_block_stack(float *x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights *blocks,
                     const uint8_t *schedule, int n_apps, void *workspace, size_t workspace_bytes, void *stream);
+/* the same with engine flags (MPL_F_NO_SMALL_STACK; 0 = mpl_block_stack) */
+int mpl_block_stack_ex(float *x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights *blocks,
+                       const uint8_t *schedule, int n_apps, void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
 
 /* y[M,N] = epilogue( LN(x)[M,K] . W[N,K]^T + bias ); ln_w == NULL skips the LayerNorm.
  * `stats` is scratch for 2*M*max(1, K/136) floats (per-slice LayerNorm partials) when ln_w != NULL.

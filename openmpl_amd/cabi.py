@@ -29,6 +29,7 @@ F_NO_SPT = 1 << 8
 F_NO_FPT = 1 << 9
 F_CONF_IN_FPT = 1 << 10
 F_KPTOK = 1 << 11
+F_NO_SMALL_STACK = 1 << 12
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
 
@@ -73,7 +74,7 @@ class Inputs(C.Structure):
 
 
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
-           "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack",
+           "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack", "mpl_block_stack_ex",
            "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_d32_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_pack_h2_bytes", "mpl_pack_h2", "mpl_pack_h2_scaled", "mpl_pack_h2_out_scale", "mpl_ln_linear_h2_workspace_bytes", "mpl_ln_linear_h2", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_device_error", "mpl_device_error_clear", "mpl_x3_spin_limit", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
            "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_pose_metrics_ex", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
@@ -135,6 +136,9 @@ def load():
         lib.mpl_block_stack.restype = C.c_int
         lib.mpl_block_stack.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BlockWeights),
                                         C.POINTER(C.c_uint8), C.c_int, _fp, C.c_size_t, _fp]
+        lib.mpl_block_stack_ex.restype = C.c_int
+        lib.mpl_block_stack_ex.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BlockWeights),
+                                           C.POINTER(C.c_uint8), C.c_int, _fp, C.c_size_t, C.c_uint, _fp]
         lib.mpl_ln_linear.restype = C.c_int
         lib.mpl_ln_linear.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int, C.c_int, _fp,
                                       _fp, _fp, _fp]

@@ -278,7 +278,8 @@ int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
 }
 
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
-                     const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, hipStream_t s) {
+                     const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, bool allow_small,
+                     hipStream_t s) {
     if (err_ws) *err_ws = nullptr;
     if (!x || n_seq <= 0 || n_tok <= 0 || D <= 0 || H <= 0 || n_apps < 0) return MPL_E_INVALID;
     // row counts are 32-bit in the kernels (byte offsets are 64-bit): refuse what would overflow instead of wrapping
@@ -288,10 +289,19 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
     // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
-    if ((np0 == 0 || np0 == 2) && sm_stack_enabled() && n_apps <= MPL_MAX_APPS) {
+    // (not when the caller asked for batch-invariant bits -- MPL_F_NO_SMALL_STACK --, nor under the A/B switches of the team
+    // kernels: one launch per GEMM, stop after n phases)
+    if ((np0 == 0 || np0 == 2) && allow_small && sm_stack_enabled() && n_apps <= MPL_MAX_APPS &&
+        !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0) {
         int n_blocks = 0;
-        for (int a = 0; a < n_apps; ++a) n_blocks = schedule[a] + 1 > n_blocks ? schedule[a] + 1 : n_blocks;
-        if (sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks)) {
+        bool raw = true;        // the engine reads the nn.Linear tensors in place: a caller that hands over packed operands only
+        for (int a = 0; a < n_apps; ++a) {      // (the C ABI allows it) gets the team kernels, not an error
+            n_blocks = schedule[a] + 1 > n_blocks ? schedule[a] + 1 : n_blocks;
+            const mpl_block_weights& b = blocks[schedule[a]];
+            raw = raw && b.ln1_w && b.ln1_b && b.qkv_w && b.qkv_b && b.proj_w && b.proj_b && b.ln2_w && b.ln2_b && b.fc1_w && b.fc1_b &&
+                  b.fc2_w && b.fc2_b;
+        }
+        if (raw && sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks)) {
             const int rc = launch_sm_stack(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, g_spin_log2.load(), s);
             if (rc != MPL_E_UNSUPPORTED) return rc;       // fewer CUs than column tiles: the team kernels below
             if (err_ws) *err_ws = nullptr;
@@ -465,12 +475,17 @@ int mpl_spt_tokens(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs
     return launch_spt(cfg, w, in, xs, w->spt_packed != 0, (hipStream_t)stream);
 }
 
-int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
-                    const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, void* stream) {
+int mpl_block_stack_ex(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
+                       const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, unsigned flags, void* stream) {
     clear_stale_hip_error();
     if (int rc = earlier_device_failure()) return rc;
     return block_stack_impl(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes, nullptr,
-                            (hipStream_t)stream);
+                            (flags & MPL_F_NO_SMALL_STACK) == 0, (hipStream_t)stream);
+}
+
+int mpl_block_stack(float* x, int n_seq, int n_tok, int dim, int heads, const mpl_block_weights* blocks,
+                    const uint8_t* schedule, int n_apps, void* workspace, size_t workspace_bytes, void* stream) {
+    return mpl_block_stack_ex(x, n_seq, n_tok, dim, heads, blocks, schedule, n_apps, workspace, workspace_bytes, 0u, stream);
 }
 
 int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* ln_b, float eps, const float* W,
@@ -572,7 +587,7 @@ int mpl_device_error_clear(int device) {
 int mpl_x3_spin_limit(int log2_polls) {
     if ((log2_polls & 0xff) < 1 || (log2_polls & 0xff) > 30 || log2_polls < 0) return MPL_E_INVALID;
     // the fault injection (bits 8..) is compiled into the product library but inert unless the process opted in
-    // (MPL_FAULT_INJECT=1 in the environment when the library was loaded), and it is ONE-SHOT: the first stack launch that
+    // (MPL_FAULT_INJECT=1 in the environment at the FIRST call of this function), and it is ONE-SHOT: the first stack launch that
     // consumes it clears it, so a test that dies between set and reset cannot leave the process deserting workgroups
     static const bool inject_ok = getenv("MPL_FAULT_INJECT") != nullptr && atoi(getenv("MPL_FAULT_INJECT")) != 0;
     if ((log2_polls >> 8) != 0 && !inject_ok) return MPL_E_UNSUPPORTED;
@@ -686,7 +701,7 @@ int mpl_forward(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* i
         }
         const bool kp = (cfg->flags & MPL_F_KPTOK) != 0;
         if ((rc = block_stack_impl(xs, B, kp ? V * cfg->num_joints : V, kp ? cfg->dim : D, cfg->heads, w->fpt_blocks,
-                                   sched, n, rest, rest_bytes, &err_ws, s)))
+                                   sched, n, rest, rest_bytes, &err_ws, (cfg->flags & MPL_F_NO_SMALL_STACK) == 0, s)))
             return rc;
     }
     return launch_fuse_head(cfg, w, xs, B, out, nullptr, err_ws, s);

@@ -437,6 +437,8 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     for (int i = 0; i < n_apps; ++i) n_blocks = schedule[i] + 1 > n_blocks ? schedule[i] + 1 : n_blocks;
     if (!x || !blocks || !schedule || !sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks)) return MPL_E_INVALID;
     if (!ws || ws_bytes < sm_stack_ws_bytes(M, D)) return MPL_E_WORKSPACE;
+    (void)take_fault_injection();       // the one-shot test hook deserts a workgroup of a TEAM launch: an armed one must not outlive
+                                        // this (unrelated) launch and hit the next team launch of the process
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;

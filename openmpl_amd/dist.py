@@ -120,6 +120,12 @@ class ShardedLifter:
     def __init__(self, model: Callable, group=None):
         self.model = model
         self.group = group
+        # a shard must equal the rows of the single-process result bit for bit, whatever the world size leaves of the batch: the
+        # small-batch engine (<= 32 token rows, another fp32 arithmetic: ~1e-7 apart) is therefore off for sharded lifting
+        # (MultiView_MPL.set_small_batch_engine; models wrapped in MultiView_MPL_G expose it through .features)
+        for m in (model, getattr(model, "features", None)):
+            if hasattr(m, "set_small_batch_engine"):
+                m.set_small_batch_engine(False)
 
     def lift_shard(self, poses, rays=None, centers=None, batch: Optional[int] = None) -> GatherHandle:
         world = dist.get_world_size(self.group)

@@ -103,6 +103,44 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+# ---------------------------------------------------------------------------------------------- the forward as ONE torch operator
+# north_star: "hand-written HIP ... exposed as a torch extension".  The library is reached through ctypes (cabi.py); this
+# registration makes the same call a dispatcher-visible operator, openmpl_amd::forward, without another build: torch.profiler
+# shows it, torch.library.opcheck can test it, and torch.compile(fullgraph=True) of a caller traces through it as ONE opaque
+# node with the meta function below.  The module is not a tensor: it travels as an integer handle into a registry of live
+# modules (weak references).  The parameters are captured state of the operator, like the weights of a compiled graph.
+import weakref as _weakref
+
+_LIVE_MODULES = _weakref.WeakValueDictionary()
+_NEXT_HANDLE = [1]
+
+
+def _module_of(handle: int) -> "MultiView_MPL":
+    m = _LIVE_MODULES.get(int(handle))
+    if m is None:
+        raise RuntimeError("openmpl_amd::forward: module handle %d is not alive" % handle)
+    return m
+
+
+@torch.library.custom_op("openmpl_amd::forward", mutates_args=(), device_types="cuda")
+def _forward_op(handle: int, poses: List[torch.Tensor], rays: List[torch.Tensor], centers: List[torch.Tensor]) -> List[torch.Tensor]:
+    """[poses (B,17,3)] of MultiView_MPL.forward (reference :450-525); with head_kadkhod [x3, x1, x2].  rays / centers: V tensors
+    or an empty list (= None)."""
+    m = _module_of(handle)
+    out = m._forward_impl(list(poses), list(rays) or None, list(centers) or None)
+    if isinstance(out, tuple):
+        return [out[0]] + list(out[1])
+    return [out]
+
+
+@_forward_op.register_fake
+def _forward_op_fake(handle, poses, rays, centers):
+    m = _module_of(handle)
+    B = poses[0].shape[0]
+    n = 3 if m.head_kadkhod else 1
+    return [poses[0].new_empty((B, m.num_joints, 3), dtype=torch.float32) for _ in range(n)]
+
+
 class MultiView_MPL(nn.Module):
     """Constructor surface and parameter layout of the reference ``MultiView_MPL`` (:94-317)."""
 
@@ -240,6 +278,11 @@ class MultiView_MPL(nn.Module):
             self.head = nn.ModuleList([first] + rest)
 
         self._unsupported = self._find_unsupported()
+        self.__dict__["_op_handle"] = _NEXT_HANDLE[0]       # plain attributes: not part of state_dict / repr
+        _NEXT_HANDLE[0] += 1
+        _LIVE_MODULES[self._op_handle] = self
+        self.__dict__["_use_torch_op"] = "auto"
+        self.__dict__["_small_batch_engine"] = "auto"
         self._hip_cache = {}
         self._dp_replica = False
         self._dp_src = None
@@ -575,7 +618,43 @@ class MultiView_MPL(nn.Module):
         return dev, B, poses, rays, centers
 
     # ------------------------------------------------------------------ forward (reference :450-525)
+    def use_torch_op(self, mode="auto"):
+        """How forward() reaches the kernels: True -- always through the registered operator openmpl_amd::forward; False -- always
+        the direct ctypes call; "auto" (default) -- through the operator whenever something is watching the dispatcher (a
+        torch.profiler session, torch.compile tracing) and directly otherwise: the direct call is what the benchmarks time, the
+        operator adds the dispatcher's Python round trip (tools/small_batch.py measures it) and nothing else -- same kernels,
+        same stream, bitwise the same poses."""
+        if mode not in (True, False, "auto"):
+            raise ValueError("use_torch_op: True, False or 'auto'")
+        self.__dict__["_use_torch_op"] = mode
+        return self
+
+    def set_small_batch_engine(self, mode="auto"):
+        """Engine of the FPT block stack for at most 32 token rows (B x V <= 32: a single frame, a few persons), fp32 precision:
+        True / "auto" -- the small-batch engine (csrc/sm_stack.hip: every GEMM on the whole chip, exact fp32 MFMA), 2-3x lower
+        latency; False -- the team kernels of the large batches for EVERY batch size.  The two fp32 engines agree to ~1e-7 but
+        not bit for bit, so with "auto" a pose of a batch of <= 32 / V poses does not carry the bits it would carry inside a
+        larger batch.  Code that needs results independent of how a batch is split -- the last ragged batch of a validate()
+        loop against a rerun, shards against the unsharded batch -- asks for False; openmpl_amd.dist.ShardedLifter and
+        DataParallel replicas always run with False for that reason (a shard must equal the single-process result bitwise)."""
+        if mode not in (True, False, "auto"):
+            raise ValueError("set_small_batch_engine: True, False or 'auto'")
+        self.__dict__["_small_batch_engine"] = mode
+        return self
+
+    def _small_engine_allowed(self) -> bool:
+        return self._small_batch_engine in (True, "auto") and not self._dp_replica
+
     def forward(self, poses: Sequence[torch.Tensor], rays=None, centers=None):
+        mode = self._use_torch_op
+        if mode is True or (mode == "auto" and not self._dp_replica and
+                            (torch.compiler.is_compiling() or torch.autograd.profiler._is_profiler_enabled)):
+            out = torch.ops.openmpl_amd.forward(self._op_handle, list(poses), list(rays) if rays is not None else [],
+                                                list(centers) if centers is not None else [])
+            return (out[0], [out[1], out[2]]) if self.head_kadkhod else out[0]
+        return self._forward_impl(poses, rays, centers)
+
+    def _forward_impl(self, poses: Sequence[torch.Tensor], rays=None, centers=None):
         if self._unsupported:
             raise NotImplementedError("MultiView_MPL (HIP): unsupported configuration: " + self._unsupported)
         if self.training:
@@ -588,6 +667,8 @@ class MultiView_MPL(nn.Module):
         with torch.cuda.device(dev):
             ent = self._marshal(dev)
             cfg = ent["cfg"]
+            # engine selection of the block stack is a per-call decision (set_small_batch_engine; replicas never take the small engine)
+            cfg.flags = (cfg.flags & ~cabi.F_NO_SMALL_STACK) | (0 if self._small_engine_allowed() else cabi.F_NO_SMALL_STACK)
             inp = cabi.Inputs()
             inp.batch = B
             for v in range(self.num_views):
@@ -630,8 +711,9 @@ class MultiView_MPL(nn.Module):
             sched = (C.c_uint8 * len(order))(*order)
             ws_bytes = lib.mpl_block_stack_workspace_bytes(B, n_tok, dim)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            cabi.check(lib.mpl_block_stack(xs.data_ptr(), B, n_tok, dim, self.num_heads, ent["fpt_blocks"], sched,
-                                           len(order), ws.data_ptr(), ws_bytes, stream), "mpl_block_stack")
+            cabi.check(lib.mpl_block_stack_ex(xs.data_ptr(), B, n_tok, dim, self.num_heads, ent["fpt_blocks"], sched,
+                                              len(order), ws.data_ptr(), ws_bytes, cfg.flags & cabi.F_NO_SMALL_STACK, stream),
+                       "mpl_block_stack")
         y = torch.empty((B, E), **f32)
         if self.linear_weighted_mean:                                           # :441-443
             xn = torch.empty((B, V * E), **f32)
@@ -733,6 +815,19 @@ class MultiView_MPL_G(nn.Module):
 
     def forward(self, x, centers=None, rays=None):                                     # :583-585
         return self.features(x, rays=rays, centers=centers)
+
+    # engine switches of the HIP path (not part of the reference's surface), forwarded to the model inside
+    def set_matmul_precision(self, precision: str):
+        self.features.set_matmul_precision(precision)
+        return self
+
+    def set_small_batch_engine(self, mode="auto"):
+        self.features.set_small_batch_engine(mode)
+        return self
+
+    def use_torch_op(self, mode="auto"):
+        self.features.use_torch_op(mode)
+        return self
 
     def init_weights(self, pretrained=""):
         """Reference :587-646.  A checkpoint path containing a dataset name is loaded non-strictly;

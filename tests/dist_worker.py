@@ -29,6 +29,9 @@ def main():
     m = MultiView_MPL(**FLAGS)
     detrng.fill_module_(m, seed=5)
     m = m.to(dev).eval()
+    # the single-process reference of a sharded run is the batch-invariant arithmetic: ShardedLifter switches the small-batch
+    # engine (another fp32 arithmetic for <= 32 token rows) off, and so does the reference run
+    m.set_small_batch_engine(False)
     batches = []
     for step in range(2):
         p, r, c = detrng.make_inputs(batch, FLAGS["num_views"], seed=77, step=step)

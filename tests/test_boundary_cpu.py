@@ -208,3 +208,40 @@ def test_cached_parameter_lists_follow_reassignment():
     # a DataParallel replica is a fresh object with plain tensor attributes: never served from (or stored in) a cache
     r = m._replicate_for_data_parallel()
     assert r._dp_replica and "_tl_cache" not in r.__dict__ or r.__dict__.get("_tl_cache") is m.__dict__.get("_tl_cache")
+
+
+def test_forward_is_a_registered_torch_operator_with_a_meta_function():
+    """north_star "exposed as a torch extension": openmpl_amd::forward is registered with the dispatcher; its fake (meta)
+    implementation gives shape / dtype / device without a GPU, so torch.compile can trace a caller through it as one node."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert hasattr(torch.ops.openmpl_amd, "forward")
+    for kw, n_out in ((dict(), 1), (dict(head_kadkhod=True, hidden_dim=64), 3)):
+        m = MultiView_MPL(num_views=3, depth=1, **kw).eval()
+        with FakeTensorMode():
+            poses = [torch.empty(5, 17, 3, device="cuda") for _ in range(3)]
+            out = torch.ops.openmpl_amd.forward(m._op_handle, poses, [], [])
+        assert len(out) == n_out
+        for o in out:
+            assert tuple(o.shape) == (5, 17, 3) and o.dtype == torch.float32 and o.device.type == "cuda"
+    with pytest.raises(RuntimeError, match="not alive"):
+        with FakeTensorMode():
+            torch.ops.openmpl_amd.forward(10 ** 9, [torch.empty(1, 17, 3, device="cuda")], [], [])
+    with pytest.raises(ValueError):
+        m.use_torch_op("sometimes")
+    with pytest.raises(ValueError):
+        m.set_small_batch_engine("maybe")
+
+
+def test_cached_tensor_lists_follow_wholesale_parameter_swaps():
+    """paths that replace parameters without a registration hook (functional_call-style writes into _parameters,
+    _apply under overwrite_module_params_on_conversion) must not leave the forward with a stale list of tensors."""
+    m = MultiView_MPL(num_views=2, depth=1).eval()
+    first = m._tensor_lists()
+    assert m._tensor_lists() is first                                  # cached
+    w_old = m.blocks[0].attn.qkv.weight
+    m.blocks[0].attn.qkv._parameters["weight"] = torch.nn.Parameter(w_old.detach().clone())   # no hook fires
+    again = m._tensor_lists()
+    assert again is not first and any(t is m.blocks[0].attn.qkv.weight for t in again[1])
+    assert not any(t is w_old for t in again[1])
+    m.float()                                                          # _apply drops every cache
+    assert "_tl_cache" not in m.__dict__
