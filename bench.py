@@ -231,7 +231,12 @@ def stack_kernel_name(precision, batch, views, D, dev, launches=1):
     cap = torch.cuda.get_device_properties(dev).multi_processor_count // (D // 136)
     if precision == "bf16":
         return "h2_stack_kernel<1>"           # bf16 operands: one row tile per team step (the pair form is not faster)
-    return "h2_stack2_kernel<2>" if n_tiles > cap else "h2_stack_kernel<2>"
+    if n_tiles > cap:
+        return "h2_stack2_kernel<2>"
+    cus, G = torch.cuda.get_device_properties(dev).multi_processor_count, D // 136
+    if rpt == 64 and 16 % views == 0 and n_tiles * 2 * G <= cus:
+        return "h2_stackn_kernel<2>"          # row-narrow teams: 16- or 32-row workgroups while they fit one per compute unit
+    return "h2_stack_kernel<2>"
 
 
 def stack_roofline(model, flags, batch, batches, precision, dev, n_prof=20):

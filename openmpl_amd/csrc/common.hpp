@@ -137,6 +137,9 @@ int take_fault_injection();
 int refuse_stream_capture(hipStream_t s);
 void h2_set_spin_log2(int log2_polls);     // test hook (mpl_x3_spin_limit)
 void h2_set_row_tiles(int rt);             // A/B switch of the block stack: 0 by shape, 1 / 2 row tiles per stage
+void h2_set_narrow(int mode);              // row-narrow teams: 0 by shape, 1 never, 2 / 3 = 32- / 16-row workgroups where legal
+// arrival counters of a stack call: one per (row tile, 16-row group) -- the row-narrow teams synchronise per sub-tile -- then the error word
+constexpr int H2_CTR_PER_TILE = 4;
 // The persistent block-stack kernels (h2_stack_kernel and its pair forms, sm_stack_kernel) need every workgroup resident: the library
 // serialises its own launches of them per device, whatever stream they are on -- each launch waits for the event recorded
 // behind the previous one (api.hip).  The event exists from the first call (waiting on a never-recorded event is a no-op).

@@ -363,6 +363,9 @@ void h2_set_spin_log2(int v) { g_h2_spin_log2.store(v & 0xff); }
 unsigned long long* h2_debug_buffer() { return g_h2_dbg.load(); }
 int h2_spin_log2() { return g_h2_spin_log2.load(); }
 int h2_row_tiles() { return g_h2_rt.load(); }
+static std::atomic<int> g_h2_narrow{0};
+void h2_set_narrow(int mode) { g_h2_narrow.store(mode & 3); }
+int h2_narrow_mode() { return g_h2_narrow.load(); }
 
 
 template <int EPI, bool LNF, int NPASS>

@@ -174,12 +174,15 @@ __device__ __forceinline__ void h2_emit_tail(bool wt, char* base, int t, unsigne
 // channels, generic form (any n_tok <= 32, any head width that divides 136): S whole sequences of nt tokens; the output
 // is written as packed A2 of width Dq (column c scaled by so[c], the static scales of this workgroup's 136 v columns) for proj.  The 4-token shapes never come here (registers).
 template <int NP>
+// rg_lo / rgs: the row groups (16 rows each) of the tile this workgroup owns (row-narrow teams; 0 / 4 = the whole tile): only their
+// sequences are scored and written -- 16 must then be a multiple of nt, the launcher sees to it
 __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int tid, int nt, int hd, int S, char* C2, int tile_m,
-                                             int g_out, int Dq, const float* so) {
+                                             int g_out, int Dq, const float* so, int rg_lo = 0, int rgs = 4) {
     const int hd4 = hd >> 2;
     const int HP = BN / hd, nn = nt * nt;
     const float scale = 1.0f / sqrtf((float)hd);
-    for (int t = tid; t < S * HP * nn; t += 512) {
+    const int sq_lo = rgs == 4 ? 0 : (16 * rg_lo) / nt, sq_hi = rgs == 4 ? S : (16 * (rg_lo + rgs)) / nt;
+    for (int t = sq_lo * HP * nn + tid; t < sq_hi * HP * nn; t += 512) {
         const int j = t % nt, i = (t / nt) % nt, hh = (t / nn) % HP, sq = t / (nn * HP);
         const float* q = T + (sq * nt + i) * H2_ATT_TS + hh * hd;
         const float* k = T + (sq * nt + j) * H2_ATT_TS + BN + hh * hd;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
         SC[t] = ((s0 + s1) + (s2 + s3)) * scale;
     }
     __syncthreads();
-    for (int t = tid; t < S * HP * nt; t += 512) {
+    for (int t = sq_lo * HP * nt + tid; t < sq_hi * HP * nt; t += 512) {
         float* pr = SC + t * nt;
         float mx = pr[0];
         for (int j = 1; j < nt; ++j) mx = fmaxf(mx, pr[j]);
@@ -231,6 +234,7 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
     };
     for (int t = tid; t < BM * 16; t += 512) {
         const int li = t & 15, kq = (t >> 4) & 3, rg = (t >> 6) & 3, p = t >> 8;
+        if (rg < rg_lo || rg >= rg_lo + rgs) continue;
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 32 * p + 4 * kq), b = pv4(row, 32 * p + 16 + 4 * kq);
         float4 sa = {1.f, 1.f, 1.f, 1.f}, sb = {1.f, 1.f, 1.f, 1.f};
@@ -240,6 +244,7 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
     }
     for (int t = tid; t < BM * 2; t += 512) {
         const int li = t & 15, kq = (t >> 4) & 1, rg = t >> 5;
+        if (rg < rg_lo || rg >= rg_lo + rgs) continue;
         const int row = rg * 16 + li;
         const float4 a = pv4(row, 128 + 4 * kq);
         float4 sa = {1.f, 1.f, 1.f, 1.f};
@@ -266,9 +271,15 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
 // takes every A operand packed (also the LayerNorm GEMMs: the residual epilogues emit x as a packed bf16 copy beside the
 // fp32 rows) and applies a folded LayerNorm in the epilogue: rstd (acc - mean s_n) + c_n with s_n = sum_k of the packed
 // gamma o W_n.
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2>
+// ACT / rg_lo / rgs -- row-narrow teams (h2_stackn_kernel: launches that leave most of the chip idle, e.g. the reference's shipped
+// call shape of 256 frames x 2 views = 8 row tiles): a workgroup owns only the row groups rg_lo .. rg_lo + rgs - 1 (16 or 32
+// rows) of its 64-row tile, so 4 / rgs times as many workgroups share the launch.  The waves of those row groups run the phase
+// exactly as in the full-tile form (ACT = true: same fragments, same product order, same epilogue -- the poses are bitwise the
+// same); the waves of the other row groups (ACT = false) only keep their share of the W pieces moving and meet the barriers.
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2, bool ACT = true>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
-                                         unsigned* chain, unsigned chain_need, bool arrive = true) {
+                                         unsigned* chain, unsigned chain_need, bool arrive = true, int rg_lo = 0, int rgs = 4) {
+    static_assert(ACT || (RT == 1 && CHAIN), "loader-only waves exist in the row-narrow stack only");
     constexpr int ABYTES = RT * 4 * H2_RG;       // A bytes per stage
     constexpr int STAGE = ABYTES + H2_W;
     constexpr int NST = RT == 1 ? H2_NST : 4;
@@ -290,7 +301,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // the HEAD of a stage, bring ALL A pieces (four each) and the waves 0..3, which request behind their product rows, W only:
     // the A strips come from beyond L2 (their producers store write-through) and need the longer flight
     constexpr bool AB = H2_R2_AB && RT == 2 && NP == 1;
-    constexpr bool HAS_A = AB ? !LEAD : LEAD;
+    constexpr bool HAS_A = (AB ? !LEAD : LEAD) && ACT;
     constexpr bool WT = CHAIN;
     const int lane = tid & 63;
     const int rg = wave & 3;
@@ -674,9 +685,11 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        read_a(0, A0);
-        if (RAWX) finish_a(A0);
-        read_b(0, B0);
+        if constexpr (ACT) {
+            read_a(0, A0);
+            if (RAWX) finish_a(A0);
+            read_b(0, B0);
+        }
     }
     const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_vm = 0, t_bar = 0, t_mm = 0;      // bench-only sums: counted DMA wait, lgkm + barrier, the MFMA rows of a stage
@@ -739,13 +752,15 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         };
         auto loads = [&]() {
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
+            if constexpr (ACT) {
+                if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+                rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
+            }
             // the requested stage t + DIST has the pass (g + DIST) mod NPASS (= g when DIST = NST) and carries A when that is 0
             constexpr int gr = (g0 + DIST) % NPASS;
             if (RF && !(H2_ABL & 2))
                 refill_fast(std::integral_constant<int, gr>{}, std::integral_constant<bool, gr == 0>{}, P2 ? slot_p : slot_c);
-            if (REM == 4) epilogue_operands();
+            if (REM == 4 && ACT) epilogue_operands();
         };
         // The two waves of a SIMD run out of phase: the waves 0..3 multiply first and load afterwards, the waves 4..7 the other
         // way round -- while one wave of a SIMD sits in its DMA requests and fragment reads, the other one has the matrix pipe.
@@ -758,7 +773,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         unsigned long long m0 = 0;
         if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
-        if constexpr (NP == 2) {
+        if constexpr (!ACT) {
+        } else if constexpr (NP == 2) {
             mfma_row(accp, a_cur, 1, b_cur, 0);         // lo . hi
             mfma_row(accp, a_cur, 0, b_cur, 1);         // hi . lo
             mfma_row(accp, a_cur, 0, b_cur, 0);         // hi . hi
@@ -769,7 +785,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         __builtin_amdgcn_sched_barrier(0);
         if (H2_DBG && a.dbg) t_mm += __builtin_amdgcn_s_memtime() - m0;
         if (LEAD) loads();
-        if (RAWX && more && next_has_a && !(H2_ABL & 16)) finish_a(a_nxt);
+        if (RAWX && ACT && more && next_has_a && !(H2_ABL & 16)) finish_a(a_nxt);
         __builtin_amdgcn_sched_barrier(0);
         slot_c = slot_n;
     };
@@ -871,6 +887,28 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     };
     unsigned long long t_st = 0;
 
+    if constexpr (!ACT) {
+        // loader-only wave of a row-narrow workgroup: nothing to compute or store; it meets the barriers of the epilogue below
+        // (and lends its threads to the LDS form of the attention, which every thread of the workgroup walks)
+        if constexpr (EPI == H2_EPI_ATT) {
+            if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
+                __syncthreads();
+                __syncthreads();
+            } else {
+                float* Tt = reinterpret_cast<float*>(smem);
+                __syncthreads();
+                __syncthreads();
+                h2_attention<NP>(WT, Tt, Tt + BM * H2_ATT_TS, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm, n0 / BN, Dq,
+                                 reinterpret_cast<const float*>(smem + H2_VEC) + VSO, rg_lo, rgs);
+            }
+        } else if constexpr (EPI == H2_EPI_RES) {
+            if (a.stats_out) {
+                __syncthreads();
+                __syncthreads();
+                __syncthreads();
+            }
+        }
+    } else {
     if constexpr (EPI == H2_EPI_ATT) {
       if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
         // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS (x3_gemm.hip): a
@@ -989,7 +1027,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 }
             __syncthreads();
             h2_attention<NP>(WT, Tt, SC, tid, a.att_ntok, a.att_hd, a.rpt / a.att_ntok, a.C2, tm * RT + rt, n0 / BN, Dq,
-                             reinterpret_cast<const float*>(smem + H2_VEC) + VSO);
+                             reinterpret_cast<const float*>(smem + H2_VEC) + VSO, rg_lo, rgs);
         }
       }
     } else {
@@ -1093,6 +1131,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         }
     }
+    }
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1144,6 +1183,7 @@ struct H2StackArgs {
     float *x, *stats;
     unsigned* counters;          // one per row tile (+ the error word), zeroed before the launch
     int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
+    int rgs;                     // row-narrow stack: row groups (16 rows) per workgroup, 1 or 2 (else 4 = whole tiles)
     float eps;
     unsigned long long* dbg;
     unsigned *err_ws, *err_host;
@@ -1386,6 +1426,77 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
     }
 }
 
+// The stack for launches that would leave most of the chip idle (fewer 64-row tiles x column groups than compute units: the
+// reference's shipped call shape TEST.BATCH_SIZE 256 x 2 views = 8 tiles = 32 workgroups of h2_stack_kernel): ROW-NARROW teams.
+// A 64-row tile is split into 4 / rgs sub-tiles of rgs row groups (16 or 32 rows); a team of G workgroups walks ONE sub-tile
+// through every phase, so 4 / rgs times as many compute units stream the same weights, each for a quarter / half of the rows.
+// Inside a workgroup the waves keep their full-tile roles: wave w works on row group w & 3 if the workgroup owns it (h2_phase
+// ACT = true: the very code of h2_stack_kernel, so the poses are bitwise the same), otherwise it only requests its W pieces and
+// meets the barriers (ACT = false).  Column groups are untouched: heads stay whole, the in-register attention is unchanged.
+template <int NP>
+__global__ __launch_bounds__(512, 2) void h2_stackn_kernel(const H2StackArgs s) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = s.G, D = s.D;
+    int team, tn;
+    {
+        const int b = blockIdx.x;
+        team = (b & 7) + 8 * ((b >> 3) / G);
+        tn = (b >> 3) % G;
+        if (team >= s.n_teams) return;
+    }
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    __syncthreads();
+    const int rs = 4 / s.rgs;                    // sub-tiles per row tile
+    const int n_units = s.n_tiles * rs;
+    for (int unit0 = team; unit0 < n_units; unit0 += s.n_teams) {
+        unsigned need = 0;
+        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            int wvp = wave_s, unit = unit0, tnp = tn;
+            asm volatile("" : "+s"(wvp), "+s"(unit), "+s"(tnp));
+            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(tidp));
+            const int wv = wvp;
+            const int tile = unit / rs, rg_lo = (unit - tile * rs) * s.rgs;
+            const bool act = (wv & 3) >= rg_lo && (wv & 3) < rg_lo + s.rgs;
+            unsigned* ctr = s.counters + H2_CTR_PER_TILE * tile + rg_lo;      // one arrival counter per sub-tile
+            const char* const* w = s.w[ph >> 2];
+            bool ok = true;
+            if (s.inject > 0 && ph == s.inject && unit == 0 && tnp == 0) return;     // fault injection (test hook)
+#define H2N_PHASE(EPI, LNF, NPASS)                                                                                                          \
+    do {                                                                                                                                    \
+        if (wv < 4) ok = act ? h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, s.rgs)   \
+                             : h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, false>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, s.rgs); \
+        else if (wv < 6) ok = act ? h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, s.rgs)   \
+                                  : h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, false>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, s.rgs); \
+        else ok = act ? h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC2, 1, NP, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, s.rgs)   \
+                      : h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC2, 1, NP, false>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, s.rgs); \
+    } while (0)
+            switch (ph & 3) {
+                case 0: {
+                    const H2Args a = h2_args_qkv<NP>(s, w[0], D, G);
+                    H2N_PHASE(H2_EPI_ATT, true, 3);
+                    break;
+                }
+                case 2: {
+                    const H2Args a = h2_args_fc1<NP>(s, w[2], D, G);
+                    H2N_PHASE(H2_EPI_GELU, true, 2);
+                    break;
+                }
+                default: {
+                    const bool fc2 = (ph & 3) == 3;
+                    const H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G);
+                    H2N_PHASE(H2_EPI_RES, false, 1);
+                    break;
+                }
+            }
+#undef H2N_PHASE
+            if (!ok) return;
+        }
+    }
+}
+
 // the kernel of the pair form: six steps per block application for fp16x2 operands, every phase on pairs for bf16 operands
 template <int NP>
 static auto h2_pair_kernel() -> void (*)(const H2StackArgs) {
@@ -1397,6 +1508,9 @@ static auto h2_pair_kernel() -> void (*)(const H2StackArgs) {
 unsigned long long* h2_debug_buffer();       // h2_gemm.hip (A/B switches and test hooks shared by both engines)
 int h2_spin_log2();
 int h2_row_tiles();
+int h2_narrow_mode();
+struct H2StackArgs;
+int launch_h2n_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2n_gemm.hip: the row-narrow stack kernel
 
 // The whole block stack in one launch (both engines).  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands of engine NP;
 // counters: n_tiles arrival counters + 1 error word, zeroed by the caller (the entry kernel of the engine); x16: NP = 1 only.
@@ -1444,13 +1558,27 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     // four, too shallow for the flight time of the A strips, and a wave's product rows and its requests do not overlap
     const bool pairs = force == 2 || (force == 0 && NP == 2 && a.n_tiles > cap);
     const int n_units = pairs ? (a.n_tiles + 1) / 2 : a.n_tiles;
-    a.n_teams = n_units < cap ? n_units : cap;
+    // row-narrow teams (fp16x2 operands): when whole-tile teams would leave compute units idle, a tile is split into sub-tiles of
+    // 16 or 32 rows (h2_stackn_kernel) -- the narrowest form that still gives every workgroup a compute unit of its own; by the
+    // shape of the launch only, and bitwise the same poses.  Sequences must not straddle row groups: 16 a multiple of n_tok.
+    a.rgs = 4;
+    if (NP == 2 && !pairs && a.rpt == BM && (16 % n_tok) == 0) {
+        const int nm = h2_narrow_mode(), cus = resident[dev].load();
+        if (nm == 3) a.rgs = 1;
+        else if (nm == 2) a.rgs = 2;
+        else if (nm == 0 && force == 0) {
+            if (a.n_tiles * 4 * a.G <= cus) a.rgs = 1;
+            else if (a.n_tiles * 2 * a.G <= cus) a.rgs = 2;
+        }
+    }
+    const int n_units_n = a.rgs == 4 ? n_units : a.n_tiles * (4 / a.rgs);
+    a.n_teams = n_units_n < cap ? n_units_n : cap;
     if (a.n_teams * a.G > H2_MAX_WGS) a.n_teams = H2_MAX_WGS / a.G;
     a.n_apps = n_apps;
     a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
     a.eps = eps;
     a.dbg = h2_debug_buffer();
-    a.err_ws = counters + a.n_tiles;
+    a.err_ws = counters + H2_CTR_PER_TILE * a.n_tiles;
     a.err_host = device_error_word(dev);
     a.spin_log2 = h2_spin_log2();
     a.inject = take_fault_injection();
@@ -1468,9 +1596,11 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     int rc;
     {
         ProfScope prof(MPL_K_GEMM, s);
-        if (pairs) hipLaunchKernelGGL(h2_pair_kernel<NP>(), dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
+        rc = MPL_OK;
+        if (a.rgs != 4) rc = launch_h2n_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
+        else if (pairs) hipLaunchKernelGGL(h2_pair_kernel<NP>(), dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         else hipLaunchKernelGGL(h2_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
-        rc = hip_check_launch();
+        if (rc == MPL_OK) rc = hip_check_launch();
     }
     if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;
     return rc;

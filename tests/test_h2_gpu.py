@@ -305,6 +305,36 @@ def test_shipped_call_shape_b256_v2():
     _assert_close(out, ref, "B=256 V=2 vs fp64 oracle")
 
 
+@pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 256), ("chosen_v4_b8_l12", 256), ("chosen_v2_b1_l12", 32), ("chosen_v8_b4_l2", 61),
+                                    ("chosen_v4_b8_l2", 100), ("full_v4_b8_l2", 64), ("chosen_v4_b8_l2", 9), ("chosen_v5_b19_l2", 40)])
+def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
+    """Launches that would leave compute units idle split every 64-row tile into sub-tiles of 16 or 32 rows, one team each
+    (h2_stackn_kernel; VERDICT r4 item 2: the reference's shipped call shape, 256 frames x 2 views, is 8 tiles = 32 workgroups).
+    The waves of a sub-tile run the full-tile code on their row groups, so the poses must be bitwise those of the whole-tile teams:
+    forced both ways and both widths (mpl_x3_stack_mode bits 5, 6) -- ragged tiles, the LDS attention of 8 views, width 1088, and
+    five views (60-row tiles: no narrow form exists, the switch must be a no-op) included."""
+    lib = cabi.load()
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    P, R, Cn = _big_inputs(B, V, 321)
+    outs = {}
+    try:
+        for tag, bits in (("whole", 1 << 5), ("rows32", 2 << 5), ("rows16", 3 << 5), ("auto", 0)):
+            cabi.check(lib.mpl_x3_stack_mode(bits | 8), "stack mode")           # bit 3: the team kernels also at <= 32 rows
+            with torch.no_grad():
+                outs[tag] = m(P, rays=R, centers=Cn)
+            torch.cuda.synchronize()
+    finally:
+        cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+    assert torch.isfinite(outs["whole"]).all()
+    for tag in ("rows32", "rows16", "auto"):
+        assert torch.equal(outs["whole"], outs[tag]), "%s changed results: max |d| = %.3e" % (tag, float((outs["whole"] - outs[tag]).abs().max()))
+    if B <= 100:
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = mpl_oracle.forward(sd, g["flags"], [x.cpu() for x in P], [x.cpu() for x in R], [x.cpu() for x in Cn], dtype=torch.float64)
+        _assert_close(outs["rows16"], ref, name + " 16-row teams vs fp64 oracle")
+
+
 @pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 512), ("chosen_v4_b8_l2", 48), ("chosen_v4_b8_l2", 1), ("full_v4_b8_l2", 200),
                                     ("chosen_v5_b19_l2", 100), ("chosen_v31_b2_l12", 9), ("chosen_v8_b4_l2", 37), ("chosen_v2_b1_l12", 97)])
 def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
