@@ -166,7 +166,7 @@ H2Ws carve_h2_ws(void* base, size_t M, size_t D, int rpt) {
     w.att2 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)D, rpt)));
     w.hid2 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)(2 * D), rpt)));
     w.stats = reinterpret_cast<float*>(take((M + 64) * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
-    w.counters = reinterpret_cast<unsigned*>(take((H2_CTR_PER_TILE * ((M + rpt - 1) / rpt) + 64) * sizeof(unsigned)));
+    w.counters = reinterpret_cast<unsigned*>(take((h2_err_index((int)((M + rpt - 1) / rpt)) + 64) * sizeof(unsigned)));
     w.bytes = off;
     return w;
 }
@@ -193,7 +193,7 @@ B1Ws carve_b1_ws(void* base, size_t M, size_t D, int rpt) {
     w.att1 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)D, rpt, 1)));
     w.hid1 = reinterpret_cast<unsigned short*>(take(h2_act_bytes((int)M, (int)(2 * D), rpt, 1)));
     w.stats = reinterpret_cast<float*>(take((M + 64) * 2 * (size_t)ln_stat_slices((int)D) * sizeof(float)));
-    w.counters = reinterpret_cast<unsigned*>(take((H2_CTR_PER_TILE * ((M + rpt - 1) / rpt) + 64) * sizeof(unsigned)));
+    w.counters = reinterpret_cast<unsigned*>(take((h2_err_index((int)((M + rpt - 1) / rpt)) + 64) * sizeof(unsigned)));
     w.bytes = off;
     return w;
 }
@@ -205,7 +205,7 @@ int block_stack_b1(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     const B1Ws w = carve_b1_ws(ws, (size_t)M, (size_t)D, rpt);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const int n_tiles = (M + rpt - 1) / rpt;
-    if (err_ws) *err_ws = w.counters + H2_CTR_PER_TILE * n_tiles;
+    if (err_ws) *err_ws = w.counters + h2_err_index(n_tiles);
     int rc;
     const unsigned short* ops[MPL_MAX_APPS * 4];
     for (int a = 0; a < n_apps; ++a) {
@@ -213,7 +213,7 @@ int block_stack_b1(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
         for (int i = 0; i < 4; ++i) ops[4 * a + i] = (&b.qkv_w16)[i];
     }
     // entry of the stack, one launch: the rows as packed bf16 operand, their LayerNorm slice partials, zeroed counters + error word
-    if ((rc = launch_b1_entry(x, M, D, D, rpt, w.x16, w.stats, w.counters, H2_CTR_PER_TILE * n_tiles + 1, s))) return rc;
+    if ((rc = launch_b1_entry(x, M, D, D, rpt, w.x16, w.stats, w.counters, h2_err_index(n_tiles) + 1, s))) return rc;
     if (!g_x3_per_gemm.load(std::memory_order_relaxed))
         return launch_b1_stack(x, w.x16, M, D, n_tok, H, ops, n_apps, w.att1, w.hid1, w.stats, w.counters, eps, g_x3_stop.load(), s);
     // A/B switch (mpl_x3_stack_mode): the same phases as one launch per GEMM
@@ -244,7 +244,7 @@ int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     const H2Ws w = carve_h2_ws(ws, (size_t)M, (size_t)D, rpt);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
     const int n_tiles = (M + rpt - 1) / rpt;
-    if (err_ws) *err_ws = w.counters + H2_CTR_PER_TILE * n_tiles;
+    if (err_ws) *err_ws = w.counters + h2_err_index(n_tiles);
     int rc;
     const unsigned short* ops[MPL_MAX_APPS * 4];
     for (int a = 0; a < n_apps; ++a) {
@@ -253,7 +253,7 @@ int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     }
     // entry of the stack, one launch: LayerNorm slice partials of the incoming rows, zeroed arrival counters + error word, and
     // the check that proj / fc2 were packed against the static scales of their producers (mpl_pack_h2_scaled)
-    if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, H2_CTR_PER_TILE * n_tiles + 1, ops, n_apps, s))) return rc;
+    if ((rc = launch_h2_entry(x, M, D, D, w.stats, w.counters, h2_err_index(n_tiles) + 1, ops, n_apps, s))) return rc;
     if (!g_x3_per_gemm.load(std::memory_order_relaxed))
         return launch_h2_stack(x, M, D, n_tok, H, ops, n_apps, w.att2, w.hid2, w.stats, w.counters, eps, g_x3_stop.load(), s);
     // A/B switch (mpl_x3_stack_mode): the same phases as one launch per GEMM
@@ -568,6 +568,7 @@ int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const 
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);
+    h2_set_write_through((one_launch_per_gemm >> 7) & 1);  // bit 7: write-through hand-off stores also for teams that sit on one XCD
     h2_set_narrow((one_launch_per_gemm >> 5) & 3);         // bits 5, 6: row-narrow teams: 0 = by shape, 1 = never, 2 / 3 = 32- / 16-row workgroups where legal
     h2_set_row_tiles((one_launch_per_gemm >> 1) & 3);      // bits 1, 2: 0 = by shape, 1 / 2 = force the one- / two-tile stage
     sm_stack_disable((one_launch_per_gemm >> 3) & 1);      // bit 3: no small-batch engine (the team kernels for every batch)

@@ -140,6 +140,9 @@ void h2_set_row_tiles(int rt);             // A/B switch of the block stack: 0 b
 void h2_set_narrow(int mode);              // row-narrow teams: 0 by shape, 1 never, 2 / 3 = 32- / 16-row workgroups where legal
 // arrival counters of a stack call: one per (row tile, 16-row group) -- the row-narrow teams synchronise per sub-tile -- then the error word
 constexpr int H2_CTR_PER_TILE = 4;
+constexpr int H2_XCC_WORDS = 256;          // behind the arrival counters: one word per team, the set of XCDs its workgroups run on
+inline int h2_err_index(int n_tiles) { return H2_CTR_PER_TILE * n_tiles + H2_XCC_WORDS; }      // the error word of the call (the last word)
+void h2_set_write_through(int always);     // A/B switch: 1 = write-through hand-off stores whatever the placement of a team
 // The persistent block-stack kernels (h2_stack_kernel and its pair forms, sm_stack_kernel) need every workgroup resident: the library
 // serialises its own launches of them per device, whatever stream they are on -- each launch waits for the event recorded
 // behind the previous one (api.hip).  The event exists from the first call (waiting on a never-recorded event is a no-op).

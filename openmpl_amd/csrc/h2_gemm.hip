@@ -366,6 +366,9 @@ int h2_row_tiles() { return g_h2_rt.load(); }
 static std::atomic<int> g_h2_narrow{0};
 void h2_set_narrow(int mode) { g_h2_narrow.store(mode & 3); }
 int h2_narrow_mode() { return g_h2_narrow.load(); }
+static std::atomic<int> g_h2_wt_always{getenv("MPL_WRITE_THROUGH") != nullptr ? 1 : 0};
+void h2_set_write_through(int always) { g_h2_wt_always.store(always & 1); }
+int h2_write_through_always() { return g_h2_wt_always.load(); }
 
 
 template <int EPI, bool LNF, int NPASS>

@@ -115,6 +115,8 @@ struct H2Args {
     unsigned* err_ws;        // chain mode: see x3_gemm.hip X3Args
     unsigned* err_host;
     int spin_log2;
+    int plain;               // chain mode: the team sits on ONE XCD (h2_team_placement): hand-off stores stay in its L2 (plain
+                             // stores) instead of writing through; consumers read past their L1 either way
 };
 
 enum { H2_EPI_BIAS = 0, H2_EPI_GELU = 1, H2_EPI_RES = 2, H2_EPI_ATT = 3 };
@@ -302,7 +304,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // the A strips come from beyond L2 (their producers store write-through) and need the longer flight
     constexpr bool AB = H2_R2_AB && RT == 2 && NP == 1;
     constexpr bool HAS_A = (AB ? !LEAD : LEAD) && ACT;
-    constexpr bool WT = CHAIN;
+    const bool WT = CHAIN && !a.plain;
     const int lane = tid & 63;
     const int rg = wave & 3;
     const int li = lane & 15, kq = lane >> 4;
@@ -1183,6 +1185,8 @@ struct H2StackArgs {
     float *x, *stats;
     unsigned* counters;          // one per row tile (+ the error word), zeroed before the launch
     int M, D, n_tok, heads, rpt, n_tiles, n_teams, G, n_apps, n_phases;
+    unsigned* xcc;               // one word per team: bit x set = a workgroup of the team runs on XCD x (h2_team_placement)
+    int plain_ok;                // 0: write-through hand-off stores whatever the placement (A/B switch)
     int rgs;                     // row-narrow stack: row groups (16 rows) per workgroup, 1 or 2 (else 4 = whole tiles)
     float eps;
     unsigned long long* dbg;
@@ -1200,28 +1204,48 @@ __device__ __forceinline__ const float* h2_trailer(const char* w2, int N, int K)
 // H2Args of the four GEMMs of a block application inside a stack.  NP = 2: x (fp32) is the A operand of qkv / fc1, the
 // attention / GELU outputs leave under the static scales so.  NP = 1: x16 is the A operand, proj / fc2 rewrite it beside x.
 template <int NP>
-__device__ __forceinline__ H2Args h2_args_qkv(const H2StackArgs& s, const char* w, int D, int G) {
+__device__ __forceinline__ H2Args h2_args_qkv(const H2StackArgs& s, const char* w, int D, int G, int plain) {
     const float* v = h2_trailer<NP>(w, 3 * D, D);
     return H2Args{NP == 1 ? s.x16 : nullptr, NP == 1 ? nullptr : s.x, D, w, v, v + 3 * D, s.stats, nullptr, NP == 1 ? nullptr : v + 12 * D,
                   nullptr, 0, nullptr, 0, s.att2, nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg,
-                  s.err_ws, s.err_host, s.spin_log2};
+                  s.err_ws, s.err_host, s.spin_log2, plain};
 }
 template <int NP>
-__device__ __forceinline__ H2Args h2_args_fc1(const H2StackArgs& s, const char* w, int D, int G) {
+__device__ __forceinline__ H2Args h2_args_fc1(const H2StackArgs& s, const char* w, int D, int G, int plain) {
     const float* v = h2_trailer<NP>(w, 2 * D, D);
     return H2Args{NP == 1 ? s.x16 : nullptr, NP == 1 ? nullptr : s.x, D, w, v, v + 2 * D, s.stats, nullptr, NP == 1 ? nullptr : v + 8 * D,
                   nullptr, 0, nullptr, 0, s.hid2, nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host,
-                  s.spin_log2};
+                  s.spin_log2, plain};
 }
 // proj (A = attention output, K = D) and fc2 (A = hidden, K = 2D): one body for both.  NP = 2: the operand arrives under the
 // producer's per-column static scales, which these weights were packed against (mpl_pack_h2_scaled; h2_entry_kernel checks
 // the fingerprints): nothing to take out here
 template <int NP>
-__device__ __forceinline__ H2Args h2_args_res(const H2StackArgs& s, const char* w, bool fc2, int D, int G) {
+__device__ __forceinline__ H2Args h2_args_res(const H2StackArgs& s, const char* w, bool fc2, int D, int G, int plain) {
     const int K = fc2 ? 2 * D : D;
     const float* v = h2_trailer<NP>(w, D, K);
     return H2Args{fc2 ? s.hid2 : s.att2, nullptr, 0, w, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, NP == 1 ? s.x16 : nullptr,
-                  s.stats, s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                  s.stats, s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2, plain};
+}
+
+// Where a team runs.  The hand-off stores of a team are write-through by default (sc0 sc1: placement-independent, but the line
+// leaves the L2 and every consumer fetches it across the fabric: tools/h2_probe.hip, 42 against 24 cycles per KiB).  The XCDs'
+// L2s are coherent for the compute units of ONE XCD, so a team whose workgroups all sit on one XCD can keep its operands there:
+// plain stores, consumers read past their L1 (sc1) as before.  Nothing is assumed about placement: every workgroup publishes the
+// XCD it actually runs on (HW_REG_XCC_ID) in a word of its team at the start of the kernel; once a workgroup has seen all its
+// partners arrive at the end of the first phase -- each arrival is ordered behind that workgroup's publication -- the word is
+// complete, and from the third phase on the team stores plain iff exactly one bit is set.  (The blocks of a team are b, b + 8,
+// ...: on this part they land on XCD b mod 8 and the answer is yes; elsewhere the kernel simply keeps writing through.)
+__device__ __forceinline__ void h2_publish_xcd(const H2StackArgs& s, int team, int tid) {
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(s.xcc + team, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ int h2_team_on_one_xcd(const H2StackArgs& s, int team) {
+    const unsigned m = __hip_atomic_load(s.xcc + team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (s.plain_ok && m != 0u && (m & (m - 1u)) == 0u) ? 1 : 0;
 }
 
 template <int NP>
@@ -1238,10 +1262,16 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
         if (team >= s.n_teams) return;
     }
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    h2_publish_xcd(s, team, tid);
+    int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
     __syncthreads();
     for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
         unsigned need = 0;
         for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            if (!seen && ph >= 2) {       // the proj phase has seen every partner arrive: the team's placement word is complete
+                plain = __builtin_amdgcn_readfirstlane(h2_team_on_one_xcd(s, team));
+                seen = 1;
+            }
             // the thread id is rebuilt from the wave index (a scalar) and the lane number every phase: kept in a register
             // across the phases it was the one value the 256-register budget spilled to scratch
             int wvp = wave_s, tile = tile0, tnp = tn;
@@ -1255,14 +1285,14 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
             if (s.inject > 0 && ph == s.inject && tile == 0 && tnp == 0) return;     // fault injection (test hook)
             switch (ph & 3) {
                 case 0: {   // x = x + proj(attn(qkv(norm1(x))))   (Block.forward :84-90)
-                    const H2Args a = h2_args_qkv<NP>(s, w[0], D, G);
+                    H2Args a = h2_args_qkv<NP>(s, w[0], D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0, 1, NP>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC2, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     break;
                 }
                 case 2: {   // x = x + fc2(gelu(fc1(norm2(x))))    (Block.forward :91, Mlp.forward :31-37)
-                    const H2Args a = h2_args_fc1<NP>(s, w[2], D, G);
+                    H2Args a = h2_args_fc1<NP>(s, w[2], D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, H2_WC0, 1, NP>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC1, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_WC2, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
@@ -1270,7 +1300,7 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
                 }
                 default: {
                     const bool fc2 = (ph & 3) == 3;
-                    const H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G);
+                    H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_WC0, 1, NP>(a, smem, tidp, wv, 0, tile, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC1, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_WC2, 1, NP>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need);
@@ -1300,11 +1330,17 @@ __global__ __launch_bounds__(512, 2) void h2_stackp_kernel(const H2StackArgs s) 
         if (team >= s.n_teams) return;
     }
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    h2_publish_xcd(s, team, tid);
+    int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
     __syncthreads();
     const int n_pairs = (s.n_tiles + 1) >> 1;
     for (int pair0 = team; pair0 < n_pairs; pair0 += s.n_teams) {
         unsigned need = 0;
         for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            if (!seen && ph >= 2) {       // the proj phase has seen every partner arrive: the team's placement word is complete
+                plain = __builtin_amdgcn_readfirstlane(h2_team_on_one_xcd(s, team));
+                seen = 1;
+            }
             int wvp = wave_s, pair = pair0, tnp = tn;
             asm volatile("" : "+s"(wvp), "+s"(pair), "+s"(tnp));
             int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1316,14 +1352,14 @@ __global__ __launch_bounds__(512, 2) void h2_stackp_kernel(const H2StackArgs s) 
             if (s.inject > 0 && ph == s.inject && pair == 0 && tnp == 0) return;     // fault injection (test hook)
             switch (ph & 3) {
                 case 0: {
-                    const H2Args a = h2_args_qkv<NP>(s, w[0], D, G);
+                    H2Args a = h2_args_qkv<NP>(s, w[0], D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_RP_WC0, 2, NP>(a, smem, tidp, wv, 0, pair, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_RP_WC1, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_RP_WC2, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
                     break;
                 }
                 case 2: {
-                    const H2Args a = h2_args_fc1<NP>(s, w[2], D, G);
+                    H2Args a = h2_args_fc1<NP>(s, w[2], D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 2, H2_T0, true, H2_RP_WC0, 2, NP>(a, smem, tidp, wv, 0, pair, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_RP_WC1, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_GELU, true, 2, NT - H2_T0, true, H2_RP_WC2, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
@@ -1331,7 +1367,7 @@ __global__ __launch_bounds__(512, 2) void h2_stackp_kernel(const H2StackArgs s) 
                 }
                 default: {
                     const bool fc2 = (ph & 3) == 3;
-                    const H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G);
+                    H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G, plain);
                     if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_RP_WC0, 2, NP>(a, smem, tidp, wv, 0, pair, tnp, ctr, need);
                     else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_RP_WC1, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
                     else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_RP_WC2, 2, NP>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, need);
@@ -1363,6 +1399,8 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
         if (team >= s.n_teams) return;
     }
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    h2_publish_xcd(s, team, tid);
+    int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
     __syncthreads();
     auto vecs = [&](const char* w2, int N, int K) -> const float* {
         return reinterpret_cast<const float*>(w2 + (size_t)(N / BN) * (K / BK) * H2_W);
@@ -1374,6 +1412,10 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
         // first / second column group, fc2.  A step that has a partner step waits for the team only in the first and arrives
         // only in the second of the two.
         for (int e = 0; e < 6 * s.n_apps; ++e) {
+            if (!seen && e >= 3) {        // the proj step has seen every partner arrive: the team's placement word is complete
+                plain = __builtin_amdgcn_readfirstlane(h2_team_on_one_xcd(s, team));
+                seen = 1;
+            }
             int wvp = wave_s, pair = pair0, tnp = tn;
             asm volatile("" : "+s"(wvp), "+s"(pair), "+s"(tnp));
             int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1395,7 +1437,7 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
                 const float* v = vecs(w[0], 3 * D, D);
                 const H2Args a{nullptr, s.x, D, w[0], v, v + 3 * D, s.stats, nullptr, v + 12 * D, nullptr, 0, nullptr, 0, s.att2,
                                nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg, s.err_ws, s.err_host,
-                               s.spin_log2};
+                               s.spin_log2, plain};
                 const int tile = 2 * pair + k;
                 if (wv < 4) ok = h2_phase<H2_EPI_ATT, true, 3, H2_T0, true, H2_WC0>(a, smem, tidp, wv, 0, tile, tnp, ctr, nd, arr);
                 else if (wv < 6) ok = h2_phase<H2_EPI_ATT, true, 3, NT - H2_T0, true, H2_WC1>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, nd, arr);
@@ -1404,7 +1446,7 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
                                              // for two row tiles do not fit the register file beside the double-buffered fragments)
                 const float* v = vecs(w[2], 2 * D, D);
                 const H2Args a{nullptr, s.x, D, w[2], v, v + 2 * D, s.stats, nullptr, v + 8 * D, nullptr, 0, nullptr, 0, s.hid2,
-                               nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                               nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2, plain};
                 const int cg = 2 * tnp + (k - 3);
                 if (wv < 4) ok = h2_phase<H2_EPI_GELU, true, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, cg, ctr, nd, arr);
                 else if (wv < 6) ok = h2_phase<H2_EPI_GELU, true, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, cg, ctr, nd, arr);
@@ -1415,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
                 const char* w2 = fc2 ? w[3] : w[1];
                 const float* v = vecs(w2, D, K);
                 const H2Args a{fc2 ? s.hid2 : s.att2, nullptr, 0, w2, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, nullptr, s.stats,
-                               s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2};
+                               s.M, D, K, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host, s.spin_log2, plain};
                 if (wv < 4) ok = h2_phase<H2_EPI_RES, false, 1, H2_T0, true, H2_R2_WC0, 2>(a, smem, tidp, wv, 0, pair, tnp, ctr, nd, arr);
                 else if (wv < 6) ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC1, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
                 else ok = h2_phase<H2_EPI_RES, false, 1, NT - H2_T0, true, H2_R2_WC2, 2>(a, smem, tidp, wv, H2_T0, pair, tnp, ctr, nd, arr);
@@ -1447,12 +1489,18 @@ __global__ __launch_bounds__(512, 2) void h2_stackn_kernel(const H2StackArgs s) 
         if (team >= s.n_teams) return;
     }
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    h2_publish_xcd(s, team, tid);
+    int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
     __syncthreads();
     const int rs = 4 / s.rgs;                    // sub-tiles per row tile
     const int n_units = s.n_tiles * rs;
     for (int unit0 = team; unit0 < n_units; unit0 += s.n_teams) {
         unsigned need = 0;
         for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            if (!seen && ph >= 2) {       // the proj phase has seen every partner arrive: the team's placement word is complete
+                plain = __builtin_amdgcn_readfirstlane(h2_team_on_one_xcd(s, team));
+                seen = 1;
+            }
             int wvp = wave_s, unit = unit0, tnp = tn;
             asm volatile("" : "+s"(wvp), "+s"(unit), "+s"(tnp));
             int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1475,18 +1523,18 @@ __global__ __launch_bounds__(512, 2) void h2_stackn_kernel(const H2StackArgs s) 
     } while (0)
             switch (ph & 3) {
                 case 0: {
-                    const H2Args a = h2_args_qkv<NP>(s, w[0], D, G);
+                    H2Args a = h2_args_qkv<NP>(s, w[0], D, G, plain);
                     H2N_PHASE(H2_EPI_ATT, true, 3);
                     break;
                 }
                 case 2: {
-                    const H2Args a = h2_args_fc1<NP>(s, w[2], D, G);
+                    H2Args a = h2_args_fc1<NP>(s, w[2], D, G, plain);
                     H2N_PHASE(H2_EPI_GELU, true, 2);
                     break;
                 }
                 default: {
                     const bool fc2 = (ph & 3) == 3;
-                    const H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G);
+                    H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G, plain);
                     H2N_PHASE(H2_EPI_RES, false, 1);
                     break;
                 }
@@ -1509,6 +1557,7 @@ unsigned long long* h2_debug_buffer();       // h2_gemm.hip (A/B switches and te
 int h2_spin_log2();
 int h2_row_tiles();
 int h2_narrow_mode();
+int h2_write_through_always();
 struct H2StackArgs;
 int launch_h2n_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2n_gemm.hip: the row-narrow stack kernel
 
@@ -1578,7 +1627,9 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
     a.eps = eps;
     a.dbg = h2_debug_buffer();
-    a.err_ws = counters + H2_CTR_PER_TILE * a.n_tiles;
+    a.err_ws = counters + h2_err_index(a.n_tiles);
+    a.xcc = counters + H2_CTR_PER_TILE * a.n_tiles;
+    a.plain_ok = h2_write_through_always() ? 0 : 1;
     a.err_host = device_error_word(dev);
     a.spin_log2 = h2_spin_log2();
     a.inject = take_fault_injection();
