@@ -278,6 +278,11 @@ __device__ __forceinline__ void h2_attention(bool WT, float* T, float* SC, int t
 // rows) of its 64-row tile, so 4 / rgs times as many workgroups share the launch.  The waves of those row groups run the phase
 // exactly as in the full-tile form (ACT = true: same fragments, same product order, same epilogue -- the poses are bitwise the
 // same); the waves of the other row groups (ACT = false) only keep their share of the W pieces moving and meet the barriers.
+// the attention of the qkv phase runs in registers (a sequence = 2, 4 or 8 lanes of a 16-row group) for these shapes; else in LDS
+__device__ __forceinline__ bool h2_att_in_registers(int ntok, int hd, int rpt) {
+    return (ntok == 2 || ntok == 4 || ntok == 8) && (hd == 68 || hd == BN) && rpt == BM;
+}
+
 template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2, bool ACT = true>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need, bool arrive = true, int rg_lo = 0, int rgs = 4) {
@@ -893,7 +898,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         // loader-only wave of a row-narrow workgroup: nothing to compute or store; it meets the barriers of the epilogue below
         // (and lends its threads to the LDS form of the attention, which every thread of the workgroup walks)
         if constexpr (EPI == H2_EPI_ATT) {
-            if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
+            if (h2_att_in_registers(a.att_ntok, a.att_hd, a.rpt)) {
                 __syncthreads();
                 __syncthreads();
             } else {
@@ -912,7 +917,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
     } else {
     if constexpr (EPI == H2_EPI_ATT) {
-      if (a.att_ntok == 4 && (a.att_hd == 68 || a.att_hd == BN) && a.rpt == BM) {
+      if (h2_att_in_registers(a.att_ntok, a.att_hd, a.rpt)) {
         // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS (x3_gemm.hip): a
         // sequence is the 4 lanes of a quad, k_j / v_j come by DPP quad broadcast, the q.k sums are reduced over the tiles of
         // the wave, the 4 kq lanes and -- through 2 KiB of LDS -- the two waves of the row group.
@@ -925,76 +930,187 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             value4(1, rt, n, kv[n]);
             value4(2, rt, n, vv[n]);
         }
-        auto quad = [](float x, int j) -> float {
-            const int xi = __builtin_bit_cast(int, x);
-            int r;
-            switch (j) {
-                case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
-                case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
-                case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
-                default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
-            }
-            return __builtin_bit_cast(float, r);
-        };
-        const bool two_heads = a.att_hd == 68;
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float d = qv[n][0] * quad(kv[n][0], j);
-                d = fmaf(qv[n][1], quad(kv[n][1], j), d);
-                d = fmaf(qv[n][2], quad(kv[n][2], j), d);
-                d = fmaf(qv[n][3], quad(kv[n][3], j), d);
-                s0[j] += h1 ? 0.f : d;
-                s1[j] += h1 ? d : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = xor16_add(s0[j]); s0[j] = xor32_add(s0[j]);
-            s1[j] = xor16_add(s1[j]); s1[j] = xor32_add(s1[j]);
-        }
-        float* xs = reinterpret_cast<float*>(smem) + rt * (2 * BM * 8);     // [row tile][2 halves][64 rows][8]
-        const int half = slot0 ? 1 : 0;
-        __syncthreads();                                    // every wave is done reading the last stage
-        if (kq == 0) {
-            st4(xs + (half * BM + row_l) * 8, float4{s0[0], s0[1], s0[2], s0[3]});
-            st4(xs + (half * BM + row_l) * 8 + 4, float4{s1[0], s1[1], s1[2], s1[3]});
-        }
-        __syncthreads();
-        float p0[4], p1[4];
-        {
-            const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
-            const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
-            const float scale = 1.0f / sqrtf((float)a.att_hd);
-            const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
-            const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
-            auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
-                const float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
-                const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
-                const float inv = 1.0f / ((e0 + e1) + (e2 + e3));
-                pr[0] = e0 * inv; pr[1] = e1 * inv; pr[2] = e2 * inv; pr[3] = e3 * inv;
-            };
-            softmax4(t0, p0);
-            softmax4(t1, p1);
-        }
         float ov[NTW][4];
+        // 2 or 8 tokens per sequence (two views: the reference's shipped configuration; eight: BASELINE configs[2]): the same scheme
+        // with the partner i ^ r of token i instead of a broadcast -- quad permutes for r < 4, the half-row mirror (i -> 7 - i) in
+        // front of them for r >= 4 -- so that a lane meets every key / value of its sequence in 1 + (NTK - 1) DPP moves per
+        // value; the probabilities of a row are indexed by r (key token i ^ r), a permutation the softmax does not care about.
+        // (Round 4 ran these shapes through the q | k | v tile in LDS: 20.7 k of the 45.6 k cycles of a qkv phase at 8 views.)
+        auto att_xor = [&](auto ntk_c) {
+            constexpr int NTK = decltype(ntk_c)::value;
+            auto mirror = [](float x) -> float {
+                const int xi = __builtin_bit_cast(int, x);
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, 0x141, 0xf, 0xf, false));      // row_half_mirror
+            };
+            auto xpart = [](float x, float xm, int r) -> float {       // the value lane i ^ r of the 8-lane half row holds
+                const int xi = __builtin_bit_cast(int, x), mi = __builtin_bit_cast(int, xm);
+                int o;
+                switch (r) {
+                    case 0: o = xi; break;
+                    case 1: o = __builtin_amdgcn_update_dpp(xi, xi, 0xb1, 0xf, 0xf, false); break;     // quad_perm [1,0,3,2]
+                    case 2: o = __builtin_amdgcn_update_dpp(xi, xi, 0x4e, 0xf, 0xf, false); break;     // [2,3,0,1]
+                    case 3: o = __builtin_amdgcn_update_dpp(xi, xi, 0x1b, 0xf, 0xf, false); break;     // [3,2,1,0]
+                    case 4: o = __builtin_amdgcn_update_dpp(mi, mi, 0x1b, 0xf, 0xf, false); break;     // (i ^ 7) ^ 3
+                    case 5: o = __builtin_amdgcn_update_dpp(mi, mi, 0x4e, 0xf, 0xf, false); break;     // (i ^ 7) ^ 2
+                    case 6: o = __builtin_amdgcn_update_dpp(mi, mi, 0xb1, 0xf, 0xf, false); break;     // (i ^ 7) ^ 1
+                    default: o = mi; break;                                                            // i ^ 7
+                }
+                return __builtin_bit_cast(float, o);
+            };
+            const bool two_heads = a.att_hd == 68;
+            float s0[NTK], s1[NTK];
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
-            const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
-            float so4[4] = {1.f, 1.f, 1.f, 1.f};
-            if constexpr (NP == 2) oscale4(0, n, so4);
+            for (int r = 0; r < NTK; ++r) s0[r] = s1[r] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float o = pj[0] * quad(vv[n][c], 0);
-                o = fmaf(pj[1], quad(vv[n][c], 1), o);
-                o = fmaf(pj[2], quad(vv[n][c], 2), o);
-                o = fmaf(pj[3], quad(vv[n][c], 3), o);
-                ov[n][c] = o * so4[c];
+            for (int n = 0; n < NTW; ++n) {
+                const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+                float km[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (NTK > 4) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) km[c] = mirror(kv[n][c]);
+                }
+#pragma unroll
+                for (int r = 0; r < NTK; ++r) {
+                    float d = qv[n][0] * xpart(kv[n][0], km[0], r);
+                    d = fmaf(qv[n][1], xpart(kv[n][1], km[1], r), d);
+                    d = fmaf(qv[n][2], xpart(kv[n][2], km[2], r), d);
+                    d = fmaf(qv[n][3], xpart(kv[n][3], km[3], r), d);
+                    s0[r] += h1 ? 0.f : d;
+                    s1[r] += h1 ? d : 0.f;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < NTK; ++r) {
+                s0[r] = xor16_add(s0[r]); s0[r] = xor32_add(s0[r]);
+                s1[r] = xor16_add(s1[r]); s1[r] = xor32_add(s1[r]);
+            }
+            float* xs = reinterpret_cast<float*>(smem) + rt * (2 * BM * 2 * NTK);     // [row tile][2 halves][64 rows][2 heads][NTK]
+            const int half = slot0 ? 1 : 0;
+            __syncthreads();                                    // every wave is done reading the last stage
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < NTK; ++r) {
+                    xs[(half * BM + row_l) * 2 * NTK + r] = s0[r];
+                    xs[(half * BM + row_l) * 2 * NTK + NTK + r] = s1[r];
+                }
+            }
+            __syncthreads();
+            float p0[NTK], p1[NTK];
+            {
+                const float scale = 1.0f / sqrtf((float)a.att_hd);
+                float t0[NTK], t1[NTK];
+#pragma unroll
+                for (int r = 0; r < NTK; ++r) {
+                    t0[r] = (xs[row_l * 2 * NTK + r] + xs[(BM + row_l) * 2 * NTK + r]) * scale;
+                    t1[r] = (xs[row_l * 2 * NTK + NTK + r] + xs[(BM + row_l) * 2 * NTK + NTK + r]) * scale;
+                }
+                auto softmax = [](const float (&t)[NTK], float (&pr)[NTK]) {
+                    float mx = t[0];
+#pragma unroll
+                    for (int r = 1; r < NTK; ++r) mx = fmaxf(mx, t[r]);
+                    float l = 0.f;
+#pragma unroll
+                    for (int r = 0; r < NTK; ++r) {
+                        pr[r] = __expf(t[r] - mx);
+                        l += pr[r];
+                    }
+                    const float inv = 1.0f / l;
+#pragma unroll
+                    for (int r = 0; r < NTK; ++r) pr[r] *= inv;
+                };
+                softmax(t0, p0);
+                softmax(t1, p1);
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+                float so4[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (NP == 2) oscale4(0, n, so4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float vm = NTK > 4 ? mirror(vv[n][c]) : 0.f;
+                    float o = (h1 ? p1[0] : p0[0]) * vv[n][c];
+#pragma unroll
+                    for (int r = 1; r < NTK; ++r) o = fmaf(h1 ? p1[r] : p0[r], xpart(vv[n][c], vm, r), o);
+                    ov[n][c] = o * so4[c];
+                }
+            }
+        };
+        if (a.att_ntok == 4) {
+            auto quad = [](float x, int j) -> float {
+                const int xi = __builtin_bit_cast(int, x);
+                int r;
+                switch (j) {
+                    case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
+                    case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
+                    case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
+                    default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
+                }
+                return __builtin_bit_cast(float, r);
+            };
+            const bool two_heads = a.att_hd == 68;
+            float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d = qv[n][0] * quad(kv[n][0], j);
+                    d = fmaf(qv[n][1], quad(kv[n][1], j), d);
+                    d = fmaf(qv[n][2], quad(kv[n][2], j), d);
+                    d = fmaf(qv[n][3], quad(kv[n][3], j), d);
+                    s0[j] += h1 ? 0.f : d;
+                    s1[j] += h1 ? d : 0.f;
+                }
+            }
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = xor16_add(s0[j]); s0[j] = xor32_add(s0[j]);
+                s1[j] = xor16_add(s1[j]); s1[j] = xor32_add(s1[j]);
+            }
+            float* xs = reinterpret_cast<float*>(smem) + rt * (2 * BM * 8);     // [row tile][2 halves][64 rows][8]
+            const int half = slot0 ? 1 : 0;
+            __syncthreads();                                    // every wave is done reading the last stage
+            if (kq == 0) {
+                st4(xs + (half * BM + row_l) * 8, float4{s0[0], s0[1], s0[2], s0[3]});
+                st4(xs + (half * BM + row_l) * 8 + 4, float4{s1[0], s1[1], s1[2], s1[3]});
+            }
+            __syncthreads();
+            float p0[4], p1[4];
+            {
+                const float4 a0 = ld4(xs + row_l * 8), a1 = ld4(xs + row_l * 8 + 4);
+                const float4 b0 = ld4(xs + (BM + row_l) * 8), b1 = ld4(xs + (BM + row_l) * 8 + 4);
+                const float scale = 1.0f / sqrtf((float)a.att_hd);
+                const float t0[4] = {(a0.x + b0.x) * scale, (a0.y + b0.y) * scale, (a0.z + b0.z) * scale, (a0.w + b0.w) * scale};
+                const float t1[4] = {(a1.x + b1.x) * scale, (a1.y + b1.y) * scale, (a1.z + b1.z) * scale, (a1.w + b1.w) * scale};
+                auto softmax4 = [](const float (&t)[4], float (&pr)[4]) {
+                    const float mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+                    const float e0 = __expf(t[0] - mx), e1 = __expf(t[1] - mx), e2 = __expf(t[2] - mx), e3 = __expf(t[3] - mx);
+                    const float inv = 1.0f / ((e0 + e1) + (e2 + e3));
+                    pr[0] = e0 * inv; pr[1] = e1 * inv; pr[2] = e2 * inv; pr[3] = e3 * inv;
+                };
+                softmax4(t0, p0);
+                softmax4(t1, p1);
+            }
+    #pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const bool h1 = two_heads && 4 * tile_of(n) + kq >= 17;
+                const float pj[4] = {h1 ? p1[0] : p0[0], h1 ? p1[1] : p0[1], h1 ? p1[2] : p0[2], h1 ? p1[3] : p0[3]};
+                float so4[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (NP == 2) oscale4(0, n, so4);
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float o = pj[0] * quad(vv[n][c], 0);
+                    o = fmaf(pj[1], quad(vv[n][c], 1), o);
+                    o = fmaf(pj[2], quad(vv[n][c], 2), o);
+                    o = fmaf(pj[3], quad(vv[n][c], 3), o);
+                    ov[n][c] = o * so4[c];
+                }
+            }
+        } else if (a.att_ntok == 8) {
+            att_xor(std::integral_constant<int, 8>{});
+        } else {
+            att_xor(std::integral_constant<int, 2>{});
         }
         const int Go = Dq / BN, g_out = n0 / BN;
         char* cbase = a.C2 + (((size_t)tm * RT + rt) * 4 + rg) * h2_ksteps(Dq, NP) * H2_RG;

@@ -1,9 +1,9 @@
-"""bf16 engine (b1_gemm.hip) check + A/B against the round-2 bf16 engine, one process:
+"""bf16 engine (b1_gemm.hip) check + timing beside the fp32 engine, one process:
     python tools/b1_check.py [--fast]
  * parity: new engine vs the oracle's bf16 emulation (fp64) on goldens' models at several batch sizes (one-tile form, pair
    form, ragged tiles, generic / in-register attention), persistent launch vs one launch per GEMM, pair form vs one-tile form
    (bitwise);
- * speed: ms per forward and per stack launch, new vs old engine, V = 8 B = 1024 depth 2 / 12 (BASELINE configs[2])."""
+ * speed: ms per forward and per stack launch, bf16 vs fp32 engine, V = 8 B = 1024 depth 2 / 12 (BASELINE configs[2])."""
 import os
 import sys
 import time
@@ -56,17 +56,15 @@ for name, B in [("chosen_v8_b4_l2", 64), ("chosen_v8_b4_l2", 1024), ("chosen_v4_
     out_1 = run(m, P, R, Cn)                        # forced one-tile form
     mode(8 | (2 << 1))
     out_2 = run(m, P, R, Cn)                        # forced pair form
-    mode(8 | OLD)
-    m.set_matmul_precision("bf16_old")
-    out_o = run(m, P, R, Cn)
+    out_o = out
     mode(0)
     e = mpl_oracle.rel_errors
     deep = g["flags"]["depth"] > 2
     ok = e(out, emu)[0] < (3e-3 if deep else 1e-3) and torch.isfinite(out).all()
     bw = torch.equal(out_1, out_2)
     bad += (not ok) + (not bw)
-    print("%-18s B=%4d  new vs emu %.2e/%.2e  old vs emu %.2e/%.2e  new vs fp64 ref %.2e  per-GEMM vs chain %.1e  pair==one-tile %s  %s"
-          % (name, B, *e(out, emu), *e(out_o, emu), e(out, ref)[0], e(out_g, out)[0], bw, "ok" if ok and bw else "FAIL"), flush=True)
+    print("%-18s B=%4d  new vs emu %.2e/%.2e  new vs fp64 ref %.2e  per-GEMM vs chain %.1e  pair==one-tile %s  %s"
+          % (name, B, *e(out, emu), e(out, ref)[0], e(out_g, out)[0], bw, "ok" if ok and bw else "FAIL"), flush=True)
     del m
 
 print("parity failures:", bad, flush=True)
@@ -75,7 +73,7 @@ for fs, V, L, B in [("chosen", 8, 2, 1024), ("chosen", 8, 12, 1024), ("chosen", 
     b = [make_batch(B, V, dev, seed=1, step=s) for s in range(2)]
     res = {}
     for rep in range(2):
-        for prec, bits in (("bf16", 0), ("bf16_old", OLD)):
+        for prec, bits in (("bf16", 0), ("fp32", 0)):
             mode(bits)
             m.set_matmul_precision(prec)
             with torch.no_grad():
@@ -96,6 +94,6 @@ for fs, V, L, B in [("chosen", 8, 2, 1024), ("chosen", 8, 12, 1024), ("chosen", 
             res.setdefault(prec, []).append((dt, pr["gemm"][0] / 4))
     mode(0)
     f = lambda k: "%.3f ms / stack %.3f ms (%.0f poses/s)" % (min(x[0] for x in res[k]), min(x[1] for x in res[k]), B / min(x[0] for x in res[k]) * 1e3)
-    print("%-6s V=%d L=%2d B=%4d | new: %s | old: %s" % (fs, V, L, B, f("bf16"), f("bf16_old")), flush=True)
+    print("%-6s V=%d L=%2d B=%4d | bf16: %s | fp32: %s" % (fs, V, L, B, f("bf16"), f("fp32")), flush=True)
     del m
 sys.exit(1 if bad else 0)

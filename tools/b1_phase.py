@@ -1,6 +1,6 @@
 """Per-phase time of the bf16 block stack by stopping the persistent launch after n GEMMs (mpl_x3_stack_mode bits 8..):
     python tools/b1_phase.py [V] [B] [depth]
-Prints the stack time for n = 1 .. 8 (two block applications) in the pair form, the forced one-tile form and the round-2 engine."""
+Prints the stack time for n = 1 .. 8 (two block applications): bf16 engine (default form), its pair form, the fp32 engine."""
 import os
 import sys
 
@@ -19,7 +19,7 @@ fs = sys.argv[4] if len(sys.argv) > 4 else "chosen"
 m = build_model(model_flags(fs, V, L), dev)
 b = make_batch(B, V, dev, seed=1)
 rows = []
-for label, prec, bits in (("pair", "bf16", 0), ("one-tile", "bf16", 1 << 1), ("old", "bf16_old", 1 << 4), ("fp32", "fp32", 0)):
+for label, prec, bits in (("bf16", "bf16", 0), ("bf16 pairs", "bf16", 2 << 1), ("fp32", "fp32", 0)):
     m.set_matmul_precision(prec)
     ts = []
     for n in list(range(1, 9)) + [0]:
