@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="poses per GPU per step")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--depth", type=int, default=12)
-    ap.add_argument("--flagset", choices=("chosen", "full"), default="chosen")
+    ap.add_argument("--flagset", choices=("chosen", "full", "kptok"), default="chosen",
+                    help="chosen / full: the two shipped YAML families; kptok: CHOSEN + FPT_blocks_view_keypoint_tokens (the joints x "
+                         "views token grid, 17 V tokens of width 32: BASELINE configs[4] with --views 31 --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs / engines)")
     ap.add_argument("--force-dist", action="store_true",
@@ -141,7 +143,9 @@ def cpu_model():
 
 def model_flags(flagset, views, depth, **more):
     flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=depth, num_views=views)
-    flags.update(CHOSEN if flagset == "chosen" else FULL)
+    flags.update(FULL if flagset == "full" else CHOSEN)
+    if flagset == "kptok":
+        flags["FPT_blocks_view_keypoint_tokens"] = True
     flags.update(more)
     return flags
 
@@ -163,6 +167,8 @@ def make_batch(batch, views, dev, seed, step=0):
 
 
 def fpt_width(flags):
+    if flags.get("FPT_blocks_view_keypoint_tokens"):
+        return 32
     return 17 * 32 * (2 if flags.get("input_rays_as_token") else 1)
 
 
@@ -349,10 +355,69 @@ def run_rank(a):
         print(json.dumps(result), file=json_out, flush=True)
 
 
+def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_dist):
+    """The joints x views token grid (17 V tokens of width 32): the dominant kernel is the long-sequence attention
+    (token_attention_long_p4_kernel: K / V of one head LDS resident, keys in pairs), a VALU kernel.  Its roofline is the VALU issue
+    floor: per (query, key) pair and head 4 FMAs for the score (2 packed issue slots), 1 v_exp_f32 (quarter rate: 4 slots), ~3 for
+    the running maximum / sum / rescale, 4 FMAs for P.V (2 packed slots) = 11 issue slots of a 64-lane instruction per 64 pairs,
+    on 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction."""
+    import torch
+    from openmpl_amd import cabi
+    from oracle import mpl_oracle
+    n_prof = max(a.steps, 20)
+    with torch.no_grad():
+        for i in range(3):
+            P, R, C = batches[i % len(batches)]
+            model(P, rays=R, centers=C)
+        cabi.profile_start()
+        for i in range(n_prof):
+            P, R, C = batches[i % len(batches)]
+            model(P, rays=R, centers=C)
+        torch.cuda.synchronize()
+        prof = cabi.profile_stop()
+    N, H, apps = 17 * a.views, 8, flags["depth"] + 1
+    att_ms, att_n = prof["attention"]
+    us = att_ms / max(1, att_n) * 1e3
+    pairs = float(a.batch) * H * N * N                                   # (query, key) pairs per launch
+    slots = 11.0
+    floor_us = pairs * slots / 64.0 * 2.0 / (1024 * 2.4e9) * 1e6         # wave64 VALU instruction = 2 cycles on a SIMD-32
+    flop = pairs * 16.0                                                  # 2 x (4 score + 4 P.V) multiply-adds per pair
+    roof = dict(bound="valu", kernel="token_attention_long_p4_kernel", launches_per_step=att_n // n_prof, launches_timed=att_n,
+                avg_launch_us=round(us, 1), valu_floor_us=round(floor_us, 1), achieved=round(flop / (us * 1e-6) / 1e12, 2),
+                peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(floor_us / us, 4),
+                note="frac = VALU issue floor / measured launch time (11 issue slots per 64 query-key pairs: 4 FMA scores as 2 packed, "
+                     "v_exp_f32 at quarter rate = 4, 3 for max / sum / rescale, 4 FMA P.V as 2 packed); `achieved` = attention FLOP/s "
+                     "against the fp32 vector peak (= fp32 matrix peak, 157.3 TFLOP/s)",
+                kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
+                share_of_kernel_time=round(att_ms / sum(t for t, _ in prof.values()), 3), traffic=None)
+    P, R, C = batches[0]
+    nb = min(16, a.batch)
+    sub = lambda lst, n: [x[:n].contiguous() for x in lst]
+    cpu = lambda lst, n: [x[:n].cpu() for x in lst]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        got = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
+    ref = mpl_oracle.forward(sd, flags, cpu(P, nb), cpu(R, nb), cpu(C, nb))
+    mx, nw = mpl_oracle.rel_errors(got, ref)
+    return {
+        "metric": "poses/sec (V=%d, J=17, batch=%d per GPU) fp32, joints x views token grid" % (a.views, a.batch),
+        "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "rccl_ranks": world if used_dist else 0,
+        "config": {"workload": "large-view stress: V=%d J=17 batch=%d fp32, CHOSEN + FPT_blocks_view_keypoint_tokens (%d-token grid), depth %d"
+                               % (a.views, a.batch, N, a.depth), "global_batch": world * a.batch,
+                   "parallelism": "single GPU" if not used_dist else "dp%d" % world},
+        "roofline": roof, "cpu_baseline": None,
+        "parity": dict(max_scaled=float("%.3e" % mx), norm_wise=float("%.3e" % nw), poses=nb, tol=1e-4), "extra": {},
+    }
+
+
 def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used_dist):
     import torch
     from openmpl_amd import cabi
     from oracle import mpl_oracle
+    if a.flagset == "kptok":
+        return kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_dist)
     # ---- per-kernel time, measured live with HIP events on the launch stream: a WHOLE region of `steps` forwards run like the
     # timed one (same batches, back to back, warm), with every launch bracketed -- not a handful of forwards behind an idle gap
     P, R, C = batches[0]

@@ -45,9 +45,12 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #define H2_RP_WC0 (H2_R2_AB ? 4 : 1)      // W pieces per wave role of the bf16 pair form
 #define H2_RP_WC1 (H2_R2_AB ? 1 : 4)
 #define H2_RP_WC2 (H2_R2_AB ? 0 : 3)
-#define H2_R2_WC0 1      // W pieces per wave role of the two-tile stage (the waves 0..3 carry four A pieces)
-#define H2_R2_WC1 4
-#define H2_R2_WC2 3
+#ifndef H2_R2_AB2
+#define H2_R2_AB2 0     // the same duty for the two-tile stage of the fp16x2 engine (h2_stack2_kernel)
+#endif
+#define H2_R2_WC0 (H2_R2_AB2 ? 4 : 1)      // W pieces per wave role of the two-tile stage (the waves 0..3 carry four A pieces)
+#define H2_R2_WC1 (H2_R2_AB2 ? 1 : 4)
+#define H2_R2_WC2 (H2_R2_AB2 ? 0 : 3)
 #define H2_WC0 (H2_WSPLIT == 1 ? 2 : 1)
 #define H2_WC1 (H2_WSPLIT == 1 ? 3 : 4)
 #define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
@@ -307,7 +310,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // M = 8192 on the fp16x2 engine, tools/ab_rt2.sh, and removed again).  AB (bf16 pair form): the waves 4..7, which request at
     // the HEAD of a stage, bring ALL A pieces (four each) and the waves 0..3, which request behind their product rows, W only:
     // the A strips come from beyond L2 (their producers store write-through) and need the longer flight
-    constexpr bool AB = H2_R2_AB && RT == 2 && NP == 1;
+    constexpr bool AB = RT == 2 && (NP == 1 ? H2_R2_AB != 0 : H2_R2_AB2 != 0);
     constexpr bool HAS_A = (AB ? !LEAD : LEAD) && ACT;
     const bool WT = CHAIN && !a.plain;
     const int lane = tid & 63;

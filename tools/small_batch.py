@@ -35,5 +35,21 @@ for fs, V, Bs in (("chosen", 2, (1, 8, 16, 32)), ("chosen", 4, (1, 4, 8, 12, 16)
                 pr = cabi.profile_stop()
             res[tag] = (lat, thr, pr["gemm"][0] / 4 * 1e3, pr["spt"][0] / 4 * 1e3)
         cabi.check(lib.mpl_x3_stack_mode(0), "mode")
-        print("%-6s V=%d B=%2d | " % (fs, V, B) + " | ".join("%s: %.0f us per call (%.0f back to back; stack %.0f, SPT %.0f)" % ((t,) + res[t]) for t in res), flush=True)
+        # the registered torch operator (openmpl_amd::forward) against the direct ctypes call: host time per call, not synchronised
+        host = {}
+        for route in (False, True):
+            m.use_torch_op(route)
+            with torch.no_grad():
+                for i in range(5):
+                    m(b[i % 2][0], rays=b[i % 2][1], centers=b[i % 2][2])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(200):
+                    m(b[i % 2][0], rays=b[i % 2][1], centers=b[i % 2][2])
+                host[route] = (time.perf_counter() - t0) / 200 * 1e6
+                torch.cuda.synchronize()
+        m.use_torch_op("auto")
+        res["host us per call direct / via torch op"] = (host[False], host[True], 0.0, 0.0)
+        print("%-6s V=%d B=%2d | " % (fs, V, B) + " | ".join("%s: %.0f us per call (%.0f back to back; stack %.0f, SPT %.0f)" % ((t,) + res[t]) for t in res if not t.startswith("host")) +
+              " | host: direct %.1f us, via openmpl_amd::forward %.1f us" % res["host us per call direct / via torch op"][:2], flush=True)
     del m

@@ -1,5 +1,5 @@
 """Wall time of the block-stack launch against the number of active row-tile teams (same work per workgroup):
-a time that grows with the active fraction of the chip is power / clock, not the kernel.  [ENGINE=h2|x3] python tools/stack_time.py"""
+a time that grows with the active fraction of the chip is power / clock, not the kernel.  [ENGINE=h2|b1] python tools/stack_time.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
