@@ -1739,16 +1739,25 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
             else if (a.n_tiles * 2 * a.G <= cus) a.rgs = 2;
         }
     }
+    // plain hand-off stores for teams on one XCD: everywhere but the two-tile stage of the fp16x2 engine.  Same-process A/B
+    // (tools/wt_ab.py): bf16 engine -2 .. -4 % stack time (its stage is bound by the L2 -> LDS path, half of its bytes are
+    // activations), row-narrow teams -2 %, headline fp16x2 stack 0 % in time but 9 % less fabric traffic (2.43 -> 2.22 GB per
+    // launch, L2 hit rate 80 -> 89 %: profiles/r05_gemm_traffic.json); FULL on the two-tile stage +1.7 % (slower): write-through there
+    a.plain_ok = (!h2_write_through_always() && (NP == 1 || !pairs)) ? 1 : 0;
     const int n_units_n = a.rgs == 4 ? n_units : a.n_tiles * (4 / a.rgs);
     a.n_teams = n_units_n < cap ? n_units_n : cap;
     if (a.n_teams * a.G > H2_MAX_WGS) a.n_teams = H2_MAX_WGS / a.G;
+    // residency: every workgroup that takes part (n_teams x G <= cap x G <= CUs) needs a CU of its own -- 160 KiB of LDS make that
+    // ONE per CU whatever the occupancy API reports (it is only asked whether the kernel fits at all); the grid is rounded up to
+    // whole XCD rounds, the surplus blocks leave at once (team >= n_teams)
+    if (a.n_teams * a.G > resident[dev].load()) return MPL_E_UNSUPPORTED;
     a.n_apps = n_apps;
     a.n_phases = (stop_after > 0 && stop_after < 4 * n_apps) ? stop_after : 4 * n_apps;
     a.eps = eps;
     a.dbg = h2_debug_buffer();
     a.err_ws = counters + h2_err_index(a.n_tiles);
     a.xcc = counters + H2_CTR_PER_TILE * a.n_tiles;
-    a.plain_ok = h2_write_through_always() ? 0 : 1;
+    a.plain_ok = 0;          // set below, once the form of the launch is known
     a.err_host = device_error_word(dev);
     a.spin_log2 = h2_spin_log2();
     a.inject = take_fault_injection();

@@ -474,8 +474,16 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     if (!attr_set[dev][mi].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES) != hipSuccess)
             return MPL_E_LAUNCH;
+        // the grid barrier needs grid <= resident workgroups.  The LDS footprint (~150 KiB of 160) allows ONE workgroup per CU
+        // whatever the occupancy API says, so the API's known over-count of one block per CU at 81 .. 112 SGPRs (256-thread
+        // blocks, MI355X_MICROARCH.md "Correctness boundaries"; these kernels spill ~340 SGPRs and sit in that bucket) cannot
+        // strand a workgroup here: per_cu is clamped to 1 and the grid (3 D / 16 <= cus, checked above) to per_cu x CUs
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 256, SM_LDS_BYTES) != hipSuccess || per_cu < 1)
+            return MPL_E_UNSUPPORTED;
         attr_set[dev][mi].store(true, std::memory_order_release);
     }
+    if (a.n_wg > cus) return MPL_E_UNSUPPORTED;            // grid <= min(per_cu, 1) x CUs
     if (hipMemsetAsync(a.bar, 0, SM_BAR_WORDS * sizeof(unsigned), s) != hipSuccess) return MPL_E_LAUNCH;
     // a grid barrier needs the chip like the team kernels do: serialised with them per device (api.hip)
     hipEvent_t ev = stack_chain_event(dev);
