@@ -358,9 +358,10 @@ def run_rank(a):
 def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_dist):
     """The joints x views token grid (17 V tokens of width 32): the dominant kernel is the long-sequence attention
     (token_attention_long_p4_kernel: K / V of one head LDS resident, keys in pairs), a VALU kernel.  Its roofline is the VALU issue
-    floor: per (query, key) pair and head 4 FMAs for the score (2 packed issue slots), 1 v_exp_f32 (quarter rate: 4 slots), ~3 for
-    the running maximum / sum / rescale, 4 FMAs for P.V (2 packed slots) = 11 issue slots of a 64-lane instruction per 64 pairs,
-    on 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction."""
+    floor in slots of 2 cycles (one plain wave64 instruction on a SIMD-32): per (query, key) and head the score is 4 FMAs = 2 packed
+    instructions of 2 slots each = 4 slots, v_exp_f32 runs at quarter rate = 4 slots, the exponent argument, the running maximum
+    and the row sum ~2.5, P.V 4 FMAs = 4 slots: ~15 slots per (query, key) -- a packed fp32 instruction does two lanes' worth of
+    work and occupies the pipe twice as long, so pairing keys saves instructions, not pipe time -- on 1024 SIMDs x 2.4 GHz."""
     import torch
     from openmpl_amd import cabi
     from oracle import mpl_oracle
@@ -379,15 +380,15 @@ def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_
     att_ms, att_n = prof["attention"]
     us = att_ms / max(1, att_n) * 1e3
     pairs = float(a.batch) * H * N * N                                   # (query, key) pairs per launch
-    slots = 11.0
+    slots = 15.0
     floor_us = pairs * slots / 64.0 * 2.0 / (1024 * 2.4e9) * 1e6         # wave64 VALU instruction = 2 cycles on a SIMD-32
     flop = pairs * 16.0                                                  # 2 x (4 score + 4 P.V) multiply-adds per pair
     roof = dict(bound="valu", kernel="token_attention_long_p4_kernel", launches_per_step=att_n // n_prof, launches_timed=att_n,
                 avg_launch_us=round(us, 1), valu_floor_us=round(floor_us, 1), achieved=round(flop / (us * 1e-6) / 1e12, 2),
                 peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(floor_us / us, 4),
-                note="frac = VALU issue floor / measured launch time (11 issue slots per 64 query-key pairs: 4 FMA scores as 2 packed, "
-                     "v_exp_f32 at quarter rate = 4, 3 for max / sum / rescale, 4 FMA P.V as 2 packed); `achieved` = attention FLOP/s "
-                     "against the fp32 vector peak (= fp32 matrix peak, 157.3 TFLOP/s)",
+                note="frac = VALU issue floor / measured launch time (15 two-cycle slots per query-key pair and head: 4 score FMAs, "
+                     "v_exp_f32 at quarter rate = 4, ~2.5 for exponent argument / maximum / row sum, 4 P.V FMAs + the sum; packed "
+                     "instructions count as two slots); `achieved` = attention FLOP/s against the fp32 vector peak (157.3 TFLOP/s)",
                 kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
                 share_of_kernel_time=round(att_ms / sum(t for t, _ in prof.values()), 3), traffic=None)
     P, R, C = batches[0]
