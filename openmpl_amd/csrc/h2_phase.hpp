@@ -1594,6 +1594,9 @@ __global__ __launch_bounds__(512, 2) void h2_stack2_kernel(const H2StackArgs s) 
 // Inside a workgroup the waves keep their full-tile roles: wave w works on row group w & 3 if the workgroup owns it (h2_phase
 // ACT = true: the very code of h2_stack_kernel, so the poses are bitwise the same), otherwise it only requests its W pieces and
 // meets the barriers (ACT = false).  Column groups are untouched: heads stay whole, the in-register attention is unchanged.
+// Measured and dropped (round 5, tools/ab.sh): in the 16-row form seven waves wait ~450 cycles per stage at the barrier for the one
+// wave pair that multiplies (tools/chain_phase.py), so its W pieces were given to the six loader-only waves (three each, by
+// rank): no gain for the stage, and the extra instantiations cost every form of this kernel 8 % (SGPR spills 492 -> 768).
 template <int NP>
 __global__ __launch_bounds__(512, 2) void h2_stackn_kernel(const H2StackArgs s) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
