@@ -165,3 +165,29 @@ def test_single_rank_group_still_runs_the_collective():
         assert torch.equal(gather_outputs(x, 5), x)
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_lifter_asks_the_model_for_batch_invariant_bits():
+    """A shard must equal the rows of the single-process result bit for bit whatever the world size leaves of the batch: the lifter
+    switches the model's small-batch engine (another fp32 arithmetic for <= 32 token rows) off -- on the model itself and, for the
+    cfg wrapper MultiView_MPL_G, on the model inside (.features).  No process group is needed for that."""
+    class Inner:
+        mode = "auto"
+
+        def set_small_batch_engine(self, mode):
+            self.mode = mode
+
+    class Wrapper:
+        def __init__(self):
+            self.features = Inner()
+
+        def __call__(self, *a, **k):
+            raise AssertionError("not called here")
+
+    inner = Inner()
+    ShardedLifter(inner)
+    assert inner.mode is False
+    w = Wrapper()
+    ShardedLifter(w)
+    assert w.features.mode is False
+    ShardedLifter(lambda poses, rays=None, centers=None: poses[0])        # a plain callable: nothing to switch, no error
