@@ -1760,7 +1760,6 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     a.dbg = h2_debug_buffer();
     a.err_ws = counters + h2_err_index(a.n_tiles);
     a.xcc = counters + H2_CTR_PER_TILE * a.n_tiles;
-    a.plain_ok = 0;          // set below, once the form of the launch is known
     a.err_host = device_error_word(dev);
     a.spin_log2 = h2_spin_log2();
     a.inject = take_fault_injection();

@@ -30,4 +30,6 @@ $P --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUS
 $P --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU TCC_HIT_sum TCC_MISS_sum -d $O/pmc_b -o p -- $CMD > $O/pmc_b.log 2>&1
 $P --pmc FETCH_SIZE -d $O/pmc_c -o p -- $CMD > $O/pmc_c.log 2>&1
 $P --pmc WRITE_SIZE -d $O/pmc_d -o p -- $CMD > $O/pmc_d.log 2>&1
-ls $O
+# gpurun merges at most 64 MiB back: keep what tools/make_profiles.py reads, drop the raw traces
+find $O -type f ! -name 't_kernel_stats.csv' ! -name 'p_counter_collection.csv' ! -name 'bench.json' ! -name 'cmd.txt' ! -name 'srchash.txt' ! -name 'bench.log' -delete
+du -sh $O
