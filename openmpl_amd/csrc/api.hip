@@ -569,6 +569,7 @@ int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);
     h2_set_write_through((one_launch_per_gemm >> 7) & 1);  // bit 7: write-through hand-off stores also for teams that sit on one XCD
+    h2_set_direct_w(((one_launch_per_gemm >> 4) & 1) ^ 1);  // bit 4: the 16-row teams in the ring form (A/B against the direct-W form)
     h2_set_narrow((one_launch_per_gemm >> 5) & 3);         // bits 5, 6: row-narrow teams: 0 = by shape, 1 = never, 2 / 3 = 32- / 16-row workgroups where legal
     h2_set_row_tiles((one_launch_per_gemm >> 1) & 3);      // bits 1, 2: 0 = by shape, 1 / 2 = force the one- / two-tile stage
     sm_stack_disable((one_launch_per_gemm >> 3) & 1);      // bit 3: no small-batch engine (the team kernels for every batch)

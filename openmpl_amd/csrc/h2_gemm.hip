@@ -369,6 +369,9 @@ int h2_narrow_mode() { return g_h2_narrow.load(); }
 static std::atomic<int> g_h2_wt_always{getenv("MPL_WRITE_THROUGH") != nullptr ? 1 : 0};
 void h2_set_write_through(int always) { g_h2_wt_always.store(always & 1); }
 int h2_write_through_always() { return g_h2_wt_always.load(); }
+static std::atomic<int> g_h2_direct_w{1};
+void h2_set_direct_w(int on) { g_h2_direct_w.store(on & 1); }
+int h2_direct_w() { return g_h2_direct_w.load(); }
 
 
 template <int EPI, bool LNF, int NPASS>

@@ -21,6 +21,7 @@ constexpr int H2_STAGE = H2_A + H2_W;        // 26624
 constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
 constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
 constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
+constexpr int H2_DW_PROG = 96 * 1024;      // direct-W form: progress word (k-tile) of the multiplying waves
 constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
 constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
@@ -32,6 +33,21 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #endif
 #ifndef H2_ABL
 #define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier
+#endif
+#ifndef H2_DW_APRE
+#define H2_DW_APRE 1    // direct-W form: the A fragment is read one k-tile ahead
+#endif
+#ifndef H2_DW_AHEAD
+#define H2_DW_AHEAD 0   // direct-W form: k-tiles the L2 warming of the idle waves may run ahead (0 = none)
+#endif
+#ifndef H2_DW_NT
+#define H2_DW_NT 0
+#endif
+#ifndef H2_DW_PD
+#define H2_DW_PD 4
+#endif
+#ifndef H2_DW_PIN
+#define H2_DW_PIN 1     // direct-W form: pin the MFMA / load interleave of a stage (sched_group_barrier)
 #endif
 #ifndef H2_WT_AUX
 #define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
@@ -286,10 +302,11 @@ __device__ __forceinline__ bool h2_att_in_registers(int ntok, int hd, int rpt) {
     return (ntok == 2 || ntok == 4 || ntok == 8) && (hd == 68 || hd == BN) && rpt == BM;
 }
 
-template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2, bool ACT = true>
+template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2, bool ACT = true, bool DW = false>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
                                          unsigned* chain, unsigned chain_need, bool arrive = true, int rg_lo = 0, int rgs = 4) {
     static_assert(ACT || (RT == 1 && CHAIN), "loader-only waves exist in the row-narrow stack only");
+    static_assert(!DW || (RT == 1 && CHAIN && NP == 2), "direct-W form: 16-row teams of the fp16x2 stack");
     constexpr int ABYTES = RT * 4 * H2_RG;       // A bytes per stage
     constexpr int STAGE = ABYTES + H2_W;
     constexpr int NST = RT == 1 ? H2_NST : 4;
@@ -314,7 +331,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     constexpr bool HAS_A = (AB ? !LEAD : LEAD) && ACT;
     const bool WT = CHAIN && !a.plain;
     const int lane = tid & 63;
-    const int rg = wave & 3;
+    // DW: every wave works for row group rg_lo (the two multiplying waves sit on different SIMDs)
+    const int rg = DW ? rg_lo : (wave & 3);
     const int li = lane & 15, kq = lane >> 4;
     const int M = a.M, N = a.N, K = a.K;
     const int m0 = tm * RT * a.rpt, n0 = NPASS == 2 ? tn * (2 * BN) : tn * BN;
@@ -475,7 +493,35 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     bool arrived = !CHAIN;
     if (CHAIN && !LEAD && wave == 7)
         arrived = __hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need;
-    issue_w();
+    // ---- DW (direct-W form, 16-row teams): no ring.  The two multiplying waves take their W fragments straight from global
+    // memory (L2) into registers, PD stages ahead; the whole A operand of the row group (2 KT KiB) is brought into LDS once,
+    // by all eight waves, behind the hand-off.  Same fragments, same product order, same epilogue as the ring form.
+    constexpr int PD = NPASS == 3 ? 3 : H2_DW_PD;
+    f16x8 Bb[DW && ACT ? PD : 1][NTW][2];
+    auto dw_ld = [](const char* p) -> f16x8 {
+        if (H2_DW_NT) return __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
+        return *reinterpret_cast<const f16x8*>(p);
+    };
+    auto dw_fetch = [&](auto j_c, int kt) {
+        constexpr int j = decltype(j_c)::value;
+        if constexpr (DW && ACT) {
+            const char* src = is_w[j % NPASS] + (size_t)kt * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                Bb[j][n][0] = dw_ld(src + (n * 2 + 0) * 1024);
+                Bb[j][n][1] = dw_ld(src + (n * 2 + 1) * 1024);
+            }
+        }
+    };
+    if constexpr (DW) {
+        dw_fetch(std::integral_constant<int, 0>{}, 0);
+        dw_fetch(std::integral_constant<int, 1>{}, 1 / NPASS);
+        if constexpr (PD > 2) dw_fetch(std::integral_constant<int, 2>{}, 2 / NPASS);
+        if constexpr (PD == 4) dw_fetch(std::integral_constant<int, 3>{}, 3 / NPASS);
+        static_assert(PD >= 2 && PD <= 4, "register ring depth");
+    } else {
+        issue_w();
+    }
     if (CHAIN) {
         if (!LEAD && wave == 7 && !arrived) {
             const unsigned lim = 1u << a.spin_log2;
@@ -499,13 +545,38 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
     }
     const unsigned long long t_chain = (H2_DBG == 2 && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
-    issue_a();
+    if constexpr (!DW) {
+        issue_a();
+    } else {
+        // the A operand of row group rg_lo, k-tile kt at LDS offset 2048 kt: piece i = 2 kt + half, spread over the eight waves
+        const int rows_lo = m0 + rg_lo * 16 + li;
+        const int rowa = (rg_lo * 16 + li < a.rpt && rows_lo < M) ? rows_lo : (M - 1);
+        const unsigned vA = RAWX ? (unsigned)(((size_t)(rowa - m0) * a.ldx + 4 * kq) * 4) : (unsigned)(lane * 16);
+        const unsigned vT = RAWX ? (unsigned)(((size_t)(rowa - m0) * a.ldx + 136 * kq + 128) * 4) : 0u;
+        const char* abase = RAWX ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx) : a.A2 + ((size_t)tm * 4 + rg_lo) * KT * H2_RG;
+        const unsigned keep = dma_m0_save();
+        for (int i = wave; i < 2 * KT; i += 8) {
+            const int kt = i >> 1, half = i & 1;
+            const char* src;
+            unsigned vo;
+            if (RAWX) {
+                const bool full = kt < 4 * G;
+                src = full ? abase + (size_t)(136 * (kt >> 2) + 32 * (kt & 3)) * 4 + half * 64 : abase + (size_t)(136 * 4 * (kt - 4 * G)) * 4 + half * 16;
+                vo = full ? vA : vT;
+            } else {
+                src = abase + (size_t)i * 1024;
+                vo = vA;
+            }
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(vo), "s"(src), "s"(lds0 + (unsigned)i * 1024u) : "memory");
+        }
+        dma_m0_restore(keep);
+    }
     // LNF: the row statistics (slice partials {mean, M2} written by the producers of x) of this wave's 16 rows, requested
     // right behind A(0).  NPASS >= 2: by LDS-DMA (L1-bypassing in chain mode) into the A region of stage slot 1, which a
     // pass-1 stage never uses -- an ordinary load here would make the compiler drain the WHOLE queue (it cannot see the
     // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
     // RT = 2: into the 20 KiB its ring of 4 x 34 KiB leaves free below the vector region (every stage of a one-pass GEMM carries A)
-    constexpr unsigned ST_LDS = RT == 2 ? NST * STAGE : STAGE;           // + 1 KiB per wave, + 8 KiB per row tile
+    constexpr unsigned ST_LDS = DW ? 72u * 1024u : (RT == 2 ? NST * STAGE : STAGE);           // + 1 KiB per wave, + 8 KiB per row tile
     constexpr bool ST_DMA = NPASS >= 2 || RT == 2;
     static_assert(RT == 1 || ST_LDS + 16384 <= H2_VEC, "statistics rows overlap the epilogue vectors");
     float4 st_raw[4];
@@ -540,10 +611,12 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             for (int i = 0; i < 4; ++i) st_raw[i] = (2 * i < ns) ? ld4(sp + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    if constexpr (!DW) {
 #pragma unroll
-    for (int t = 1; t < DIST; ++t) {
-        issue_w();
-        issue_a();
+        for (int t = 1; t < DIST; ++t) {
+            issue_w();
+            issue_a();
+        }
     }
     const float ainv = (!LNF && a.a_inv) ? a.a_inv[0] : 1.0f;
 
@@ -646,7 +719,12 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     unsigned long long t_land = 0;
     {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
         // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
-        if (HAS_A) {
+        if constexpr (DW) {
+            if (H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = 0;
+            // the A operand and the statistics rows landed (DMA); the W fragments of the first PD stages are ordinary loads the
+            // compiler counts itself: the NTW * 2 * PD of them were requested BEFORE the DMA pieces, so they have landed too
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (HAS_A) {
             // A stages among the stages 1 .. DIST - 1: every NPASS-th
             constexpr int LATER = P2 ? 2 * WC + APW * (NPASS == 1 ? 2 : 1) : (DIST - 1) * WC + APW * ((DIST - 1) / NPASS);
             static_assert(LATER < 64, "vmcnt is 6 bits");
@@ -695,10 +773,25 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (ACT) {
+        if constexpr (ACT && !DW) {
             read_a(0, A0);
             if (RAWX) finish_a(A0);
             read_b(0, B0);
+        }
+        if constexpr (DW && RAWX) {
+            // the raw rows become the hi | lo fragments IN PLACE (a lane's eight values are its own 16 + 16 bytes), one k-tile per
+            // wave and turn: the conversion leaves the serial chain of the two multiplying waves (it was ~300 cycles per k-tile there)
+            for (int kt = wave; kt < KT; kt += 8) {
+                char* p = smem + kt * 2048 + lane * 16;
+                cvr0[0] = *reinterpret_cast<const float4*>(p);
+                cvr1[0] = *reinterpret_cast<const float4*>(p + 1024);
+                finish_a(A0);
+                *reinterpret_cast<f16x8*>(p) = A0[0][0];
+                *reinterpret_cast<f16x8*>(p + 1024) = A0[0][1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
     const unsigned long long t_loop = (H2_DBG && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
@@ -836,6 +929,104 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     using R0 = std::integral_constant<int, 0>;
     // steady state: whole groups of U stages while the last of them still has a stage to request; what is left is one of two
     // compile-time stage counts (T = NPASS KT is 0 or NPASS modulo U), both starting at POS 0
+    if constexpr (DW) {
+        if constexpr (ACT) {
+            // barrier-free k loop: A fragment of k-tile kt out of LDS, W fragments out of the register ring.  One wave per SIMD
+            // multiplies here, so the refill of a fragment register goes out right behind the LAST product that reads it (one
+            // load behind every MFMA of the second and third product row): the request overlaps the matrix pipe instead of
+            // queueing behind the stage (a block of 8 / 10 loads behind the rows cost 0.18 of 0.71 ms, tools/ab.sh)
+            auto dw_stage = [&](auto j_c, auto guard_c, int u0) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr bool GUARD = decltype(guard_c)::value;
+                constexpr int g = j % NPASS;
+                const int u = u0 + j;
+                if (!GUARD || u < T) {
+                    const int kt = u0 / NPASS + j / NPASS;
+                    if (g == 0 && !(H2_ABL & 4)) {
+                        // the fragment of this k-tile was read a k-tile ago; the next one (clamped: no branch) goes out now
+                        if (H2_DW_APRE) {
+                            A0[0][0] = A1[0][0];
+                            A0[0][1] = A1[0][1];
+                            const char* p = smem + (kt + 1 < KT ? kt + 1 : KT - 1) * 2048 + lane * 16;
+                            A1[0][0] = *reinterpret_cast<const f16x8*>(p);
+                            A1[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
+                        } else {
+                            const char* p = smem + kt * 2048 + lane * 16;
+                            A0[0][0] = *reinterpret_cast<const f16x8*>(p);
+                            A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
+                        }
+                    }
+                    const bool more = (!GUARD || u + PD < T) && !(H2_ABL & 2);
+                    const char* src = is_w[g] + (size_t)(kt + PD / NPASS) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
+                    auto mm = [&](int n, int ap, int bp) {
+                        if (!(H2_ABL & 8)) acc[g][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bb[j][n][bp], A0[0][ap], acc[g][0][n], 0, 0, 0);
+                    };
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) mm(n, 1, 0);                   // lo . hi
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {                              // hi . lo
+                        mm(n, 0, 1);
+                        if (more) Bb[j][n][1] = dw_ld(src + (n * 2 + 1) * 1024);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {                              // hi . hi
+                        mm(n, 0, 0);
+                        if (more) Bb[j][n][0] = dw_ld(src + (n * 2 + 0) * 1024);
+                    }
+                    if constexpr (!GUARD && H2_DW_PIN) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+#pragma unroll
+                        for (int i = 0; i < 2 * NTW; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                }
+            };
+            static_assert(PD % NPASS == 0, "a register slot always holds the same pass");
+            using GN = std::integral_constant<bool, false>;
+            using GY = std::integral_constant<bool, true>;
+            A1[0][0] = *reinterpret_cast<const f16x8*>(smem + lane * 16);
+            A1[0][1] = *reinterpret_cast<const f16x8*>(smem + lane * 16 + 1024);
+            int u0 = 0;
+            for (; u0 + 2 * PD <= T; u0 += PD) {                 // every stage of the group exists and has a successor to request
+                if (LEAD && H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = u0 / NPASS;
+                dw_stage(std::integral_constant<int, 0>{}, GN{}, u0);
+                dw_stage(std::integral_constant<int, 1>{}, GN{}, u0);
+                if constexpr (PD > 2) dw_stage(std::integral_constant<int, 2>{}, GN{}, u0);
+                if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GN{}, u0);
+            }
+            if (LEAD && H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = 1 << 20;     // the warming waves may finish
+            epilogue_operands();
+            for (; u0 < T; u0 += PD) {
+                dw_stage(std::integral_constant<int, 0>{}, GY{}, u0);
+                dw_stage(std::integral_constant<int, 1>{}, GY{}, u0);
+                if constexpr (PD > 2) dw_stage(std::integral_constant<int, 2>{}, GY{}, u0);
+                if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GY{}, u0);
+            }
+        } else if constexpr (H2_DW_AHEAD > 0) {
+            // the six waves that do not multiply warm the L2 with the W stream of this workgroup: the weights of a phase are used
+            // once per launch and arrive from beyond L2; the register ring of the multiplying waves (PD stages) covers ~1 us of
+            // that, not more.  One dword per 128-byte line, H2_DW_AHEAD k-tiles ahead of the multiplying waves at most.
+            const int hi_act = 4 + ((rg_lo + 2) & 3);
+            const int r = wave - (wave > rg_lo ? 1 : 0) - (wave > hi_act ? 1 : 0);      // 0 .. 5
+            const int nline = KT * (H2_W / 128);
+            const int nchunk = (nline + 63) / 64;
+            unsigned sink = 0;
+            for (int c0 = r; c0 < nchunk; c0 += 24) {
+                while ((c0 * 64) / (H2_W / 128) > *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) + H2_DW_AHEAD) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int line = (c0 + 6 * i) * 64 + lane;
+                    if (line < nline) {
+#pragma unroll
+                        for (int g = 0; g < NPASS; ++g) sink ^= *reinterpret_cast<const unsigned*>(is_w[g] + (size_t)line * 128);
+                    }
+                }
+            }
+            asm volatile("" ::"v"(sink));
+        }
+    } else {
     int t = 0;
     for (; t + U - 1 + NST < T; t += U) {
         step(R0{}, std::integral_constant<int, 0>{});
@@ -864,6 +1055,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     } else {
         do tail(tail, std::integral_constant<int, TAIL_B>{}, std::integral_constant<int, 0>{});
         while (TAIL_LOOP && --tail_rep);
+    }
     }
 
     // ------------------------------------------------------------------------------------------ epilogue
@@ -1667,6 +1859,79 @@ __global__ __launch_bounds__(512, 2) void h2_stackn_kernel(const H2StackArgs s) 
     }
 }
 
+// Direct-W form of the 16-row teams (h2d_gemm.hip).  With 16 rows a stage of the ring form is bound by the serial chain of the
+// one wave pair that multiplies -- fragment reads, its DMA requests, a barrier per two stages, both waves on ONE SIMD -- while six
+// waves only move W through LDS for them.  Here the two multiplying waves sit on different SIMDs (wave rg_lo and wave
+// 4 + (rg_lo + 2) % 4), take their W fragments straight from L2 into a register ring and run the k loop without barriers; all
+// eight waves bring the A operand of the 16 rows into LDS once per phase.  Fragments, product order and epilogue are those of the
+// ring form: bitwise the same poses.
+template <int NP>
+__global__ __launch_bounds__(512, 2) void h2_stackd_kernel(const H2StackArgs s) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = s.G, D = s.D;
+    int team, tn;
+    {
+        const int b = blockIdx.x;
+        team = (b & 7) + 8 * ((b >> 3) / G);
+        tn = (b >> 3) % G;
+        if (team >= s.n_teams) return;
+    }
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
+    h2_publish_xcd(s, team, tid);
+    int plain = 0, seen = 0;
+    __syncthreads();
+    const int n_units = s.n_tiles * 4;
+    for (int unit0 = team; unit0 < n_units; unit0 += s.n_teams) {
+        unsigned need = 0;
+        for (int ph = 0; ph < s.n_phases; ++ph, need += G) {
+            if (!seen && ph >= 2) {
+                plain = __builtin_amdgcn_readfirstlane(h2_team_on_one_xcd(s, team));
+                seen = 1;
+            }
+            int wvp = wave_s, unit = unit0, tnp = tn;
+            asm volatile("" : "+s"(wvp), "+s"(unit), "+s"(tnp));
+            int tidp = wvp * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(tidp));
+            const int wv = wvp;
+            const int tile = unit >> 2, rg_lo = unit & 3;
+            const bool act = wv < 4 ? wv == rg_lo : (wv & 3) == ((rg_lo + 2) & 3);
+            unsigned* ctr = s.counters + H2_CTR_PER_TILE * tile + rg_lo;
+            const char* const* w = s.w[ph >> 2];
+            bool ok = true;
+            if (s.inject > 0 && ph == s.inject && unit == 0 && tnp == 0) return;     // fault injection (test hook)
+#define H2D_PHASE(EPI, LNF, NPASS)                                                                                                          \
+    do {                                                                                                                                    \
+        if (wv < 4) ok = act ? h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, true, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1)   \
+                             : h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, false, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1); \
+        else ok = act ? h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, true, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1)   \
+                      : h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, false, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1); \
+    } while (0)
+            switch (ph & 3) {
+                case 0: {
+                    H2Args a = h2_args_qkv<NP>(s, w[0], D, G, plain);
+                    H2D_PHASE(H2_EPI_ATT, true, 3);
+                    break;
+                }
+                case 2: {
+                    H2Args a = h2_args_fc1<NP>(s, w[2], D, G, plain);
+                    H2D_PHASE(H2_EPI_GELU, true, 2);
+                    break;
+                }
+                default: {
+                    const bool fc2 = (ph & 3) == 3;
+                    H2Args a = h2_args_res<NP>(s, fc2 ? w[3] : w[1], fc2, D, G, plain);
+                    H2D_PHASE(H2_EPI_RES, false, 1);
+                    break;
+                }
+            }
+#undef H2D_PHASE
+            if (!ok) return;
+        }
+    }
+}
+
 // the kernel of the pair form: six steps per block application for fp16x2 operands, every phase on pairs for bf16 operands
 template <int NP>
 static auto h2_pair_kernel() -> void (*)(const H2StackArgs) {
@@ -1680,8 +1945,10 @@ int h2_spin_log2();
 int h2_row_tiles();
 int h2_narrow_mode();
 int h2_write_through_always();
+int h2_direct_w();
 struct H2StackArgs;
 int launch_h2n_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2n_gemm.hip: the row-narrow stack kernel
+int launch_h2d_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2d_gemm.hip: its direct-W form for 16-row teams
 
 // The whole block stack in one launch (both engines).  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands of engine NP;
 // counters: n_tiles arrival counters + 1 error word, zeroed by the caller (the entry kernel of the engine); x16: NP = 1 only.
@@ -1778,7 +2045,8 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     {
         ProfScope prof(MPL_K_GEMM, s);
         rc = MPL_OK;
-        if (a.rgs != 4) rc = launch_h2n_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
+        if (a.rgs == 1 && h2_direct_w()) rc = launch_h2d_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
+        else if (a.rgs != 4) rc = launch_h2n_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
         else if (pairs) hipLaunchKernelGGL(h2_pair_kernel<NP>(), dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         else hipLaunchKernelGGL(h2_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         if (rc == MPL_OK) rc = hip_check_launch();
