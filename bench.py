@@ -240,6 +240,8 @@ def stack_kernel_name(precision, batch, views, D, dev, launches=1):
     if n_tiles > cap:
         return "h2_stack2_kernel<2>"
     cus, G = torch.cuda.get_device_properties(dev).multi_processor_count, D // 136
+    if rpt == 64 and 16 % views == 0 and n_tiles * 4 * G <= cus and (2 * D // 32) * 2048 <= 72 * 1024:
+        return "h2_stackd_kernel<2>"          # 16-row teams, direct-W form (h2d_gemm.hip)
     if rpt == 64 and 16 % views == 0 and n_tiles * 2 * G <= cus:
         return "h2_stackn_kernel<2>"          # row-narrow teams: 16- or 32-row workgroups while they fit one per compute unit
     return "h2_stack_kernel<2>"

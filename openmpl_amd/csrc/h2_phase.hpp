@@ -21,7 +21,6 @@ constexpr int H2_STAGE = H2_A + H2_W;        // 26624
 constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
 constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
 constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
-constexpr int H2_DW_PROG = 96 * 1024;      // direct-W form: progress word (k-tile) of the multiplying waves
 constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
 constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
@@ -33,18 +32,6 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #endif
 #ifndef H2_ABL
 #define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier
-#endif
-#ifndef H2_DW_APRE
-#define H2_DW_APRE 1    // direct-W form: the A fragment is read one k-tile ahead
-#endif
-#ifndef H2_DW_AHEAD
-#define H2_DW_AHEAD 0   // direct-W form: k-tiles the L2 warming of the idle waves may run ahead (0 = none)
-#endif
-#ifndef H2_DW_NT
-#define H2_DW_NT 0
-#endif
-#ifndef H2_DW_PD
-#define H2_DW_PD 4
 #endif
 #ifndef H2_DW_PIN
 #define H2_DW_PIN 1     // direct-W form: pin the MFMA / load interleave of a stage (sched_group_barrier)
@@ -496,12 +483,19 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // ---- DW (direct-W form, 16-row teams): no ring.  The two multiplying waves take their W fragments straight from global
     // memory (L2) into registers, PD stages ahead; the whole A operand of the row group (2 KT KiB) is brought into LDS once,
     // by all eight waves, behind the hand-off.  Same fragments, same product order, same epilogue as the ring form.
-    constexpr int PD = NPASS == 3 ? 3 : H2_DW_PD;
+    // Measured around it (round 5, V = 2 B = 256, stack 0.77 ms in the ring form -> 0.63 ms here; tools/ab.sh):
+    //  * the k loop runs at 36 B/clk of W per CU -- the rate of TWO waves' vector loads whatever their depth (PD 2 = PD 4;
+    //    tools/micro/l2_stream.hip: 2 waves 36, 4 or 8 waves 52-64 B/clk out of L2);
+    //  * W through an LDS ring kept filled by the six idle waves, one barrier per stage (no vector loads in the multiplying
+    //    waves): 0.62-0.64 ms; two slots per wave direct and the rest through that ring: 0.66 ms -- the stage of every form is
+    //    430-490 cycles against 240 of its 15 MFMAs (tools/chain_phase.py): barrier round trip, fragment reads and more issue
+    //    slots than the MFMA gaps hide;
+    //  * nt loads 0.88 ms (every team then fetches W from beyond L2); L2 warming by the idle waves (one dword per line, by
+    //    vector load or LDS-DMA) 0.86 ms: a sparse request costs the L1 as much as a full line; W served out of a hot L2 (every
+    //    phase re-reading one 1.2 MB window): -2 %, and 0 for the whole-tile kernels -- the stream from beyond L2 is not the bound.
+    constexpr int PD = NPASS == 3 ? 3 : 4;
     f16x8 Bb[DW && ACT ? PD : 1][NTW][2];
-    auto dw_ld = [](const char* p) -> f16x8 {
-        if (H2_DW_NT) return __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
-        return *reinterpret_cast<const f16x8*>(p);
-    };
+    auto dw_ld = [](const char* p) -> f16x8 { return *reinterpret_cast<const f16x8*>(p); };
     auto dw_fetch = [&](auto j_c, int kt) {
         constexpr int j = decltype(j_c)::value;
         if constexpr (DW && ACT) {
@@ -516,9 +510,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     if constexpr (DW) {
         dw_fetch(std::integral_constant<int, 0>{}, 0);
         dw_fetch(std::integral_constant<int, 1>{}, 1 / NPASS);
-        if constexpr (PD > 2) dw_fetch(std::integral_constant<int, 2>{}, 2 / NPASS);
+        dw_fetch(std::integral_constant<int, 2>{}, 2 / NPASS);
         if constexpr (PD == 4) dw_fetch(std::integral_constant<int, 3>{}, 3 / NPASS);
-        static_assert(PD >= 2 && PD <= 4, "register ring depth");
     } else {
         issue_w();
     }
@@ -576,7 +569,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // pass-1 stage never uses -- an ordinary load here would make the compiler drain the WHOLE queue (it cannot see the
     // LDS-DMA requests in it) in front of the first conversion.  NPASS == 1 (one-GEMM launches only): ordinary loads.
     // RT = 2: into the 20 KiB its ring of 4 x 34 KiB leaves free below the vector region (every stage of a one-pass GEMM carries A)
-    constexpr unsigned ST_LDS = DW ? 72u * 1024u : (RT == 2 ? NST * STAGE : STAGE);           // + 1 KiB per wave, + 8 KiB per row tile
+    constexpr unsigned ST_LDS = DW ? 72u * 1024u /* above the A operand: the launcher keeps 2 KiB x k-tiles below it */ : (RT == 2 ? NST * STAGE : STAGE);           // + 1 KiB per wave, + 8 KiB per row tile
     constexpr bool ST_DMA = NPASS >= 2 || RT == 2;
     static_assert(RT == 1 || ST_LDS + 16384 <= H2_VEC, "statistics rows overlap the epilogue vectors");
     float4 st_raw[4];
@@ -720,7 +713,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     {   // stage 0 (P2: the stages 0, 1, 2) landed; later ones may stay in flight: of the stages 1 .. 5, 5 / 2 / 1 carry A for
         // NPASS 1 / 2 / 3, of the stages 3, 4 (P2) 2 / 1 / 1
         if constexpr (DW) {
-            if (H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = 0;
             // the A operand and the statistics rows landed (DMA); the W fragments of the first PD stages are ordinary loads the
             // compiler counts itself: the NTW * 2 * PD of them were requested BEFORE the DMA pieces, so they have landed too
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -944,17 +936,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                     const int kt = u0 / NPASS + j / NPASS;
                     if (g == 0 && !(H2_ABL & 4)) {
                         // the fragment of this k-tile was read a k-tile ago; the next one (clamped: no branch) goes out now
-                        if (H2_DW_APRE) {
-                            A0[0][0] = A1[0][0];
-                            A0[0][1] = A1[0][1];
-                            const char* p = smem + (kt + 1 < KT ? kt + 1 : KT - 1) * 2048 + lane * 16;
-                            A1[0][0] = *reinterpret_cast<const f16x8*>(p);
-                            A1[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
-                        } else {
-                            const char* p = smem + kt * 2048 + lane * 16;
-                            A0[0][0] = *reinterpret_cast<const f16x8*>(p);
-                            A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
-                        }
+                        // (reading it one k-tile ahead: 0 -- and two spilled registers)
+                        const char* p = smem + kt * 2048 + lane * 16;
+                        A0[0][0] = *reinterpret_cast<const f16x8*>(p);
+                        A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
                     }
                     const bool more = (!GUARD || u + PD < T) && !(H2_ABL & 2);
                     const char* src = is_w[g] + (size_t)(kt + PD / NPASS) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
@@ -986,45 +971,20 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             static_assert(PD % NPASS == 0, "a register slot always holds the same pass");
             using GN = std::integral_constant<bool, false>;
             using GY = std::integral_constant<bool, true>;
-            A1[0][0] = *reinterpret_cast<const f16x8*>(smem + lane * 16);
-            A1[0][1] = *reinterpret_cast<const f16x8*>(smem + lane * 16 + 1024);
             int u0 = 0;
             for (; u0 + 2 * PD <= T; u0 += PD) {                 // every stage of the group exists and has a successor to request
-                if (LEAD && H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = u0 / NPASS;
                 dw_stage(std::integral_constant<int, 0>{}, GN{}, u0);
                 dw_stage(std::integral_constant<int, 1>{}, GN{}, u0);
-                if constexpr (PD > 2) dw_stage(std::integral_constant<int, 2>{}, GN{}, u0);
+                dw_stage(std::integral_constant<int, 2>{}, GN{}, u0);
                 if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GN{}, u0);
             }
-            if (LEAD && H2_DW_AHEAD > 0) *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) = 1 << 20;     // the warming waves may finish
             epilogue_operands();
             for (; u0 < T; u0 += PD) {
                 dw_stage(std::integral_constant<int, 0>{}, GY{}, u0);
                 dw_stage(std::integral_constant<int, 1>{}, GY{}, u0);
-                if constexpr (PD > 2) dw_stage(std::integral_constant<int, 2>{}, GY{}, u0);
+                dw_stage(std::integral_constant<int, 2>{}, GY{}, u0);
                 if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GY{}, u0);
             }
-        } else if constexpr (H2_DW_AHEAD > 0) {
-            // the six waves that do not multiply warm the L2 with the W stream of this workgroup: the weights of a phase are used
-            // once per launch and arrive from beyond L2; the register ring of the multiplying waves (PD stages) covers ~1 us of
-            // that, not more.  One dword per 128-byte line, H2_DW_AHEAD k-tiles ahead of the multiplying waves at most.
-            const int hi_act = 4 + ((rg_lo + 2) & 3);
-            const int r = wave - (wave > rg_lo ? 1 : 0) - (wave > hi_act ? 1 : 0);      // 0 .. 5
-            const int nline = KT * (H2_W / 128);
-            const int nchunk = (nline + 63) / 64;
-            unsigned sink = 0;
-            for (int c0 = r; c0 < nchunk; c0 += 24) {
-                while ((c0 * 64) / (H2_W / 128) > *reinterpret_cast<volatile int*>(smem + H2_DW_PROG) + H2_DW_AHEAD) __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int line = (c0 + 6 * i) * 64 + lane;
-                    if (line < nline) {
-#pragma unroll
-                        for (int g = 0; g < NPASS; ++g) sink ^= *reinterpret_cast<const unsigned*>(is_w[g] + (size_t)line * 128);
-                    }
-                }
-            }
-            asm volatile("" ::"v"(sink));
         }
     } else {
     int t = 0;
@@ -2045,7 +2005,7 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     {
         ProfScope prof(MPL_K_GEMM, s);
         rc = MPL_OK;
-        if (a.rgs == 1 && h2_direct_w()) rc = launch_h2d_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
+        if (a.rgs == 1 && h2_direct_w() && h2_ksteps(2 * D, 2) * 2048 <= 72 * 1024) rc = launch_h2d_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
         else if (a.rgs != 4) rc = launch_h2n_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
         else if (pairs) hipLaunchKernelGGL(h2_pair_kernel<NP>(), dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         else hipLaunchKernelGGL(h2_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);

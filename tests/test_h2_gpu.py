@@ -311,7 +311,8 @@ def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
     """Launches that would leave compute units idle split every 64-row tile into sub-tiles of 16 or 32 rows, one team each
     (h2_stackn_kernel; VERDICT r4 item 2: the reference's shipped call shape, 256 frames x 2 views, is 8 tiles = 32 workgroups).
     The waves of a sub-tile run the full-tile code on their row groups, so the poses must be bitwise those of the whole-tile teams:
-    forced both ways and both widths (mpl_x3_stack_mode bits 5, 6) -- ragged tiles, the LDS attention of 8 views, width 1088, and
+    forced both ways and both widths (mpl_x3_stack_mode bits 5, 6), the 16-row teams in their direct-W form (h2_stackd_kernel: the
+    default) and in the ring form (bit 4) -- ragged tiles, the LDS attention of 8 views, width 1088, and
     five views (60-row tiles: no narrow form exists, the switch must be a no-op) included."""
     lib = cabi.load()
     m, g = _model(name)
@@ -319,7 +320,7 @@ def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
     P, R, Cn = _big_inputs(B, V, 321)
     outs = {}
     try:
-        for tag, bits in (("whole", 1 << 5), ("rows32", 2 << 5), ("rows16", 3 << 5), ("auto", 0)):
+        for tag, bits in (("whole", 1 << 5), ("rows32", 2 << 5), ("rows16", 3 << 5), ("rows16ring", (3 << 5) | 16), ("auto", 0)):
             cabi.check(lib.mpl_x3_stack_mode(bits | 8), "stack mode")           # bit 3: the team kernels also at <= 32 rows
             with torch.no_grad():
                 outs[tag] = m(P, rays=R, centers=Cn)
@@ -327,7 +328,7 @@ def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
     finally:
         cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
     assert torch.isfinite(outs["whole"]).all()
-    for tag in ("rows32", "rows16", "auto"):
+    for tag in ("rows32", "rows16", "rows16ring", "auto"):
         assert torch.equal(outs["whole"], outs[tag]), "%s changed results: max |d| = %.3e" % (tag, float((outs["whole"] - outs[tag]).abs().max()))
     if B <= 100:
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}

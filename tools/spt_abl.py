@@ -1,5 +1,5 @@
 """Time of the fused SPT kernel with one phase compiled... switched off at a time (MPL_SPT_ABL bits: 8 qkv, 1 attention, 32 proj,
-64 fc1 + GELU, 128 fc2; results are garbage): python tools/spt_abl.py"""
+64 fc1 + GELU, 128 fc2; results are garbage): [SPT_V=2 SPT_B=256] python tools/spt_abl.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
@@ -7,15 +7,16 @@ if len(sys.argv) > 1:
     import ctypes as C, torch, time
     from bench import build_model, make_batch, model_flags
     from openmpl_amd import cabi
-    m = build_model(model_flags("chosen", 4, 12), torch.device("cuda"))
-    P, R, Cn = make_batch(1024, 4, "cuda", 1)
+    V, B0 = int(os.environ.get("SPT_V", "4")), int(os.environ.get("SPT_B", "1024"))
+    m = build_model(model_flags("chosen", V, 12), torch.device("cuda"))
+    P, R, Cn = make_batch(B0, V, "cuda", 1)
     lib = cabi.load()
     dev, B, P, R, Cn = m._check_inputs(P, R, Cn)
     ent = m._marshal(dev)
     inp = cabi.Inputs(); inp.batch = B
-    for v in range(4):
+    for v in range(V):
         inp.poses[v], inp.rays[v], inp.centers[v] = P[v].data_ptr(), R[v].data_ptr(), Cn[v].data_ptr()
-    xs = torch.zeros(B * 4, 544, device="cuda")
+    xs = torch.zeros(B * V, 544, device="cuda")
     run = lambda: cabi.check(lib.mpl_spt_tokens(C.byref(ent["cfg"]), C.byref(ent["weights"]), C.byref(inp), xs.data_ptr(), torch.cuda.current_stream().cuda_stream), "spt")
     for _ in range(5): run()
     torch.cuda.synchronize(); t0 = time.perf_counter()
