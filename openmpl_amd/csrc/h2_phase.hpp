@@ -21,7 +21,6 @@ constexpr int H2_STAGE = H2_A + H2_W;        // 26624
 constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
 constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
 constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
-constexpr int H2_DW_XF = 80 * 1024;        // direct-W form, attention: the k / v accumulators on their way to the q wave (20 KiB)
 constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
 constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
@@ -292,12 +291,8 @@ __device__ __forceinline__ bool h2_att_in_registers(int ntok, int hd, int rpt) {
 
 template <int EPI, bool LNF, int NPASS, int NTW, bool CHAIN, int WC, int RT = 1, int NP = 2, bool ACT = true, bool DW = false>
 __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, int wave, int slot0, int tm, int tn,
-                                         unsigned* chain, unsigned chain_need, bool arrive = true, int rg_lo = 0, int rgs = 4, int pp = 0) {
+                                         unsigned* chain, unsigned chain_need, bool arrive = true, int rg_lo = 0, int rgs = 4) {
     static_assert(ACT || (RT == 1 && CHAIN), "loader-only waves exist in the row-narrow stack only");
-    // DW with two or three passes: one multiplying wave PER PASS and column half (pass pp of this wave), each with its own W
-    // stream and its accumulators in acc[0]; see the k loop
-    constexpr bool PP = DW && NPASS >= 2;
-    constexpr int NPL = PP ? 1 : NPASS;          // passes a multiplying wave walks
     static_assert(!DW || (RT == 1 && CHAIN && NP == 2), "direct-W form: 16-row teams of the fp16x2 stack");
     constexpr int ABYTES = RT * 4 * H2_RG;       // A bytes per stage
     constexpr int STAGE = ABYTES + H2_W;
@@ -498,23 +493,13 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     //  * nt loads 0.88 ms (every team then fetches W from beyond L2); L2 warming by the idle waves (one dword per line, by
     //    vector load or LDS-DMA) 0.86 ms: a sparse request costs the L1 as much as a full line; W served out of a hot L2 (every
     //    phase re-reading one 1.2 MB window): -2 %, and 0 for the whole-tile kernels -- the stream from beyond L2 is not the bound.
-    constexpr int PD = NPL == 3 ? 3 : 4;
-    const char* dw_w[NPL];
-    if constexpr (PP) {
-        dw_w[0] = is_w[0];
-#pragma unroll
-        for (int g = 1; g < NPASS; ++g)
-            if (g == pp) dw_w[0] = is_w[g];
-    } else {
-#pragma unroll
-        for (int g = 0; g < NPL; ++g) dw_w[g] = is_w[g];
-    }
+    constexpr int PD = NPASS == 3 ? 3 : 4;
     f16x8 Bb[DW && ACT ? PD : 1][NTW][2];
     auto dw_ld = [](const char* p) -> f16x8 { return *reinterpret_cast<const f16x8*>(p); };
     auto dw_fetch = [&](auto j_c, int kt) {
         constexpr int j = decltype(j_c)::value;
         if constexpr (DW && ACT) {
-            const char* src = dw_w[j % NPL] + (size_t)kt * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
+            const char* src = is_w[j % NPASS] + (size_t)kt * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
                 Bb[j][n][0] = dw_ld(src + (n * 2 + 0) * 1024);
@@ -524,9 +509,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     };
     if constexpr (DW) {
         dw_fetch(std::integral_constant<int, 0>{}, 0);
-        dw_fetch(std::integral_constant<int, 1>{}, 1 / NPL);
-        dw_fetch(std::integral_constant<int, 2>{}, 2 / NPL);
-        if constexpr (PD == 4) dw_fetch(std::integral_constant<int, 3>{}, 3 / NPL);
+        dw_fetch(std::integral_constant<int, 1>{}, 1 / NPASS);
+        dw_fetch(std::integral_constant<int, 2>{}, 2 / NPASS);
+        if constexpr (PD == 4) dw_fetch(std::integral_constant<int, 3>{}, 3 / NPASS);
     } else {
         issue_w();
     }
@@ -938,20 +923,17 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // compile-time stage counts (T = NPASS KT is 0 or NPASS modulo U), both starting at POS 0
     if constexpr (DW) {
         if constexpr (ACT) {
-            // barrier-free k loop: A fragment of k-tile kt out of LDS, W fragments out of the register ring.  PP (phases of two or
-            // three passes): this wave multiplies ONE pass (pp) into acc[0]; four (fc1) or six (qkv) waves share the phase, so the W
-            // stream of the workgroup comes in through all SIMDs and the k loop is KT stages long instead of NPASS KT.  One wave per SIMD
+            // barrier-free k loop: A fragment of k-tile kt out of LDS, W fragments out of the register ring.  One wave per SIMD
             // multiplies here, so the refill of a fragment register goes out right behind the LAST product that reads it (one
             // load behind every MFMA of the second and third product row): the request overlaps the matrix pipe instead of
             // queueing behind the stage (a block of 8 / 10 loads behind the rows cost 0.18 of 0.71 ms, tools/ab.sh)
-            const int TL = NPL * KT;                 // stages of this wave: PP: one per k-tile (its own pass)
             auto dw_stage = [&](auto j_c, auto guard_c, int u0) {
                 constexpr int j = decltype(j_c)::value;
                 constexpr bool GUARD = decltype(guard_c)::value;
-                constexpr int g = j % NPL;
+                constexpr int g = j % NPASS;
                 const int u = u0 + j;
-                if (!GUARD || u < TL) {
-                    const int kt = u0 / NPL + j / NPL;
+                if (!GUARD || u < T) {
+                    const int kt = u0 / NPASS + j / NPASS;
                     if (g == 0 && !(H2_ABL & 4)) {
                         // the fragment of this k-tile was read a k-tile ago; the next one (clamped: no branch) goes out now
                         // (reading it one k-tile ahead: 0 -- and two spilled registers)
@@ -959,8 +941,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                         A0[0][0] = *reinterpret_cast<const f16x8*>(p);
                         A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
                     }
-                    const bool more = (!GUARD || u + PD < TL) && !(H2_ABL & 2);
-                    const char* src = dw_w[g] + (size_t)(kt + PD / NPL) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
+                    const bool more = (!GUARD || u + PD < T) && !(H2_ABL & 2);
+                    const char* src = is_w[g] + (size_t)(kt + PD / NPASS) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
                     auto mm = [&](int n, int ap, int bp) {
                         if (!(H2_ABL & 8)) acc[g][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bb[j][n][bp], A0[0][ap], acc[g][0][n], 0, 0, 0);
                     };
@@ -986,18 +968,18 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                     }
                 }
             };
-            static_assert(PD % NPL == 0, "a register slot always holds the same pass");
+            static_assert(PD % NPASS == 0, "a register slot always holds the same pass");
             using GN = std::integral_constant<bool, false>;
             using GY = std::integral_constant<bool, true>;
             int u0 = 0;
-            for (; u0 + 2 * PD <= TL; u0 += PD) {                 // every stage of the group exists and has a successor to request
+            for (; u0 + 2 * PD <= T; u0 += PD) {                 // every stage of the group exists and has a successor to request
                 dw_stage(std::integral_constant<int, 0>{}, GN{}, u0);
                 dw_stage(std::integral_constant<int, 1>{}, GN{}, u0);
                 dw_stage(std::integral_constant<int, 2>{}, GN{}, u0);
                 if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GN{}, u0);
             }
             epilogue_operands();
-            for (; u0 < TL; u0 += PD) {
+            for (; u0 < T; u0 += PD) {
                 dw_stage(std::integral_constant<int, 0>{}, GY{}, u0);
                 dw_stage(std::integral_constant<int, 1>{}, GY{}, u0);
                 dw_stage(std::integral_constant<int, 2>{}, GY{}, u0);
@@ -1041,8 +1023,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // acc[p][rt][n][r] = scaled C[row_l of row tile rt][colbase(p) + 16 tile(n) + 4 kq + r];   value = acc * sc_n (* 1 / a_scale) + c_n
     auto tile_of = [&](int n) -> int { return h2_slot_tile(slot0 + n); };
     auto value4 = [&](int p, int rt, int n, float (&v)[4]) {
-        // PP: the pass of this wave sits in acc[0] (attention: the q wave has collected k and v into acc[1], acc[2] by then)
-        const int pa = (PP && EPI != H2_EPI_ATT) ? 0 : p;
         const int cl = 16 * tile_of(n) + 4 * kq;
         const bool ok = cl + 3 < BN;
         const float* vecs = reinterpret_cast<const float*>(smem + H2_VEC) + p * 2 * BN + (ok ? cl : 0);
@@ -1054,9 +1034,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             // explicit fused operations: the same roundings in every instantiation (chain phases and one-GEMM launches agree
             // bitwise); sc_n, 1 / a_scale are powers of two: their product is exact
             float t;
-            if constexpr (NP == 2) t = fmaf(acc[pa][rt][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
-            else if constexpr (LNF) t = fmaf(cv_a[rt], fmaf(-cv_b[rt], s4[r], acc[pa][rt][n][r]), c4[r]);
-            else t = acc[pa][rt][n][r] + c4[r];
+            if constexpr (NP == 2) t = fmaf(acc[p][rt][n][r], LNF ? s4[r] : s4[r] * ainv, c4[r]);
+            else if constexpr (LNF) t = fmaf(cv_a[rt], fmaf(-cv_b[rt], s4[r], acc[p][rt][n][r]), c4[r]);
+            else t = acc[p][rt][n][r] + c4[r];
             if (EPI == H2_EPI_GELU) t = gelu_as(t);
             v[r] = ok ? t : 0.f;
         }
@@ -1069,27 +1049,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     };
     unsigned long long t_st = 0;
 
-    // PP, attention: the k and v waves hand their accumulators to the q wave of their column half through LDS (exact copies:
-    // the sums are those of the one-wave form) and then only meet the barriers
-    if constexpr (PP && EPI == H2_EPI_ATT) {
-        if constexpr (ACT) {
-            f32x4* xf = reinterpret_cast<f32x4*>(smem + H2_DW_XF) + (slot0 ? 2 : 0) * H2_T0 * 64 + lane;
-            if (pp != 0) {
-#pragma unroll
-                for (int n = 0; n < NTW; ++n) xf[((pp - 1) * H2_T0 + n) * 64] = acc[0][0][n];
-            }
-            __syncthreads();
-            if (pp == 0) {
-#pragma unroll
-                for (int g = 1; g < NPASS; ++g)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[g][0][n] = xf[((g - 1) * H2_T0 + n) * 64];
-            }
-        } else {
-            __syncthreads();
-        }
-    }
-    auto shadow_epilogue = [&]() {
+    if constexpr (!ACT) {
         // loader-only wave of a row-narrow workgroup: nothing to compute or store; it meets the barriers of the epilogue below
         // (and lends its threads to the LDS form of the attention, which every thread of the workgroup walks)
         if constexpr (EPI == H2_EPI_ATT) {
@@ -1110,12 +1070,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 __syncthreads();
             }
         }
-    };
-    if constexpr (!ACT) {
-        shadow_epilogue();
-    } else {
-    if (PP && EPI == H2_EPI_ATT && pp != 0) {
-        shadow_epilogue();
     } else {
     if constexpr (EPI == H2_EPI_ATT) {
       if (h2_att_in_registers(a.att_ntok, a.att_hd, a.rpt)) {
@@ -1356,8 +1310,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         for (int rt = 0; rt < RT; ++rt) {
             char* cbase = a.C2 + (((size_t)tm * RT + rt) * 4 + rg) * h2_ksteps(N, NP) * H2_RG;
 #pragma unroll
-            for (int pi = 0; pi < (NPASS == 2 && !PP ? 2 : 1); ++pi) {
-                const int p = PP ? pp : pi;              // PP: this wave's pass only
+            for (int p = 0; p < (NPASS == 2 ? 2 : 1); ++p) {
                 const int g_out = colbase(p) / BN;
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
@@ -1450,7 +1403,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                     }
             }
         }
-    }
     }
     }
     if (CHAIN) {
@@ -1904,21 +1856,17 @@ __global__ __launch_bounds__(512, 2) void h2_stackd_kernel(const H2StackArgs s) 
             asm volatile("" : "+v"(tidp));
             const int wv = wvp;
             const int tile = unit >> 2, rg_lo = unit & 3;
-            // the multiplying waves: pass p of the column slots 0..4 on wave p, of the slots 5..8 on wave 4 + (p + 2) % 4 -- one
-            // per SIMD in the two-pass phase, waves 0 and 6 in the one-pass phases
-            const int npass = (ph & 3) == 0 ? 3 : ((ph & 3) == 2 ? 2 : 1);
-            const int pp = wv < 4 ? wv : ((wv & 3) + 2) & 3;
-            const bool act = pp < npass;
+            const bool act = wv < 4 ? wv == rg_lo : (wv & 3) == ((rg_lo + 2) & 3);
             unsigned* ctr = s.counters + H2_CTR_PER_TILE * tile + rg_lo;
             const char* const* w = s.w[ph >> 2];
             bool ok = true;
             if (s.inject > 0 && ph == s.inject && unit == 0 && tnp == 0) return;     // fault injection (test hook)
 #define H2D_PHASE(EPI, LNF, NPASS)                                                                                                          \
     do {                                                                                                                                    \
-        if (wv < 4) ok = act ? h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, true, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1, pp)   \
-                             : h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, false, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1, pp); \
-        else ok = act ? h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, true, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1, pp)   \
-                      : h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, false, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1, pp); \
+        if (wv < 4) ok = act ? h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, true, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1)   \
+                             : h2_phase<EPI, LNF, NPASS, H2_T0, true, H2_WC0, 1, NP, false, true>(a, smem, tidp, wv, 0, tile, tnp, ctr, need, true, rg_lo, 1); \
+        else ok = act ? h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, true, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1)   \
+                      : h2_phase<EPI, LNF, NPASS, NT - H2_T0, true, H2_WC1, 1, NP, false, true>(a, smem, tidp, wv, H2_T0, tile, tnp, ctr, need, true, rg_lo, 1); \
     } while (0)
             switch (ph & 3) {
                 case 0: {
