@@ -490,6 +490,13 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     //    waves): 0.62-0.64 ms; two slots per wave direct and the rest through that ring: 0.66 ms -- the stage of every form is
     //    430-490 cycles against 240 of its 15 MFMAs (tools/chain_phase.py): barrier round trip, fragment reads and more issue
     //    slots than the MFMA gaps hide;
+    //  * more multiplying waves (one per pass and column half in the qkv / fc1 phases, accumulators handed to the q wave through
+    //    LDS; a helper wave per column half in the one-pass phases): bitwise, 0.62 ms.  The W stream of the workgroup then comes in
+    //    at 48-63 B/clk, i.e. at the 64 B/clk of a compute unit's vector L1: the k loops of a block application need 38 k cycles
+    //    at that rate and take 46 k (two multiplying waves: 52 k); the other half of its ~100 k cycles are the phase entries
+    //    (hand-off, A operand, LayerNorm conversion: 27 k) and the epilogues (25 k).  Every 16-row workgroup streams ALL of W for
+    //    its 136 columns: only narrower column groups (more compute units per row tile) would cut that, and they would change
+    //    the slice statistics and the attention sums, i.e. the bits;
     //  * nt loads 0.88 ms (every team then fetches W from beyond L2); L2 warming by the idle waves (one dword per line, by
     //    vector load or LDS-DMA) 0.86 ms: a sparse request costs the L1 as much as a full line; W served out of a hot L2 (every
     //    phase re-reading one 1.2 MB window): -2 %, and 0 for the whole-tile kernels -- the stream from beyond L2 is not the bound.

@@ -1,6 +1,6 @@
 """Per-phase time line of the persistent stack kernel (chain mode) at the headline shape: the stack is stopped after
 phase p (mpl_x3_stack_mode) so that the per-wave stamps of mpl_x3_debug_buffer are those of phase p.
-[ENGINE=h2|b1] python tools/chain_phase.py [D] [n_blocks] [M] [n_tok]   (library built with -DH2_DBG=1)"""
+[ENGINE=h2|b1] python tools/chain_phase.py [D] [n_blocks] [M] [n_tok]   (library built with -DH2_DBG=1; DBG2=1 with -DH2_DBG=2: the prologue split per wave)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -41,6 +41,16 @@ for stop in range(4 * (NB - 1) - 1, 4 * NB + 1):
     print("stop %2d %-9s waves %4d | entry->loop %6.0f (min %6.0f max %6.0f) | k loop %7.0f (%5.0f/stage, %d stages) | epilogue %6.0f | drain %5.0f | total %7.0f | DMA wait/stage %4.0f  bar/stage %4.0f"
           % (stop, names[ph], len(t), (loop - ent).mean(), (loop - ent).min(), (loop - ent).max(), (epi - loop).mean(), (epi - loop).mean() / nst, nst,
              (sto - epi).mean(), (end - sto).mean(), (end - ent).mean(), t[:, 5].mean() / nst, t[:, 6].mean() / nst))
+    if os.environ.get("DBG2"):
+        # library built with -DH2_DBG=2: columns 5, 6 are the stamps behind the hand-off wait and behind the landing of the first
+        # operands; one line per wave index (multiplying and loader waves of the direct-W form differ)
+        for w in range(8):
+            u = t[np.arange(len(t)) % 8 == w]
+            if len(u):
+                print("      wave %d: entry->hand-off %6.0f | ->operands landed %6.0f | ->k loop %6.0f | k loop %7.0f | epilogue %6.0f | drain %5.0f"
+                      % (w, (u[:, 5] - u[:, 0]).mean(), (u[:, 6] - u[:, 5]).mean(), (u[:, 1] - u[:, 6]).mean(), (u[:, 2] - u[:, 1]).mean(),
+                         (u[:, 3] - u[:, 2]).mean(), (u[:, 4] - u[:, 3]).mean()))
+        continue
     # by wave role (rows of t are (block, wave): wave = index % 8): per stage DMA wait | lgkm + barrier | MFMA rows | everything else
     for role, sel in (("waves 0-3 (5 tiles, A pieces)", np.arange(len(t)) % 8 < 4), ("waves 4-7 (4 tiles)", np.arange(len(t)) % 8 >= 4)):
         if sel.sum() and t.shape[1] > 7:
