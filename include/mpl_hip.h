@@ -220,8 +220,11 @@ int mpl_x3_debug_buffer(void *device_buffer);
  * tiles walk PAIRS of tiles, h2_stack2_kernel; bf16: always one tile at a time), 1 / 2 = force the one- / two-tile stage
  * (bitwise the same poses; bf16: h2_stackp_kernel, pairs in every phase).  Bit 3: no
  * small-batch engine (sm_stack.hip: stacks of at most 32 token rows run every GEMM on the whole chip with grid barriers in
- * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bits 8.. = stop after that
- * many GEMM phases (tools/chain_phase.py). */
+ * between, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bit 4: the 16-row teams in
+ * the ring form (h2_stackn_kernel) instead of the direct-W form (h2_stackd_kernel).  Bits 5-6: row-narrow teams: 0 = by the
+ * shape of the launch, 1 = never, 2 / 3 = 32- / 16-row workgroups wherever legal.  Bit 7: write-through hand-off stores also
+ * for teams that sit on one XCD.  Every one of these forms yields bitwise the same poses.  Bits 8.. = stop after that many
+ * GEMM phases (tools/chain_phase.py). */
 int mpl_x3_stack_mode(int one_launch_per_gemm);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
