@@ -12,7 +12,7 @@ for V in (2, 4):
     m = MultiView_MPL(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=12, num_views=V, pose_3d_emb_learnable=True)
     detrng.fill_module_(m, seed=11)
     m = m.to(dev).eval()
-    for B in (1, 32, 256, 512, 1024, 2048, 4096, 8192):
+    for B in (1, 16, 32, 64, 128, 256, 384, 512, 640, 768, 1024, 1536, 2048, 4096, 8192):
         p, r, c = detrng.make_inputs(B, V, seed=1)
         P, R, C = ([torch.from_numpy(x).to(dev) for x in l] for l in (p, r, c))
         row = []

@@ -1,5 +1,5 @@
 """Determinism soak of the pipelined GEMM kernels: the same forward many times, every output bitwise equal to the first
-(a race in the DMA ring / barrier protocol would show up as a rare mismatch).  python tools/soak.py [repeats]"""
+(a race in the DMA ring / barrier protocol would show up as a rare mismatch).  [SOAK_ONLY=narrow] python tools/soak.py [repeats]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from openmpl_amd.multiview_mpl import MultiView_MPL  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 bad = 0
-for flags, B in ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024),
+SHAPES = ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024),
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True, confidence_input_as_third=True, input_rays_as_token=True,
                        multiple_spatial_blocks=True, add_3D_pos_encoding_to_rays=True), 1024),
                  (dict(num_views=8, depth=2, pose_3d_emb_learnable=True), 1000),       # 125 row tiles: pairs, the last one half empty
@@ -23,7 +23,16 @@ for flags, B in ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024)
                  (dict(num_views=8, depth=12, pose_3d_emb_learnable=True), 2),
                  (dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 8),         # 32 rows: two row tiles per weight fragment
                  (dict(num_views=3, depth=2, pose_3d_emb_learnable=True, confidence_as_attention_uncertainty_weight=True), 7),
-                 (dict(num_views=6, depth=2, pose_3d_emb_learnable=True, FPT_blocks_view_keypoint_tokens=True), 100)):
+                 (dict(num_views=6, depth=2, pose_3d_emb_learnable=True, FPT_blocks_view_keypoint_tokens=True), 100),
+                 # row-narrow teams: 16-row workgroups in the direct-W form (h2_stackd_kernel), 32-row ones in the ring form
+                 (dict(num_views=2, depth=12, pose_3d_emb_learnable=True), 256),
+                 (dict(num_views=4, depth=2, pose_3d_emb_learnable=True), 100),
+                 (dict(num_views=8, depth=2, pose_3d_emb_learnable=True), 61),
+                 (dict(num_views=16, depth=2, pose_3d_emb_learnable=True), 24),
+                 (dict(num_views=2, depth=2, pose_3d_emb_learnable=True), 640))
+if os.environ.get("SOAK_ONLY") == "narrow":
+    SHAPES = SHAPES[-5:]
+for flags, B in SHAPES:
     m = MultiView_MPL(**flags).cuda().eval()
     detrng.fill_module_(m, seed=21)
     V = flags["num_views"]
