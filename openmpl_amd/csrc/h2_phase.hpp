@@ -31,7 +31,7 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #define H2_DBG 0
 #endif
 #ifndef H2_ABL
-#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier
+#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier, 64 W out of a hot L2
 #endif
 #ifndef H2_DW_PIN
 #define H2_DW_PIN 1     // direct-W form: pin the MFMA / load interleave of a stage (sched_group_barrier)
@@ -377,6 +377,23 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     for (int rt = 0; rt < RT; ++rt)
         is_a[rt] = RAWX ? reinterpret_cast<const char*>(a.X + (size_t)m0 * a.ldx)
                        : a.A2 + (((size_t)tm * RT + rt) * 4 + (wave & 3)) * KT * H2_RG;
+    // bench-only (H2_ABL & 64): every phase streams the same 16 k-tiles of one column group of the first operand of the launch,
+    // i.e. W out of a hot L2 (results are garbage): what the stream from beyond L2 costs
+    int hotc[NPASS];
+#pragma unroll
+    for (int g = 0; g < NPASS; ++g) {
+        hotc[g] = 0;
+        if (H2_ABL & 64) is_w[g] = a.W2 + (size_t)tn * 17 * H2_W;
+    }
+    auto adv_w = [&](int g) {
+        is_w[g] += H2_W;
+        if (H2_ABL & 64) {
+            if (++hotc[g] == (NP == 2 ? 16 : 8)) {
+                hotc[g] = 0;
+                is_w[g] -= (NP == 2 ? 16 : 8) * H2_W;
+            }
+        }
+    };
     auto w_pieces = [&](const char* src, unsigned dst) {
         if constexpr (w_cnt == 0) return;
         asm volatile(
@@ -427,7 +444,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         for (int g = 0; g < NPASS; ++g)
             if (g == iw_g) {
                 w_pieces(is_w[g], lds0 + iw_slot + (unsigned)(ABYTES + w_first * 1024));
-                is_w[g] += H2_W;
+                adv_w(g);
             }
         if (++iw_g == NPASS) iw_g = 0;
         dma_m0_restore(keep);
@@ -452,7 +469,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         constexpr bool with_a = decltype(ai_c)::value;
         const unsigned keep = dma_m0_save();
         w_pieces(is_w[g], lds0 + slot + (unsigned)(ABYTES + w_first * 1024));
-        is_w[g] += H2_W;
+        adv_w(g);
         if (with_a && HAS_A) a_pieces(slot);
         dma_m0_restore(keep);
     };
@@ -499,7 +516,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     //    the slice statistics and the attention sums, i.e. the bits;
     //  * nt loads 0.88 ms (every team then fetches W from beyond L2); L2 warming by the idle waves (one dword per line, by
     //    vector load or LDS-DMA) 0.86 ms: a sparse request costs the L1 as much as a full line; W served out of a hot L2 (every
-    //    phase re-reading one 1.2 MB window): -2 %, and 0 for the whole-tile kernels -- the stream from beyond L2 is not the bound.
+    //    phase re-reading one 1.2 MB window, H2_ABL 64): -2 %, 0 for the whole-tile kernels, -7 % for bf16 at depth 12 -- the stream from beyond L2 is not the bound.
     constexpr int PD = NPASS == 3 ? 3 : 4;
     f16x8 Bb[DW && ACT ? PD : 1][NTW][2];
     auto dw_ld = [](const char* p) -> f16x8 { return *reinterpret_cast<const f16x8*>(p); };
@@ -1483,6 +1500,7 @@ __device__ __forceinline__ const float* h2_trailer(const char* w2, int N, int K)
 // attention / GELU outputs leave under the static scales so.  NP = 1: x16 is the A operand, proj / fc2 rewrite it beside x.
 template <int NP>
 __device__ __forceinline__ H2Args h2_args_qkv(const H2StackArgs& s, const char* w, int D, int G, int plain) {
+    if (H2_ABL & 64) w = s.w[0][0];
     const float* v = h2_trailer<NP>(w, 3 * D, D);
     return H2Args{NP == 1 ? s.x16 : nullptr, NP == 1 ? nullptr : s.x, D, w, v, v + 3 * D, s.stats, nullptr, NP == 1 ? nullptr : v + 12 * D,
                   nullptr, 0, nullptr, 0, s.att2, nullptr, s.M, 3 * D, D, s.rpt, s.n_tiles, G, s.eps, s.n_tok, D / s.heads, s.dbg,
@@ -1490,6 +1508,7 @@ __device__ __forceinline__ H2Args h2_args_qkv(const H2StackArgs& s, const char* 
 }
 template <int NP>
 __device__ __forceinline__ H2Args h2_args_fc1(const H2StackArgs& s, const char* w, int D, int G, int plain) {
+    if (H2_ABL & 64) w = s.w[0][0];
     const float* v = h2_trailer<NP>(w, 2 * D, D);
     return H2Args{NP == 1 ? s.x16 : nullptr, NP == 1 ? nullptr : s.x, D, w, v, v + 2 * D, s.stats, nullptr, NP == 1 ? nullptr : v + 8 * D,
                   nullptr, 0, nullptr, 0, s.hid2, nullptr, s.M, 2 * D, D, s.rpt, s.n_tiles, G, s.eps, 0, 0, s.dbg, s.err_ws, s.err_host,
@@ -1500,6 +1519,7 @@ __device__ __forceinline__ H2Args h2_args_fc1(const H2StackArgs& s, const char* 
 // the fingerprints): nothing to take out here
 template <int NP>
 __device__ __forceinline__ H2Args h2_args_res(const H2StackArgs& s, const char* w, bool fc2, int D, int G, int plain) {
+    if (H2_ABL & 64) w = s.w[0][0];
     const int K = fc2 ? 2 * D : D;
     const float* v = h2_trailer<NP>(w, D, K);
     return H2Args{fc2 ? s.hid2 : s.att2, nullptr, 0, w, v, v + D, nullptr, nullptr, nullptr, s.x, D, s.x, D, NP == 1 ? s.x16 : nullptr,

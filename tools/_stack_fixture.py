@@ -13,7 +13,7 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 
 def make_block(D, seed=0):
     g = torch.Generator().manual_seed(seed)
-    nbytes, pack = (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2) if ENGINE == "h2" else (lib.mpl_pack_b1_bytes, lib.mpl_pack_b1)
+    nbytes, pack = (lib.mpl_pack_h2_bytes, lib.mpl_pack_h2) if ENGINE == "h2" else (lib.mpl_pack_bf16_bytes, lib.mpl_pack_bf16)
 
     def operand(N, K, ln, in_scale=None):
         W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
