@@ -221,30 +221,20 @@ def timed_steps(model, batches, steps, warmup, lifter=None, global_batch=None):
         return time.perf_counter() - t0
 
 
-def stack_kernel_name(precision, batch, views, D, dev, launches=1):
-    """Name of the kernel that runs the FPT block stack, by the rules of the library (api.hip block_stack_impl,
-    h2_phase.hpp h2_launch_stack): row tiles of (64 // V) * V rows, teams of D / 136 workgroups, as many teams as the device
-    has compute units for."""
+def stack_kernel_name(precision, batch, views, D, dev, launches=1, heads=8, n_apps=13):
+    """Name of the kernel that runs the FPT block stack: the library reports the form it takes for this shape on this device
+    (`mpl_block_stack_form`: ONE rule, csrc/h2_phase.hpp h2_stack_form + csrc/api.hip block_stack_impl; pinned by
+    tests/test_h2_gpu.py::test_the_library_reports_the_form_of_a_stack_launch)."""
     import torch
-    if precision == "fp32_mfma" or D % 136:
-        return "ln_gemm_ng_kernel"
-    if precision == "fp32" and batch * views <= 32 and launches == 1:
-        return "sm_stack_kernel"
-    if launches != 1:
-        return "h2_gemm_kernel"
-    rpt = (64 // views) * views
-    n_tiles = -(-(batch * views) // rpt)
-    cap = torch.cuda.get_device_properties(dev).multi_processor_count // (D // 136)
-    if precision == "bf16":
-        return "h2_stack_kernel<1>"           # bf16 operands: one row tile per team step (the pair form is not faster)
-    if n_tiles > cap:
-        return "h2_stack2_kernel<2>"
-    cus, G = torch.cuda.get_device_properties(dev).multi_processor_count, D // 136
-    if rpt == 64 and 16 % views == 0 and n_tiles * 4 * G <= cus and (2 * D // 32) * 2048 <= 72 * 1024:
-        return "h2_stackd_kernel<2>"          # 16-row teams, direct-W form (h2d_gemm.hip)
-    if rpt == 64 and 16 % views == 0 and n_tiles * 2 * G <= cus:
-        return "h2_stackn_kernel<2>"          # row-narrow teams: 16- or 32-row workgroups while they fit one per compute unit
-    return "h2_stack_kernel<2>"
+    from openmpl_amd import cabi
+    parts = {"fp32": 2, "bf16": 1}.get(precision, 0)
+    if launches != 1 and parts:
+        return cabi.FORM_KERNELS[cabi.FORM_PER_GEMM]
+    with torch.cuda.device(dev):
+        form = cabi.load().mpl_block_stack_form(batch, views, D, heads, n_apps, parts, 0)
+    cabi.check(form if form < 0 else 0, "mpl_block_stack_form")
+    name = cabi.FORM_KERNELS[form]
+    return name % parts if "%d" in name else name
 
 
 def stack_roofline(model, flags, batch, batches, precision, dev, n_prof=20):

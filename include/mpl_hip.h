@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 11
+#define MPL_HIP_ABI_VERSION 12
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -226,6 +226,23 @@ int mpl_x3_debug_buffer(void *device_buffer);
  * for teams that sit on one XCD.  Every one of these forms yields bitwise the same poses.  Bits 8.. = stop after that many
  * GEMM phases (tools/chain_phase.py). */
 int mpl_x3_stack_mode(int one_launch_per_gemm);
+
+/* Which kernel form mpl_block_stack(_ex) takes for a stack of this shape on the current device, by the library's own rule
+ * (csrc/h2_phase.hpp h2_stack_form, csrc/api.hip block_stack_impl): for benchmarks that name the kernel they time and tests that
+ * pin the rule.  operand_parts: 2 = the blocks carry mpl_pack_h2 operands, 1 = mpl_pack_bf16, 0 = neither; `flags` as
+ * mpl_config.flags (MPL_F_NO_SMALL_STACK).  The small-batch engine additionally needs the nn.Linear tensors of the blocks
+ * (the query assumes they are there).  Negative = MPL_E_*.  Every team form yields bitwise the same poses. */
+enum {
+    MPL_FORM_UNPACKED = 0,        /* no packed operands: one launch per GEMM on the fp32-MFMA engine (ln_gemm.hip / the D = 32 path) */
+    MPL_FORM_SMALL = 1,           /* sm_stack_kernel: at most 32 token rows, every GEMM on the whole chip */
+    MPL_FORM_TEAMS = 2,           /* h2_stack_kernel<NP>: one 64-row tile per team step */
+    MPL_FORM_PAIRS = 3,           /* h2_stack2_kernel<2> (A/B: h2_stackp_kernel<1>): pairs of row tiles */
+    MPL_FORM_ROWS32 = 4,          /* h2_stackn_kernel<2>: 32-row teams */
+    MPL_FORM_ROWS16 = 5,          /* h2_stackn_kernel<2>: 16-row teams, ring form (A/B, or A operand too large for LDS) */
+    MPL_FORM_ROWS16_DIRECT = 6,   /* h2_stackd_kernel<2>: 16-row teams, direct-W form */
+    MPL_FORM_PER_GEMM = 7         /* h2_gemm_kernel: one launch per GEMM (mpl_x3_stack_mode bit 0) */
+};
+int mpl_block_stack_form(int n_seq, int n_tok, int D, int heads, int n_apps, int operand_parts, unsigned flags);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

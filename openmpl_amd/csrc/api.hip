@@ -565,6 +565,27 @@ int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const 
     return launch_h2_gemm(nullptr, a2, sc + 2, W2, false, nullptr, 0.f, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
 }
 
+int mpl_block_stack_form(int n_seq, int n_tok, int D, int heads, int n_apps, int operand_parts, unsigned flags) {
+    if (n_seq <= 0 || n_tok <= 0 || D <= 0 || heads <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS || operand_parts < 0 || operand_parts > 2)
+        return MPL_E_INVALID;
+    if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
+    const int M = n_seq * n_tok;
+    // the same questions, in the same order, as block_stack_impl asks
+    const int np = (h2_attention_fusable(n_tok, D, heads) && h2_shape_ok(D, 2 * D)) ? operand_parts : 0;
+    const bool per_gemm = g_x3_per_gemm.load(std::memory_order_relaxed);
+    if ((np == 0 || np == 2) && !(flags & MPL_F_NO_SMALL_STACK) && sm_stack_enabled() && !per_gemm && g_x3_stop.load() == 0 &&
+        sm_stack_ok(M, D, n_tok, heads, n_apps, n_apps < 24 ? n_apps : 24)) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MPL_E_LAUNCH;
+        if (3 * D / 16 <= cus) return MPL_FORM_SMALL;
+    }
+    if (np == 0) return MPL_FORM_UNPACKED;
+    if (per_gemm) return MPL_FORM_PER_GEMM;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+    return h2_stack_form_code(M, D, n_tok, np, cus);
+}
+
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);
     g_x3_stop.store(one_launch_per_gemm >> 8);

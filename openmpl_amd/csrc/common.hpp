@@ -142,6 +142,7 @@ void h2_set_narrow(int mode);              // row-narrow teams: 0 by shape, 1 ne
 constexpr int H2_CTR_PER_TILE = 4;
 constexpr int H2_XCC_WORDS = 256;          // behind the arrival counters: one word per team, the set of XCDs its workgroups run on
 inline int h2_err_index(int n_tiles) { return H2_CTR_PER_TILE * n_tiles + H2_XCC_WORDS; }      // the error word of the call (the last word)
+int h2_stack_form_code(int M, int D, int n_tok, int np, int cus);      // h2_gemm.hip: MPL_FORM_* of a team launch of this shape
 void h2_set_direct_w(int on);              // A/B switch: 0 = the 16-row teams run the ring form (h2n_gemm.hip) instead of the direct-W form
 void h2_set_write_through(int always);     // A/B switch: 1 = write-through hand-off stores whatever the placement of a team
 // The persistent block-stack kernels (h2_stack_kernel and its pair forms, sm_stack_kernel) need every workgroup resident: the library

@@ -436,6 +436,15 @@ int launch_h2_qkv_attention(const float* X, const unsigned short* W2, const floa
 
 // The whole block stack in one launch.  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands; counters: n_tiles arrival
 // counters + 1 error word, zeroed by the caller (launch_h2_entry).
+// the form a stack launch of this shape takes (MPL_FORM_* of mpl_hip.h), np = operand parts (2 = fp16x2, 1 = bf16)
+int h2_stack_form_code(int M, int D, int n_tok, int np, int cus) {
+    const H2Form f = np == 2 ? h2_stack_form<2>(M, D, n_tok, cus) : h2_stack_form<1>(M, D, n_tok, cus);
+    if (f.pairs) return MPL_FORM_PAIRS;
+    if (f.rgs == 2) return MPL_FORM_ROWS32;
+    if (f.rgs == 1) return f.direct ? MPL_FORM_ROWS16_DIRECT : MPL_FORM_ROWS16;
+    return MPL_FORM_TEAMS;
+}
+
 int launch_h2_stack(float* x, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* att2, unsigned short* hid2, float* stats, unsigned* counters, float eps, int stop_after,
                     hipStream_t s) {

@@ -1937,6 +1937,44 @@ struct H2StackArgs;
 int launch_h2n_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2n_gemm.hip: the row-narrow stack kernel
 int launch_h2d_stack(const H2StackArgs& a, int grid, hipStream_t s);      // h2d_gemm.hip: its direct-W form for 16-row teams
 
+// THE rule by which a stack launch picks its kernel form, in one place: h2_launch_stack follows it and mpl_block_stack_form
+// (api.hip) reports it (bench.py names the kernel after it, tests pin it).  By the shape of the launch, the device and the A/B
+// switches only; every form yields bitwise the same poses.
+struct H2Form {
+    int pairs;      // teams walk pairs of row tiles (two-tile stage)
+    int rgs;        // row groups per workgroup: 4 = whole tiles, 2 / 1 = 32- / 16-row teams
+    int direct;     // the 16-row teams in their direct-W form (h2d_gemm.hip)
+};
+template <int NP>
+static H2Form h2_stack_form(int M, int D, int n_tok, int cus) {
+    H2Form f{0, 4, 0};
+    const int rpt = h2_rows_per_tile(n_tok), n_tiles = (M + rpt - 1) / rpt, G = D / BN;
+    const int cap = cus / G;
+    // more row tiles than teams the chip holds: teams walk PAIRS of row tiles with the two-tile stage.  h2_row_tiles(): A/B switch
+    // (mpl_x3_stack_mode bits 1, 2).  bf16 operands (NP = 1): one tile at a time by default -- the pair form of every phase
+    // (h2_stackp_kernel) was built and measured in round 5 and is NOT faster (V = 8, B = 1024: 332 against 311 us for depth 2):
+    // the 34-KiB stage leaves a ring of four, too shallow for the flight time of the A strips, and a wave's product rows and its
+    // requests do not overlap
+    const int force = h2_row_tiles();
+    f.pairs = (force == 2 || (force == 0 && NP == 2 && n_tiles > cap)) ? 1 : 0;
+    // row-narrow teams (fp16x2 operands): when whole-tile teams would leave compute units idle, a tile is split into sub-tiles of
+    // 16 or 32 rows -- the narrowest form that still gives every workgroup a compute unit of its own.  Sequences must not straddle
+    // row groups: 16 a multiple of n_tok
+    if (NP == 2 && !f.pairs && rpt == BM && (16 % n_tok) == 0) {
+        const int nm = h2_narrow_mode();
+        if (nm == 3) f.rgs = 1;
+        else if (nm == 2) f.rgs = 2;
+        else if (nm == 0 && force == 0) {
+            if (n_tiles * 4 * G <= cus) f.rgs = 1;
+            else if (n_tiles * 2 * G <= cus) f.rgs = 2;
+        }
+    }
+    // 16-row teams: the direct-W form while the A operand of the widest GEMM (fc2, K = 2 D: 2 KiB per k-tile) fits below the
+    // statistics rows in LDS (mpl_x3_stack_mode bit 4: the ring form, for A/B)
+    f.direct = (f.rgs == 1 && h2_direct_w() && h2_ksteps(2 * D, 2) * 2048 <= 72 * 1024) ? 1 : 0;
+    return f;
+}
+
 // The whole block stack in one launch (both engines).  `ops` = n_apps x {qkv, proj, fc1, fc2} packed operands of engine NP;
 // counters: n_tiles arrival counters + 1 error word, zeroed by the caller (the entry kernel of the engine); x16: NP = 1 only.
 template <int NP>
@@ -1975,27 +2013,10 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     a.G = D / BN;
     const int cap = resident[dev].load() / a.G;
     if (cap < 1) return MPL_E_UNSUPPORTED;
-    // more row tiles than teams the chip holds: teams walk PAIRS of row tiles with the two-tile stage (by the shape of the launch
-    // only; the poses are bitwise the same in both forms).  g_h2_rt: A/B switch (mpl_x3_stack_mode bits 1, 2)
-    const int force = h2_row_tiles();
-    // bf16 operands (NP = 1): one tile at a time by default -- the pair form of every phase (h2_stackp_kernel) was built and
-    // measured in round 5 and is NOT faster (V = 8, B = 1024: 332 against 311 us for depth 2): the 34-KiB stage leaves a ring of
-    // four, too shallow for the flight time of the A strips, and a wave's product rows and its requests do not overlap
-    const bool pairs = force == 2 || (force == 0 && NP == 2 && a.n_tiles > cap);
+    const H2Form form = h2_stack_form<NP>(M, D, n_tok, resident[dev].load());
+    const bool pairs = form.pairs != 0;
     const int n_units = pairs ? (a.n_tiles + 1) / 2 : a.n_tiles;
-    // row-narrow teams (fp16x2 operands): when whole-tile teams would leave compute units idle, a tile is split into sub-tiles of
-    // 16 or 32 rows (h2_stackn_kernel) -- the narrowest form that still gives every workgroup a compute unit of its own; by the
-    // shape of the launch only, and bitwise the same poses.  Sequences must not straddle row groups: 16 a multiple of n_tok.
-    a.rgs = 4;
-    if (NP == 2 && !pairs && a.rpt == BM && (16 % n_tok) == 0) {
-        const int nm = h2_narrow_mode(), cus = resident[dev].load();
-        if (nm == 3) a.rgs = 1;
-        else if (nm == 2) a.rgs = 2;
-        else if (nm == 0 && force == 0) {
-            if (a.n_tiles * 4 * a.G <= cus) a.rgs = 1;
-            else if (a.n_tiles * 2 * a.G <= cus) a.rgs = 2;
-        }
-    }
+    a.rgs = form.rgs;
     // plain hand-off stores for teams on one XCD: everywhere but the two-tile stage of the fp16x2 engine.  Same-process A/B
     // (tools/wt_ab.py): bf16 engine -2 .. -4 % stack time (its stage is bound by the L2 -> LDS path, half of its bytes are
     // activations), row-narrow teams -2 %, headline fp16x2 stack 0 % in time but 9 % less fabric traffic (2.43 -> 2.22 GB per
@@ -2032,7 +2053,7 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
     {
         ProfScope prof(MPL_K_GEMM, s);
         rc = MPL_OK;
-        if (a.rgs == 1 && h2_direct_w() && h2_ksteps(2 * D, 2) * 2048 <= 72 * 1024) rc = launch_h2d_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
+        if (form.direct) rc = launch_h2d_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
         else if (a.rgs != 4) rc = launch_h2n_stack(a, ((a.n_teams + 7) / 8) * 8 * a.G, s);
         else if (pairs) hipLaunchKernelGGL(h2_pair_kernel<NP>(), dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);
         else hipLaunchKernelGGL(h2_stack_kernel<NP>, dim3(((a.n_teams + 7) / 8) * 8 * a.G), dim3(512), H2_LDS_BYTES, s, a);

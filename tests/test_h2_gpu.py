@@ -336,6 +336,42 @@ def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
         _assert_close(outs["rows16"], ref, name + " 16-row teams vs fp64 oracle")
 
 
+def test_the_library_reports_the_form_of_a_stack_launch():
+    """`mpl_block_stack_form` is the launch rule itself (h2_phase.hpp h2_stack_form is what h2_launch_stack follows): the shapes the
+    documentation names land on the kernels it names, the A/B switches move them, and the per-call flag keeps small batches on the
+    team kernels.  (256 compute units assumed: MI355X.)"""
+    lib = cabi.load()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the expected forms are those of a 256-CU device")
+    form = lambda B, V, parts=2, flags=0, D=544: lib.mpl_block_stack_form(B, V, D, 8, 13, parts, flags)
+    try:
+        cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+        assert form(1, 2) == cabi.FORM_SMALL and form(8, 4) == cabi.FORM_SMALL           # <= 32 token rows
+        assert form(1, 2, flags=cabi.F_NO_SMALL_STACK) == cabi.FORM_ROWS16_DIRECT         # batch-invariant bits: team kernels
+        assert form(1, 2, parts=1) == cabi.FORM_TEAMS                                     # an explicit bf16 request keeps its engine
+        assert form(256, 2) == cabi.FORM_ROWS16_DIRECT                                    # the shipped call shape: 8 tiles x 4 sub-tiles x 4
+        assert form(256, 4) == cabi.FORM_ROWS16_DIRECT and form(512, 2) == cabi.FORM_ROWS16_DIRECT      # 16 tiles
+        assert form(640, 2) == cabi.FORM_ROWS32 and form(512, 4) == cabi.FORM_ROWS32      # 17 .. 32 tiles
+        assert form(1024, 4) == cabi.FORM_TEAMS                                           # headline: 64 tiles = 64 teams
+        assert form(1024, 8) == cabi.FORM_PAIRS and form(1024, 8, parts=1) == cabi.FORM_TEAMS           # 128 tiles; bf16: one tile at a time
+        assert form(100, 5) == cabi.FORM_TEAMS                                            # 60-row tiles: no narrow form
+        assert form(64, 2, D=1088) == cabi.FORM_ROWS16                                    # K = 2176: the A operand does not fit, ring form
+        assert form(256, 2, parts=0) == cabi.FORM_UNPACKED and form(256, 2, D=512) == cabi.FORM_UNPACKED
+        assert form(0, 2) == cabi.E_INVALID if hasattr(cabi, "E_INVALID") else form(0, 2) < 0
+        cabi.check(lib.mpl_x3_stack_mode(16), "stack mode")
+        assert form(256, 2) == cabi.FORM_ROWS16
+        cabi.check(lib.mpl_x3_stack_mode(1 << 5), "stack mode")
+        assert form(256, 2) == cabi.FORM_TEAMS
+        cabi.check(lib.mpl_x3_stack_mode(2 << 1), "stack mode")
+        assert form(1024, 4) == cabi.FORM_PAIRS
+        cabi.check(lib.mpl_x3_stack_mode(1), "stack mode")
+        assert form(1024, 4) == cabi.FORM_PER_GEMM and form(1, 2) == cabi.FORM_PER_GEMM
+        cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")
+        assert form(1, 2) == cabi.FORM_ROWS16_DIRECT
+    finally:
+        cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
+
+
 @pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 512), ("chosen_v4_b8_l2", 48), ("chosen_v4_b8_l2", 1), ("full_v4_b8_l2", 200),
                                     ("chosen_v5_b19_l2", 100), ("chosen_v31_b2_l12", 9), ("chosen_v8_b4_l2", 37), ("chosen_v2_b1_l12", 97)])
 def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
