@@ -117,6 +117,12 @@ def test_shared_library_exports_every_symbol_declared_in_header():
     assert lib.mpl_hip_abi_version() == cabi.ABI_VERSION
     lib.mpl_hip_error_string.restype = ctypes.c_char_p
     assert b"workspace" in lib.mpl_hip_error_string(-3)
+    # the MPL_FORM_* codes of mpl_block_stack_form and the flag bits: the binding's constants are the header's
+    forms = dict((n, int(v)) for n, v in re.findall(r"\bMPL_FORM_([A-Z0-9_]+)\s*=\s*(\d+)", header))
+    assert forms and all(getattr(cabi, "FORM_" + n) == v for n, v in forms.items()) and set(cabi.FORM_KERNELS) == set(forms.values())
+    assert int(re.search(r"#define\s+MPL_F_NO_SMALL_STACK\s+\(1u\s*<<\s*(\d+)\)", header).group(1)) == cabi.F_NO_SMALL_STACK.bit_length() - 1
+    lib.mpl_block_stack_form.restype = ctypes.c_int
+    assert lib.mpl_block_stack_form(0, 2, 544, 8, 13, 2, 0) < 0                   # invalid arguments are refused before any device query
 
 
 def test_workspace_query_and_struct_sizes_without_gpu():
