@@ -21,6 +21,7 @@ constexpr int H2_STAGE = H2_A + H2_W;        // 26624
 constexpr int H2_NST = 6;                    // ring depth (159744 B of LDS, one workgroup per CU)
 constexpr int H2_VEC = H2_NST * H2_STAGE;    // the 4 KiB above the ring: epilogue vectors [pass][c | sc][136] of a phase
 constexpr int H2_LDS_BYTES = H2_VEC + 4096;  // = 160 KiB
+constexpr int H2_DW_RES = 80 * 1024;       // direct-W form: the residual rows of the two multiplying waves (9 KiB)
 constexpr int H2_FAIL = H2_VEC + 4092;       // last word of the LDS: "a wait of this workgroup was lost"
 constexpr int H2_T0 = 5;
 constexpr int H2_MAX_WGS = 1024;
@@ -531,6 +532,23 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             }
         }
     };
+    if constexpr (DW && EPI == H2_EPI_RES && ACT) {
+        // the residual rows of this wave's outputs (fp32 rows this workgroup wrote two phases ago: beyond L2 by now, ~3.5 k
+        // cycles away) by LDS-DMA, one KiB per column tile, requested FIRST: they do not depend on the partners, so they fly
+        // during the hand-off; no register is held for them across the k loop (as ordinary loads near its end they cost its
+        // first tail stage 3.5 k cycles), and the wait in front of the loop covers them
+        const unsigned keep_r = dma_m0_save();
+        const float* rb = a.R + (size_t)m0 * a.ldr;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            int c = 16 * h2_slot_tile(slot0 + n) + 4 * kq;
+            c = c + 3 < BN ? c : 0;
+            const unsigned off = (unsigned)(((size_t)(row[0] - m0) * a.ldr + n0 + c) * 4);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1"
+                         : : "v"(off), "s"(rb), "s"(lds0 + (unsigned)(H2_DW_RES + ((slot0 ? H2_T0 : 0) + n) * 1024)) : "memory");
+        }
+        dma_m0_restore(keep_r);
+    }
     if constexpr (DW) {
         dw_fetch(std::integral_constant<int, 0>{}, 0);
         dw_fetch(std::integral_constant<int, 1>{}, 1 / NPASS);
@@ -640,7 +658,12 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     // residual of this lane's outputs (fp32 rows this workgroup wrote itself two phases ago, or a previous launch wrote)
     float4 rv[RT][NTW];
     auto epilogue_operands = [&]() {
-        if (EPI == H2_EPI_RES) {
+        if constexpr (EPI == H2_EPI_RES && DW) {
+            // direct-W form: the residual rows were brought into LDS behind the hand-off (see there), a lane's 16 bytes per tile
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+                rv[0][n] = *reinterpret_cast<const float4*>(smem + H2_DW_RES + ((slot0 ? H2_T0 : 0) + n) * 1024 + lane * 16);
+        } else if (EPI == H2_EPI_RES) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -951,64 +974,88 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             // multiplies here, so the refill of a fragment register goes out right behind the LAST product that reads it (one
             // load behind every MFMA of the second and third product row): the request overlaps the matrix pipe instead of
             // queueing behind the stage (a block of 8 / 10 loads behind the rows cost 0.18 of 0.71 ms, tools/ab.sh)
-            auto dw_stage = [&](auto j_c, auto guard_c, int u0) {
-                constexpr int j = decltype(j_c)::value;
-                constexpr bool GUARD = decltype(guard_c)::value;
-                constexpr int g = j % NPASS;
-                const int u = u0 + j;
-                if (!GUARD || u < T) {
-                    const int kt = u0 / NPASS + j / NPASS;
-                    if (g == 0 && !(H2_ABL & 4)) {
-                        // the fragment of this k-tile was read a k-tile ago; the next one (clamped: no branch) goes out now
-                        // (reading it one k-tile ahead: 0 -- and two spilled registers)
-                        const char* p = smem + kt * 2048 + lane * 16;
-                        A0[0][0] = *reinterpret_cast<const f16x8*>(p);
-                        A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
-                    }
-                    const bool more = (!GUARD || u + PD < T) && !(H2_ABL & 2);
-                    const char* src = is_w[g] + (size_t)(kt + PD / NPASS) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
-                    auto mm = [&](int n, int ap, int bp) {
-                        if (!(H2_ABL & 8)) acc[g][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bb[j][n][bp], A0[0][ap], acc[g][0][n], 0, 0, 0);
-                    };
+            // JJ = position of the stage behind u0 (a multiple of PD): register slot JJ % PD, pass JJ % NPASS; MORE = a stage PD
+            // further on exists and is requested.  Everything is a compile-time number -- also in the tail, whose length is one
+            // of PD .. 2 PD - 1: behind a run-time branch the compiler waits for ALL loads in flight (the tail stages of the first
+            // version took 600-1 300 cycles against 420 of a steady one: ~2.7 k cycles per phase, tools-side stamps, round 5)
+            auto dw_stage = [&](auto jj_c, auto more_c, int u0) {
+                constexpr int JJ = decltype(jj_c)::value;
+                constexpr bool MORE = decltype(more_c)::value;
+                constexpr int j = JJ % PD, g = JJ % NPASS;
+                const int kt = u0 / NPASS + JJ / NPASS;
+                if (g == 0 && !(H2_ABL & 4)) {
+                    // (reading the fragment one k-tile ahead: 0 -- and two spilled registers)
+                    const char* p = smem + kt * 2048 + lane * 16;
+                    A0[0][0] = *reinterpret_cast<const f16x8*>(p);
+                    A0[0][1] = *reinterpret_cast<const f16x8*>(p + 1024);
+                }
+                constexpr bool more = MORE && !(H2_ABL & 2);
+                const char* src = is_w[g] + (size_t)(kt + PD / NPASS) * H2_W + (size_t)(slot0 * 2) * 1024 + lane * 16;
+                auto mm = [&](int n, int ap, int bp) {
+                    if (!(H2_ABL & 8)) acc[g][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bb[j][n][bp], A0[0][ap], acc[g][0][n], 0, 0, 0);
+                };
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) mm(n, 1, 0);                   // lo . hi
+                for (int n = 0; n < NTW; ++n) mm(n, 1, 0);                   // lo . hi
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) {                              // hi . lo
-                        mm(n, 0, 1);
-                        if (more) Bb[j][n][1] = dw_ld(src + (n * 2 + 1) * 1024);
-                    }
+                for (int n = 0; n < NTW; ++n) {                              // hi . lo
+                    mm(n, 0, 1);
+                    if constexpr (more) Bb[j][n][1] = dw_ld(src + (n * 2 + 1) * 1024);
+                }
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) {                              // hi . hi
-                        mm(n, 0, 0);
-                        if (more) Bb[j][n][0] = dw_ld(src + (n * 2 + 0) * 1024);
-                    }
-                    if constexpr (!GUARD && H2_DW_PIN) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+                for (int n = 0; n < NTW; ++n) {                              // hi . hi
+                    mm(n, 0, 0);
+                    if constexpr (more) Bb[j][n][0] = dw_ld(src + (n * 2 + 0) * 1024);
+                }
+                if constexpr (more && H2_DW_PIN) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
 #pragma unroll
-                        for (int i = 0; i < 2 * NTW; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        }
+                    for (int i = 0; i < 2 * NTW; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
             };
             static_assert(PD % NPASS == 0, "a register slot always holds the same pass");
-            using GN = std::integral_constant<bool, false>;
-            using GY = std::integral_constant<bool, true>;
+            using YES = std::integral_constant<bool, true>;
             int u0 = 0;
             for (; u0 + 2 * PD <= T; u0 += PD) {                 // every stage of the group exists and has a successor to request
-                dw_stage(std::integral_constant<int, 0>{}, GN{}, u0);
-                dw_stage(std::integral_constant<int, 1>{}, GN{}, u0);
-                dw_stage(std::integral_constant<int, 2>{}, GN{}, u0);
-                if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GN{}, u0);
+                dw_stage(std::integral_constant<int, 0>{}, YES{}, u0);
+                dw_stage(std::integral_constant<int, 1>{}, YES{}, u0);
+                dw_stage(std::integral_constant<int, 2>{}, YES{}, u0);
+                if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, YES{}, u0);
+            }
+            // the tail: R = T - u0 stages are left, PD <= R < 2 PD, R a multiple of NPASS
+            auto tail = [&](auto self, auto r_c, auto jj_c) -> void {
+                constexpr int R = decltype(r_c)::value, JJ = decltype(jj_c)::value;
+                dw_stage(jj_c, std::integral_constant<bool, (JJ + PD < R)>{}, u0);
+                if constexpr (JJ + 1 < R) self(self, r_c, std::integral_constant<int, JJ + 1>{});
+            };
+            using Z = std::integral_constant<int, 0>;
+            const int rest = T - u0;
+            // each tail inside a loop that runs exactly once behind an opaque trip count: with the back edge the accumulators are
+            // loop-carried values that end where they started, which keeps the allocator from renaming them MFMA by MFMA
+            // (out-of-place v_mfma + hundreds of spills; the same device as H2_TAIL_LOOP of the ring form)
+            int tail_rep = 1;
+            asm volatile("" : "+s"(tail_rep));
+            if (rest == PD) {
+                do tail(tail, std::integral_constant<int, PD>{}, Z{}); while (--tail_rep);
+            }
+            if constexpr ((PD + 1) % NPASS == 0) {
+                if (rest == PD + 1) {
+                    do tail(tail, std::integral_constant<int, PD + 1>{}, Z{}); while (--tail_rep);
+                }
+            }
+            if constexpr ((PD + 2) % NPASS == 0) {
+                if (rest == PD + 2) {
+                    do tail(tail, std::integral_constant<int, PD + 2>{}, Z{}); while (--tail_rep);
+                }
+            }
+            if constexpr (PD == 4 && (PD + 3) % NPASS == 0) {
+                if (rest == PD + 3) {
+                    do tail(tail, std::integral_constant<int, PD + 3>{}, Z{}); while (--tail_rep);
+                }
             }
             epilogue_operands();
-            for (; u0 < T; u0 += PD) {
-                dw_stage(std::integral_constant<int, 0>{}, GY{}, u0);
-                dw_stage(std::integral_constant<int, 1>{}, GY{}, u0);
-                dw_stage(std::integral_constant<int, 2>{}, GY{}, u0);
-                if constexpr (PD == 4) dw_stage(std::integral_constant<int, 3>{}, GY{}, u0);
-            }
         }
     } else {
     int t = 0;
