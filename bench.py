@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other configs / engines)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the rank code path (process group + all-gather) even at one GPU")
+    ap.add_argument("--gather", choices=("stream", "overlap"), default="stream",
+                    help="where the per-step RCCL all-gather runs: ordered into the compute stream between the tail kernel of step i "
+                         "and the first kernel of step i+1 (default: nothing competes with the persistent block-stack launch for "
+                         "compute units), or on the process group's stream beside the next forward (rounds 1-5)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_mfma", "bf16"],
                     help="fp32: fp16x2 split-operand GEMMs on the fp16 matrix cores (default); fp32_mfma: native fp32 MFMA; "
                          "bf16: bf16 operands (BASELINE.json configs[2]: use with --views 8 --depth 2 / 12)")
@@ -221,6 +225,23 @@ def timed_steps(model, batches, steps, warmup, lifter=None, global_batch=None):
         return time.perf_counter() - t0
 
 
+MIN_LEG_STEPS, LEG_REGIONS = 20, 5
+
+
+def timed_regions(model, batches, batch, steps=MIN_LEG_STEPS, warmup=5, regions=LEG_REGIONS, lifter=None, global_batch=None):
+    """A secondary measurement done like the headline: `warmup` untimed forwards, then `regions` back-to-back timed regions of
+    `steps` (>= 20) forwards each, every region bracketed by device synchronisations; the MEDIAN region is the number (the first
+    region after a model was built carries clock ramp and cold caches: it is kept, as `first_ms`)."""
+    steps = max(MIN_LEG_STEPS, steps)
+    timed_steps(model, batches, 0, warmup, lifter, global_batch)
+    ms = [timed_steps(model, batches, steps, 0, lifter, global_batch) / steps * 1e3 for _ in range(regions)]
+    first = ms[0]
+    ms.sort()
+    med = ms[len(ms) // 2]
+    return dict(poses_per_s=round(batch / med * 1e3, 1), median_ms=round(med, 4), min_ms=round(ms[0], 4), max_ms=round(ms[-1], 4),
+                first_ms=round(first, 4), regions=regions, steps_per_region=steps, warmup=warmup)
+
+
 def stack_kernel_name(precision, batch, views, D, dev, launches=1, heads=8, n_apps=13):
     """Name of the kernel that runs the FPT block stack: the library reports the form it takes for this shape on this device
     (`mpl_block_stack_form`: ONE rule, csrc/h2_phase.hpp h2_stack_form + csrc/api.hip block_stack_impl; pinned by
@@ -324,7 +345,7 @@ def run_rank(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # backend "nccl" IS RCCL on ROCm
-        lifter = ShardedLifter(model)
+        lifter = ShardedLifter(model, gather=a.gather)
     split = a.precision in ("fp32", "bf16") and model._x3_supported()
     # a few distinct resident batches (per rank: pre-sharded inputs) so that no step can reuse a cached result
     batches = [make_batch(a.batch, a.views, dev, seed=1000 + rank, step=s) for s in range(4)]
@@ -347,8 +368,8 @@ def run_rank(a):
         print(json.dumps(result), file=json_out, flush=True)
 
 
-def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_dist):
-    """The joints x views token grid (17 V tokens of width 32): the dominant kernel is the long-sequence attention
+def kptok_roofline(model, flags, batch, views, batches, n_prof=20):
+    """Roofline entry of the joints x views token grid (17 V tokens of width 32): the dominant kernel is the long-sequence attention
     (token_attention_long_p4_kernel: K / V of one head LDS resident, keys in pairs), a VALU kernel.  Its roofline is the VALU issue
     floor in slots of 2 cycles (one plain wave64 instruction on a SIMD-32): per (query, key) and head the score is 4 FMAs = 2 packed
     instructions of 2 slots each = 4 slots, v_exp_f32 runs at quarter rate = 4 slots, the exponent argument, the running maximum
@@ -356,8 +377,6 @@ def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_
     work and occupies the pipe twice as long, so pairing keys saves instructions, not pipe time -- on 1024 SIMDs x 2.4 GHz."""
     import torch
     from openmpl_amd import cabi
-    from oracle import mpl_oracle
-    n_prof = max(a.steps, 20)
     with torch.no_grad():
         for i in range(3):
             P, R, C = batches[i % len(batches)]
@@ -368,14 +387,14 @@ def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_
             model(P, rays=R, centers=C)
         torch.cuda.synchronize()
         prof = cabi.profile_stop()
-    N, H, apps = 17 * a.views, 8, flags["depth"] + 1
+    N, H = 17 * views, 8
     att_ms, att_n = prof["attention"]
     us = att_ms / max(1, att_n) * 1e3
-    pairs = float(a.batch) * H * N * N                                   # (query, key) pairs per launch
+    pairs = float(batch) * H * N * N                                     # (query, key) pairs per launch
     slots = 15.0
     floor_us = pairs * slots / 64.0 * 2.0 / (1024 * 2.4e9) * 1e6         # wave64 VALU instruction = 2 cycles on a SIMD-32
     flop = pairs * 16.0                                                  # 2 x (4 score + 4 P.V) multiply-adds per pair
-    roof = dict(bound="valu", kernel="token_attention_long_p4_kernel", launches_per_step=att_n // n_prof, launches_timed=att_n,
+    return dict(bound="valu", kernel="token_attention_long_p4_kernel", launches_per_step=att_n // n_prof, launches_timed=att_n,
                 avg_launch_us=round(us, 1), valu_floor_us=round(floor_us, 1), achieved=round(flop / (us * 1e-6) / 1e12, 2),
                 peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(floor_us / us, 4),
                 note="frac = VALU issue floor / measured launch time (15 two-cycle slots per query-key pair and head: 4 score FMAs, "
@@ -383,6 +402,14 @@ def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_
                      "instructions count as two slots); `achieved` = attention FLOP/s against the fp32 vector peak (157.3 TFLOP/s)",
                 kernel_ms_per_step={k: round(t / n_prof, 4) for k, (t, n) in prof.items()},
                 share_of_kernel_time=round(att_ms / sum(t for t, _ in prof.values()), 3), traffic=None)
+
+
+def kptok_report(a, model, flags, batches, dev, world, value, ms_per_step, used_dist):
+    """`--flagset kptok`: the bench line of the joints x views token grid (roofline: kptok_roofline)."""
+    import torch
+    from oracle import mpl_oracle
+    N = 17 * a.views
+    roof = kptok_roofline(model, flags, a.batch, a.views, batches, max(a.steps, 20))
     P, R, C = batches[0]
     nb = min(16, a.batch)
     sub = lambda lst, n: [x[:n].contiguous() for x in lst]
@@ -635,21 +662,29 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                                % ("CMU Panoptic" if a.views == 8 else "Human3.6M", a.views, a.batch,
                                   "bf16" if a.precision == "bf16" else "fp32", a.flagset.upper(), a.depth),
                    "global_batch": world * a.batch,
-                   "parallelism": ("dp%d: pre-sharded batch, 1 async RCCL all_gather of (B/G,17,3) per step" % world)
+                   "parallelism": ("dp%d: pre-sharded batch, 1 RCCL all_gather of (B/G,17,3) per step (%s)" % (world, {
+                       "stream": "ordered into the compute stream between two forwards", "overlap": "async, beside the next forward"}[a.gather]))
                    if used_dist else "single GPU"},
         "roofline": roof, "rooflines": rooflines(roof, extra, a), "cpu_baseline": cpu_base, "parity": parity, "extra": extra,
     }
 
 
 def rooflines(roof, extra, a):
-    """The roofline entries of this run side by side: the headline kernel, the bf16 engine at BASELINE configs[2]'s shape (depth 2
-    and 12) and the small-batch engine at one frame -- each from launches timed in this process."""
-    keys = ("kernel", "bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "frac_useful", "frac_executed")
+    """The roofline entries of this run side by side: the headline kernel and, from launches timed in this process, one entry
+    per secondary leg that stands for a BASELINE config -- FULL, the bf16 engine at configs[2]'s shape (depth 2 and 12), V = 31 with
+    view tokens and with the joints x views grid (configs[4]), the shipped call shape V = 2 B = 256, one frame (configs[0])."""
+    keys = ("kernel", "bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "frac_useful", "frac_executed",
+            "valu_floor_us")
     pick = lambda d, wl: dict({k: d[k] for k in keys if k in d}, workload=wl)
     out = [pick(roof, "V=%d B=%d depth %d %s %s" % (a.views, a.batch, a.depth, a.flagset.upper(), a.precision))]
     for key, wl in (("cmu_v8_depth2", "V=8 B=%d depth 2 CHOSEN bf16" % a.batch), ("cmu_v8_depth12", "V=8 B=%d depth 12 CHOSEN bf16" % a.batch)):
         if key in extra and "bf16_roofline" in extra[key]:
             out.append(pick(extra[key]["bf16_roofline"], wl))
+        if key in extra and "fp32_roofline" in extra[key]:
+            out.append(pick(extra[key]["fp32_roofline"], wl.replace("bf16", "fp32")))
+    for tag, leg in extra.get("legs", {}).items():
+        if "roofline" in leg:
+            out.append(dict(pick(leg["roofline"], leg["workload"]), poses_per_s=leg["timing"]["poses_per_s"]))
     if "v2_b1_roofline" in extra:
         out.append(pick(extra["v2_b1_roofline"], "V=2 B=1 depth %d CHOSEN fp32 (one frame)" % a.depth))
     return out
@@ -657,47 +692,51 @@ def rooflines(roof, extra, a):
 
 def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     """Secondary measurements (single GPU): the other fp32 engine, accuracy of all engines against fp64, the FULL flag
-    set, BASELINE.json configs[2] (V=8, bf16) and configs[4] (V=31), small-batch latency, the PCIe-inclusive rate."""
+    set, BASELINE.json configs[2] (V=8, bf16) and configs[4] (V=31), small-batch latency, the PCIe-inclusive rate.
+    Every throughput leg is timed like the headline (timed_regions: >= 20 steps per region, median of >= 5 regions) and the
+    legs that stand for a BASELINE config carry the roofline entry of their dominant kernel (extra.legs, `rooflines`)."""
     import torch
     from openmpl_amd import detrng
     from openmpl_amd.multiview_mpl import MultiView_MPL
     from oracle import mpl_oracle
     extra = {}
+    legs = {}
     P, R, C = batches[0]
     sub = lambda lst, n: [x[:n].contiguous() for x in lst]
     cpu = lambda lst, n: [x[:n].cpu() for x in lst]
     ref64 = mpl_oracle.forward(sd, flags, cpu(P, nb), cpu(R, nb), cpu(C, nb), dtype=torch.float64)
     e = lambda y: float("%.3e" % mpl_oracle.rel_errors(y.double(), ref64)[0])
     errs = {"hip_" + a.precision: e(got), "reference_fp32_cpu": e(ref)}
-    n_o = max(10, a.steps // 2)
     for other in ("fp32", "fp32_mfma"):                    # the other fp32 engine: rate and distance from fp64
         if other == a.precision:
             continue
         model.set_matmul_precision(other)
-        v_o = a.batch * n_o / timed_steps(model, batches, n_o, 3)
+        t_o = timed_regions(model, batches, a.batch)
         with torch.no_grad():
             got_o = model(sub(P, nb), rays=sub(R, nb), centers=sub(C, nb)).cpu()
-        extra[other + "_poses_per_s"] = round(v_o, 1)
+        extra[other + "_poses_per_s"] = t_o["poses_per_s"]
+        legs[other] = dict(workload="V=%d B=%d depth %d %s %s" % (a.views, a.batch, a.depth, a.flagset.upper(), other), timing=t_o)
         errs["hip_" + other] = e(got_o)
     model.set_matmul_precision(a.precision)
     extra["max_scaled_err_vs_fp64"] = errs
     # secondary: the FULL flag set of hm_0_...yaml (per-view SPT, conf channel, ray tokens, FPT width 1088)
     f2 = model_flags("full", a.views, a.depth)
     m2 = build_model(f2, dev)
-    n2 = max(5, a.steps // 4)
-    v2 = a.batch * n2 / timed_steps(m2, batches, n2, 3)
-    extra["full_flagset_poses_per_s"] = round(v2, 1)
-    extra["full_flagset_tflops"] = round(v2 * mpl_oracle.flop_count(f2) / 1e12, 2)
+    t2 = timed_regions(m2, batches, a.batch)
+    extra["full_flagset_poses_per_s"] = t2["poses_per_s"]
+    extra["full_flagset_tflops"] = round(t2["poses_per_s"] * mpl_oracle.flop_count(f2) / 1e12, 2)
+    legs["full_v%d" % a.views] = dict(workload="V=%d B=%d depth %d FULL fp32" % (a.views, a.batch, a.depth), timing=t2,
+                                      roofline=stack_roofline(m2, f2, a.batch, batches, "fp32", dev))
     del m2
     # BASELINE.json configs[2]: CMU Panoptic shape V=8, batch 1024, bf16 matrix cores (yaml depth 2), with the fp32 run
     # of the same shape and the bf16 deviation from the fp32 reference semantics (reported, not gated)
     f3 = model_flags("chosen", 8, 2)
     m3 = build_model(f3, dev)
     b3 = [make_batch(a.batch, 8, dev, seed=2000, step=s) for s in range(2)]
-    n3 = max(10, a.steps // 2)
-    v32 = a.batch * n3 / timed_steps(m3, b3, n3, 3)
+    t32 = timed_regions(m3, b3, a.batch)
     m3.set_matmul_precision("bf16")
-    v16 = a.batch * n3 / timed_steps(m3, b3, n3, 3)
+    t16 = timed_regions(m3, b3, a.batch)
+    v32, v16 = t32["poses_per_s"], t16["poses_per_s"]
     P3, R3, C3 = b3[0]
     with torch.no_grad():
         o16 = m3(sub(P3, 64), rays=sub(R3, 64), centers=sub(C3, 64)).cpu()
@@ -705,8 +744,8 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     r3 = mpl_oracle.forward(sd3, f3, cpu(P3, 64), cpu(R3, 64), cpu(C3, 64))
     mx3, nw3 = mpl_oracle.rel_errors(o16, r3)
     roof16 = stack_roofline(m3, f3, a.batch, b3, "bf16", dev)
-    extra["cmu_v8_depth2"] = {"fp32_poses_per_s": round(v32, 1), "bf16_poses_per_s": round(v16, 1), "bf16_ms_per_step": round(a.batch / v16 * 1e3, 4),
-                              "bf16_roofline": roof16,
+    extra["cmu_v8_depth2"] = {"fp32_poses_per_s": v32, "bf16_poses_per_s": v16, "bf16_ms_per_step": t16["median_ms"],
+                              "bf16_timing": t16, "fp32_timing": t32, "bf16_roofline": roof16,
                               "bf16_tflops": round(v16 * mpl_oracle.flop_count(f3) / 1e12, 1),
                               "bf16_frac_of_bf16_peak": round(v16 * mpl_oracle.flop_count(f3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                               "bf16_max_scaled_vs_ref": float("%.3e" % mx3), "bf16_norm_wise_vs_ref": float("%.3e" % nw3),
@@ -715,31 +754,40 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     # the same shape at depth 12 (config 3 at L = 2 and L = 12)
     f3d = model_flags("chosen", 8, 12)
     m3d = build_model(f3d, dev)
-    n3d = max(5, a.steps // 4)
-    v32d = a.batch * n3d / timed_steps(m3d, b3, n3d, 2)
+    t32d = timed_regions(m3d, b3, a.batch)
+    roof32d = stack_roofline(m3d, f3d, a.batch, b3, "fp32", dev)
     m3d.set_matmul_precision("bf16")
-    v16d = a.batch * n3d / timed_steps(m3d, b3, n3d, 2)
-    extra["cmu_v8_depth12"] = {"fp32_poses_per_s": round(v32d, 1), "bf16_poses_per_s": round(v16d, 1),
-                               "bf16_ms_per_step": round(a.batch / v16d * 1e3, 4),
+    t16d = timed_regions(m3d, b3, a.batch)
+    extra["cmu_v8_depth12"] = {"fp32_poses_per_s": t32d["poses_per_s"], "bf16_poses_per_s": t16d["poses_per_s"],
+                               "bf16_ms_per_step": t16d["median_ms"], "bf16_timing": t16d, "fp32_timing": t32d,
+                               "fp32_roofline": roof32d,
                                "bf16_roofline": stack_roofline(m3d, f3d, a.batch, b3, "bf16", dev)}
     del m3d
     # PCIe-inclusive rate of the headline workload: the same forwards fed from pinned host tensors, H2D
     # of the V x (B,17,3) poses (+ rays, centers: the API's 1680 B/pose) inside the timed region
     host = [tuple([t.cpu().pin_memory() for t in lst] for lst in b) for b in batches[:2]]
+    n_o = MIN_LEG_STEPS
+
+    def host_fed(step_fn):
+        with torch.no_grad():
+            for i in range(3):
+                step_fn(i)
+            ms = []
+            for _ in range(LEG_REGIONS):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_o):
+                    step_fn(i)
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t0) / n_o * 1e3)
+        ms.sort()
+        return round(a.batch / ms[len(ms) // 2] * 1e3, 1)
 
     def h2d_step(i):
         Ph, Rh, Ch = host[i % 2]
         up = lambda lst: [t.to(dev, non_blocking=True) for t in lst]
         return model(up(Ph), rays=up(Rh), centers=up(Ch))
-    with torch.no_grad():
-        for i in range(3):
-            h2d_step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_o):
-            h2d_step(i)
-        torch.cuda.synchronize()
-    extra["h2d_inclusive_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
+    extra["h2d_inclusive_poses_per_s"] = host_fed(h2d_step)
     # the same through ONE pinned staging buffer and one copy per batch (openmpl_amd.inputs.HostStager)
     from openmpl_amd.inputs import HostStager
     stagers = [HostStager(a.batch, a.views, 17, dev) for _ in range(2)]       # double-buffered: batch i+1 is packed while i runs
@@ -748,28 +796,31 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     def staged_step(i):
         Pv, Rv, Cv = stagers[i % 2].stage(*plain[i % 2])
         return model(Pv, rays=Rv, centers=Cv)
-    with torch.no_grad():
-        for i in range(3):
-            staged_step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_o):
-            staged_step(i)
-        torch.cuda.synchronize()
-    extra["h2d_inclusive_staged_poses_per_s"] = round(a.batch * n_o / (time.perf_counter() - t0), 1)
+    extra["h2d_inclusive_staged_poses_per_s"] = host_fed(staged_step)
     # BASELINE.json configs[0] shape on the GPU: single-frame latency (V=2, B=1, depth 12), synchronised per call
     f0 = model_flags("chosen", 2, a.depth)
     m0 = build_model(f0, dev)
     b0 = [make_batch(1, 2, dev, seed=4000, step=s) for s in range(2)]
+
+    def per_call_us(n=50, regions=LEG_REGIONS):
+        us = []
+        for _ in range(regions):
+            t0 = time.perf_counter()
+            for i in range(n):
+                m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
+                torch.cuda.synchronize()
+            us.append((time.perf_counter() - t0) / n * 1e6)
+        us.sort()
+        return round(us[len(us) // 2], 1)
     with torch.no_grad():
         for i in range(5):
             m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(50):
-            m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
-            torch.cuda.synchronize()
-        extra["v2_b1_latency_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+        extra["v2_b1_latency_us"] = per_call_us()
+        m0.use_torch_op(True)
+        extra["v2_b1_latency_torch_op_us"] = per_call_us()
+        m0.use_torch_op("auto")
+        extra["v2_b1_back_to_back"] = timed_regions(m0, b0, 1)
         # roofline of the small-batch engine (sm_stack_kernel: every GEMM on the whole chip, the fp32 nn.Linear weights streamed
         # once per forward): algorithmic bytes = the FPT weights of the depth + 1 block applications, against the HBM peak
         from openmpl_amd import cabi
@@ -784,18 +835,15 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
                                        avg_launch_us=round(us0, 1), algorithmic_bytes_per_launch=round(w0),
                                        achieved=round(w0 / (us0 * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(w0 / (us0 * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
-                                       note="65 grid barriers x ~6 us, not bandwidth, bound this launch (DESIGN.md section 4)")
+                                       kernel_ms_per_step={k: round(t / 20, 4) for k, (t, n) in pr0.items()},
+                                       note="grid barriers (latency), not bandwidth, bound this launch (DESIGN.md section 4)")
         # the same frame through the team kernels (the small-batch engine of sm_stack.hip switched off: mpl_x3_stack_mode bit 3)
         try:
             cabi.check(cabi.load().mpl_x3_stack_mode(8), "stack mode")
             for i in range(5):
                 m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(50):
-                m0(b0[i % 2][0], rays=b0[i % 2][1], centers=b0[i % 2][2])
-                torch.cuda.synchronize()
-            extra["v2_b1_latency_team_kernels_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+            extra["v2_b1_latency_team_kernels_us"] = per_call_us()
         finally:
             cabi.check(cabi.load().mpl_x3_stack_mode(0), "stack mode")
     del m0
@@ -803,39 +851,49 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
     # :37-39): whole forward, CHOSEN flag set, depth 12.  The block stack is a chain of 52 dependent GEMMs per 64-row tile that
     # one team of D / 136 workgroups walks serially, so its time (~1 ms) does not shrink with the batch: small batches leave
     # CUs idle ("small batches")
-    curve = {}
+    curve, curve_t = {}, {}
     for Vc in (2, 4):
         fc = model_flags("chosen", Vc, a.depth)
         mc = build_model(fc, dev)
         for Bc in (1, 32, 256, 1024):
             bc = [make_batch(Bc, Vc, dev, seed=5000 + Bc, step=s) for s in range(2)]
-            nc = max(10, a.steps // 3)
-            curve["v%d_b%d" % (Vc, Bc)] = round(Bc * nc / timed_steps(mc, bc, nc, 3), 1)
+            tc = timed_regions(mc, bc, Bc)
+            curve["v%d_b%d" % (Vc, Bc)] = tc["poses_per_s"]
+            curve_t["v%d_b%d" % (Vc, Bc)] = tc
+            if Vc == 2 and Bc == 256:          # the reference's shipped call shape: its own roofline entry (row-narrow teams)
+                legs["v2_b256"] = dict(workload="V=2 B=256 depth %d CHOSEN fp32 (the reference's shipped TEST.BATCH_SIZE)" % a.depth,
+                                       timing=tc, roofline=stack_roofline(mc, fc, Bc, bc, "fp32", dev))
         del mc
     extra["batch_curve_poses_per_s"] = curve
+    extra["batch_curve_timing"] = curve_t
     # BASELINE.json configs[4]: large-view stress V=31, batch 256 (31-token FPT), and the 17V = 527-token joints x views
     # grid (KPTOK, LDS-resident K/V of one head)
     for tag, fl in (("v31_b256_chosen", {}), ("v31_b256_kptok", dict(FPT_blocks_view_keypoint_tokens=True))):
         f5 = model_flags("chosen", 31, a.depth, **fl)
         m5 = build_model(f5, dev)
         b5 = [make_batch(256, 31, dev, seed=3000, step=s) for s in range(2)]
-        n5 = max(5, a.steps // 5)
-        v5 = 256 * n5 / timed_steps(m5, b5, n5, 2)
-        extra[tag + "_poses_per_s"] = round(v5, 1)
-        extra[tag + "_tflops"] = round(v5 * mpl_oracle.flop_count(f5) / 1e12, 1)
+        t5 = timed_regions(m5, b5, 256)
+        extra[tag + "_poses_per_s"] = t5["poses_per_s"]
+        extra[tag + "_tflops"] = round(t5["poses_per_s"] * mpl_oracle.flop_count(f5) / 1e12, 1)
+        roof5 = kptok_roofline(m5, f5, 256, 31, b5) if fl else stack_roofline(m5, f5, 256, b5, "fp32", dev)
+        legs[tag] = dict(workload="V=31 B=256 depth %d CHOSEN%s fp32" % (a.depth, " + joints x views token grid" if fl else ""),
+                         timing=t5, roofline=roof5)
         del m5
     # the non-default tails at the reference's default width (TRANSFORMER_OUTPUT_HEAD_HIDDEN_DIM = 1024, config.py:98):
     # step time relative to the default head on the same batches
     heads = {}
-    base = timed_steps(model, batches, n_o, 3) / n_o * 1e3
+    base = timed_regions(model, batches, a.batch)["median_ms"]
     for tag, fl in (("deep_head", dict(deep_head=True, hidden_dim=1024)), ("head_kadkhod", dict(head_kadkhod=True, hidden_dim=1024)),
                     ("linear_weighted_mean", dict(linear_weighted_mean=True))):
         mh = build_model(model_flags("chosen", a.views, a.depth, **fl), dev)
-        t = timed_steps(mh, batches, n_o, 3) / n_o * 1e3
+        t = timed_regions(mh, batches, a.batch)["median_ms"]
         heads[tag] = dict(ms_per_step=round(t, 4), vs_default_head=round(t / base, 3))
         del mh
     heads["default_head_ms_per_step"] = round(base, 4)
     extra["heads_hidden_dim_1024"] = heads
+    extra["legs"] = legs
+    extra["legs_note"] = ("every leg: %d warm-up forwards, then the MEDIAN of %d regions of >= %d forwards (timed_regions); `first_ms` is "
+                          "the first region after the model was built" % (5, LEG_REGIONS, MIN_LEG_STEPS))
     return extra
 
 
@@ -847,13 +905,25 @@ def dist_and_dp_extras(a, model, batches, dev):
     import torch.distributed as dist
     from openmpl_amd.dist import ShardedLifter
     out = {}
-    n = max(10, a.steps)
+    n = max(MIN_LEG_STEPS, a.steps)
     try:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        lifter = ShardedLifter(model)
-        out["force_dist_poses_per_s"] = round(a.batch * n / timed_steps(model, batches, n, 3, lifter, a.batch), 1)
+        # direct | collective ordered into the compute stream (default) | collective on the process group's stream beside the
+        # next forward (rounds 1-5), alternating in ONE process: the price of the rank path with one rank
+        modes = {"direct": None, "stream": ShardedLifter(model, gather="stream"), "overlap": ShardedLifter(model, gather="overlap")}
+        runs = {k: [] for k in modes}
+        for rep in range(3):
+            for k, lf in modes.items():
+                runs[k].append(timed_regions(model, batches, a.batch, n, 3, LEG_REGIONS, lf, a.batch if lf is not None else None))
+        best = {k: sorted(r, key=lambda t: t["median_ms"])[len(r) // 2] for k, r in runs.items()}
+        out["force_dist_poses_per_s"] = best[a.gather]["poses_per_s"]
+        out["force_dist"] = dict(gather_default=a.gather, direct=best["direct"], stream=best["stream"], overlap=best["overlap"],
+                                 stream_vs_direct=round(best["stream"]["median_ms"] / best["direct"]["median_ms"], 4),
+                                 overlap_vs_direct=round(best["overlap"]["median_ms"] / best["direct"]["median_ms"], 4),
+                                 note="three alternations of {direct, stream, overlap}, each the median of %d regions of %d steps; "
+                                      "a process group of ONE rank (RCCL all_gather_into_tensor of (B,17,3) every step)" % (LEG_REGIONS, n))
         dist.destroy_process_group()
     except Exception as e:            # a box without a working RCCL: say so, the headline does not depend on it
         out["force_dist_poses_per_s"] = "failed: %r" % (e,)
@@ -870,7 +940,7 @@ def dist_and_dp_extras(a, model, batches, dev):
             for i in range(n):
                 dp(host[i % 2][0], rays=host[i % 2][1], centers=host[i % 2][2])
             torch.cuda.synchronize()
-        dp_out[tag] = dict(gpus=len(dev_ids), poses_per_s=round(a.batch * n / (time.perf_counter() - t0), 1))
+        dp_out[tag] = dict(gpus=len(dev_ids), steps=n, poses_per_s=round(a.batch * n / (time.perf_counter() - t0), 1))
     dp_out["note"] = ("torch.nn.DataParallel(model) called with CPU tensors as validate() does (function_mpl.py:350): scatter copies "
                       "the inputs, replicas share the per-device packed operands (packed once, not per forward)")
     out["data_parallel"] = dp_out

@@ -331,7 +331,12 @@ int mpl_ln_linear_h2(const float *x, int M, int K, int has_ln, float eps, const 
  * operands: it sets a sticky per-device error word, the poses of that call are NaN, and EVERY later call on the device
  * returns MPL_E_DEVICE until mpl_device_error_clear() -- the reference's convention for a failed forward is a Python
  * exception (SURVEY.md 8b "Error convention"), which is what the binding turns this into.
- * mpl_device_error(dev): 1 when the word is set (dev < 0: the current device); no synchronisation, reads pinned memory.
+ * mpl_device_error(dev): the word, 0 = no failure (dev < 0: the current device); no synchronisation, reads pinned memory.  Bits:
+ *   1 = lost hand-off / operands packed against other scales (above);
+ *   2 = the split-operand SPT engine met a confidence-weighted attention row (confidence_as_attention_uncertainty_weight,
+ *       reference multiview_mpl.py:61-62: the softmax rows are multiplied by the caller's `conf`, which is DATA) beyond the
+ *       fp16 window its static scales assume: that sequence's poses are NaN -- never a saturated, plausible-looking pose --
+ *       and the caller is pointed at the native-fp32 engine (MPL precision "fp32_mfma"), which has no window.
  * mpl_x3_spin_limit(v): test hook.  v & 0xff = log2 of the polls before a wait counts as lost (default 23 ~ 10 s);
  * v >> 8 = fault injection: when > 0, one workgroup of the next launches deserts its team before that GEMM phase, so
  * that the failure path can be exercised deterministically (tests/test_failures_gpu.py). */

@@ -62,7 +62,7 @@ unsigned* mpl::device_error_word(int dev) {
 int mpl::device_error_pending(int dev) {
     if (dev < 0 || dev >= 64) return 0;
     std::lock_guard<std::mutex> g(g_err_mu);
-    return g_err_host[dev] && *reinterpret_cast<volatile unsigned*>(g_err_host[dev]) != 0u;
+    return g_err_host[dev] ? (int)*reinterpret_cast<volatile unsigned*>(g_err_host[dev]) : 0;
 }
 void mpl::device_error_clear(int dev) {
     if (dev < 0 || dev >= 64) return;
@@ -442,15 +442,18 @@ const char* mpl_hip_error_string(int code) {
         case MPL_E_WORKSPACE: return "workspace missing or too small";
         case MPL_E_LAUNCH: return "HIP runtime error at kernel launch";
         case MPL_E_DEVICE:
-            return "an earlier forward on this device lost a hand-off between the workgroups of its persistent kernel, or was "
-                   "handed proj / fc2 operands that were not packed against their producers' scales (its poses are NaN): the "
-                   "GPU was shared with other work for longer than the wait bound, or mpl_pack_h2_scaled was skipped; clear "
-                   "with mpl_device_error_clear()";
+            return "an earlier forward on this device failed on the device and its poses are NaN (mpl_device_error() bits: 1 = a "
+                   "workgroup of the persistent block-stack kernel lost a hand-off -- the GPU was shared with other work for "
+                   "longer than the wait bound -- or proj / fc2 operands were not packed against their producers' scales "
+                   "(mpl_pack_h2_scaled skipped); 2 = confidence_as_attention_uncertainty_weight with confidences so large that "
+                   "the weighted attention output left the fp16 window of the split operands: run that model with "
+                   "set_matmul_precision('fp32_mfma'), the native-fp32 engine has no window); clear with mpl_device_error_clear()";
         default: return "unknown error";
     }
 }
 
 int mpl_fpt_width(const mpl_config* cfg) {
+    if (!cfg) return MPL_E_INVALID;
     return cfg->num_joints * cfg->dim * ((cfg->flags & MPL_F_RAYS_TOKEN) ? 2 : 1);
 }
 

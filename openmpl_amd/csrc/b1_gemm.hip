@@ -7,7 +7,7 @@
 // The engine is the stage of h2_gemm.hip (h2_phase.hpp) with ONE part per operand (NP = 1).  The second KiB of every 2-KiB
 // fragment slot, which holds the lo part of an fp16x2 operand, holds the NEXT k-tile here: a stage is a PAIR of k-tiles
 // (K = 64), moves exactly the pieces of an h2 stage through the same ring and issues one v_mfma_f32_16x16x32_bf16 per k-tile
-// and column tile.  Round 2's bf16 engine (x3_gemm.hip with one part: three k-tiles per 39-KiB stage, ring of 4, one row tile
+// and column tile.  Round 2's bf16 engine (removed in round 5; one part: three k-tiles per 39-KiB stage, ring of 4, one row tile
 // per team, 1.44 KiB of operand per MFMA) was bound by the L2 -> LDS path; this one walks PAIRS of row tiles in EVERY phase
 // whenever a team owns two (V = 8, B = 1024: 128 row tiles = exactly two per team) -- every W k-tile pair is fetched and read
 // from LDS once for both tiles, 34 KiB per 36 MFMAs per SIMD = 0.94 KiB per MFMA -- and, with one part per operand, the

@@ -1,4 +1,4 @@
-// Device helpers shared by the FPT GEMM kernels (ln_gemm.hip: fp32 matrix cores; x3_gemm.hip: fp32 via 3-way bf16
+// Device helpers shared by the FPT GEMM kernels (ln_gemm.hip: fp32 matrix cores; h2_phase.hpp: the packed-operand engines; round 2's fp32 via 3-way bf16
 // operand split on the bf16 matrix cores): tile constants, LayerNorm partial statistics, epilogues, LDS-DMA.
 #pragma once
 #include "common.hpp"

@@ -5,7 +5,7 @@
 // Attention.proj :65 + residual :90, Block.norm2 + Mlp.fc1 + GELU :32-33, Mlp.fc2 :35 + residual :91.
 //
 // Arithmetic.  The packed 16-bit matrix pipe of gfx950 is 16x faster than the fp32 one, so an fp32 product is formed from
-// 16-bit pieces.  Round 2 (x3_gemm.hip, still selectable as "fp32x3") used three bf16 pieces per operand and six partial
+// 16-bit pieces.  Round 2 (removed in round 5) used three bf16 pieces per operand and six partial
 // products.  This engine uses TWO fp16 pieces and THREE partial products -- the "3xTF32" scheme of the CUDA world on the
 // fp16 pipe (fp16 has the 11-bit significand of TF32):
 //     x = hi + lo (+ eps),  hi = fp16(x),  lo = fp16(x - hi)      |eps| <= 2^-22 |x|   (x - hi is exact in fp32)

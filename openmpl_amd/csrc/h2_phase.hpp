@@ -28,20 +28,30 @@ constexpr int H2_MAX_WGS = 1024;
 constexpr int H2_ATT_TS = 3 * BN + 4;        // row stride (floats) of the q | k | v tile of the generic attention epilogue
 constexpr float H2_SA = 1024.0f;             // scale of a normalised LayerNorm input (|z| <= sqrt(K): fine up to K = 2048)
 constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind the fragments: c | sc | sw | bound | so
+// ---- laboratory switches.  The product library is built WITHOUT -DMPL_LAB: every switch below then has the one value the
+// shipped kernels were measured and tested with, and a stray -DH2_* on the command line is a compile error instead of a
+// silently different (or, for H2_ABL, deliberately WRONG) library.  tools/build_variants.sh passes -DMPL_LAB together with the
+// switch it varies; the values and what they do are unchanged from rounds 3-5.
+#ifndef MPL_LAB
+#if defined(H2_DBG) || defined(H2_ABL) || defined(H2_DW_PIN) || defined(H2_WT_AUX) || defined(H2_WSPLIT) || defined(H2_R2_AB) || \
+    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2)
+#error "H2_* experiment switches are laboratory-only: build with -DMPL_LAB (tools/build_variants.sh does)"
+#endif
+#endif
 #ifndef H2_DBG
-#define H2_DBG 0
+#define H2_DBG 0        // 1 / 2: per-wave shader-clock stamps of every phase (tools/chain_phase.py)
 #endif
 #ifndef H2_ABL
-#define H2_ABL 0   // bench-only ablations (results are garbage): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier, 64 W out of a hot L2
+#define H2_ABL 0        // bench-only ablations (results are GARBAGE): 1 no B fragment reads, 2 no DMA refill, 4 no A fragment reads, 8 no MFMA, 16 no LayerNorm conversion, 32 no barrier, 64 W out of a hot L2
 #endif
 #ifndef H2_DW_PIN
 #define H2_DW_PIN 1     // direct-W form: pin the MFMA / load interleave of a stage (sched_group_barrier)
 #endif
 #ifndef H2_WT_AUX
-#define H2_WT_AUX 17   // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
+#define H2_WT_AUX 17    // cache policy of the hand-off stores: 17 = sc0 sc1 (write-through), 16 = sc1
 #endif
 #ifndef H2_WSPLIT
-#define H2_WSPLIT 1    // W pieces per stage and wave: 0 = 1 (waves 0..3) / 4 (waves 4, 5) / 3 (waves 6, 7); 1 = 2 / 3 / 2
+#define H2_WSPLIT 1     // W pieces per stage and wave: 0 = 1 (waves 0..3) / 4 (waves 4, 5) / 3 (waves 6, 7); 1 = 2 / 3 / 2
 #endif
 #ifndef H2_R2_AB
 #define H2_R2_AB 1      // bf16 pair form: A pieces by the waves 4..7 (see h2_phase)
@@ -119,7 +129,7 @@ struct H2Args {
     float eps;
     int att_ntok, att_hd;
     unsigned long long* dbg;
-    unsigned* err_ws;        // chain mode: see x3_gemm.hip X3Args
+    unsigned* err_ws;        // chain mode: the error word of the call (workspace), set when a hand-off wait is lost
     unsigned* err_host;
     int spin_log2;
     int plain;               // chain mode: the team sits on ONE XCD (h2_team_placement): hand-off stores stay in its L2 (plain
@@ -565,7 +575,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 if (__hip_atomic_load(chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chain_need) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (spin == lim && lane == 0) {     // a lost partner is an ERROR, never a licence to go on (x3_gemm.hip)
+            if (spin == lim && lane == 0) {     // a lost partner is an ERROR, never a licence to go on
                 *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 1u;
                 if (a.err_ws) __hip_atomic_store(a.err_ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.err_host) __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1144,7 +1154,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
     } else {
     if constexpr (EPI == H2_EPI_ATT) {
       if (h2_att_in_registers(a.att_ntok, a.att_hd, a.rpt)) {
-        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS (x3_gemm.hip): a
+        // ---- Attention.forward :55-64 for 4 tokens per sequence and 68- or 136-wide heads, in REGISTERS: a
         // sequence is the 4 lanes of a quad, k_j / v_j come by DPP quad broadcast, the q.k sums are reduced over the tiles of
         // the wave, the 4 kq lanes and -- through 2 KiB of LDS -- the two waves of the row group.
 #pragma unroll
@@ -1428,7 +1438,7 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         if (H2_DBG && a.dbg) t_st = __builtin_amdgcn_s_memtime();
         if constexpr (EPI == H2_EPI_RES) {
             if (a.stats_out) {
-                // LayerNorm partials {mean, M2} of the 136-column slice of each row (x3_gemm.hip): two exchanges through LDS
+                // LayerNorm partials {mean, M2} of the 136-column slice of each row: two exchanges through LDS
                 constexpr int XR = RT * 64;
                 float* xch = reinterpret_cast<float*>(smem);       // [2 phases][2 halves][RT x 64 rows]
                 const int half = slot0 ? 1 : 0;
@@ -2090,7 +2100,7 @@ static int h2_launch_stack(float* x, unsigned short* x16, int M, int D, int n_to
             if (!ops[4 * i + j]) return MPL_E_INVALID;
             a.w[i][j] = reinterpret_cast<const char*>(ops[4 * i + j]);
         }
-    // the library serialises ITS OWN persistent launches per device (see x3_gemm.hip launch_stack_np); not under graph capture
+    // the library serialises ITS OWN persistent launches per device (h2_launch_stack below); not under graph capture
     if (int rc = refuse_stream_capture(s)) return rc;
     hipEvent_t ev = stack_chain_event(dev);
     if (!ev) return MPL_E_LAUNCH;

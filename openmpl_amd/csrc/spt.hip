@@ -51,6 +51,7 @@ struct SptParams {
     int c3;  // channel count of the pos_3d_* tensors (d or 2d)
     int spw;  // sequences per workgroup (spt_kernel: 1..16, few sequences spread over the chip; spt3_kernel<SS>: SS)
     int abl;  // bench-only ablation mask (MPL_SPT_ABL): 1 no attention, 2 no GELU, 4 no MFMA phases, 8 no epilogue math
+    unsigned* err_host;  // sticky error word of the device (common.hpp device_error_word): bit 1 = an operand left its fp16 window
     unsigned char sched[MPL_MAX_APPS];  // layer | weighted << 7
 };
 
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(NTHR, 1) void spt_kernel(const SptParams p) {
 
 // =====================================================================================================================
 // spt3_kernel -- the same stage with the Linear layers on the bf16 matrix cores (fp32 arithmetic from exactly split
-// operands, as x3_gemm.hip: x = hi + mid + lo in bf16, six partial products per product, fp32 accumulation).
+// operands, as the round-2 fp32 engine did: x = hi + mid + lo in bf16, six partial products per product, fp32 accumulation).
 //
 //   * token-major rows (row = joint * 16 + sequence) and the W fragment as FIRST MFMA operand: lane (s, kq) of an
 //     accumulator tile holds 4 consecutive columns of (joint j, sequence s) -- for the qkv tiles exactly the 4-dim vector
@@ -1046,10 +1047,19 @@ __global__ __launch_bounds__(NTHR, 1) void spt3_kernel(const SptParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     o[t] = float4{o[t].x * inv[t], o[t].y * inv[t], o[t].z * inv[t], o[t].w * inv[t]};
-                    // the confidence weights are data: only with them can the operand leave the window its static scale assumes
-                    if (weighted)
-                        o[t] = float4{__builtin_amdgcn_fmed3f(o[t].x, -65000.f, 65000.f), __builtin_amdgcn_fmed3f(o[t].y, -65000.f, 65000.f),
-                                      __builtin_amdgcn_fmed3f(o[t].z, -65000.f, 65000.f), __builtin_amdgcn_fmed3f(o[t].w, -65000.f, 65000.f)};
+                    // the confidence weights are data (reference :61-62 multiplies the softmax rows by whatever `conf` it is
+                    // given): only with them can the operand leave the window its static, data-free scale assumes.  That is
+                    // reported, never absorbed: the row becomes NaN (so do the poses of its sequence) and the device error word
+                    // gets bit 1 -- the next API call and check_device() raise, pointing at the native-fp32 engine, which has
+                    // no window.  (Rounds 3-5 clamped to +-65000 here: plausible-looking poses from saturated operands.)
+                    if (weighted) {
+                        const float big = fmaxf(fmaxf(fabsf(o[t].x), fabsf(o[t].y)), fmaxf(fabsf(o[t].z), fabsf(o[t].w)));
+                        if (!(big <= 65000.f)) {
+                            const float qn = __builtin_nanf("");
+                            o[t] = float4{qn, qn, qn, qn};
+                            if (p.err_host) __hip_atomic_fetch_or(p.err_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -1369,8 +1379,16 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     p.B = in->batch; p.V = cfg->num_views; p.in_ch = cfg->in_chans;
     p.flags = f;
     p.c3 = (f & MPL_F_POS3D_TO_RAYS) ? 2 * SD : SD;
+#ifdef MPL_LAB       // the phase ablations (garbage results) exist in laboratory builds only: tools/build_variants.sh -f spt.hip
     static const int abl = getenv("MPL_SPT_ABL") ? atoi(getenv("MPL_SPT_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     p.abl = abl;
+    {
+        int dev = 0;
+        p.err_host = hipGetDevice(&dev) == hipSuccess ? device_error_word(dev) : nullptr;
+    }
     // schedule (:405-410): [blk(x,w)]; if last: blk(x); blk(x)
     int n = 0;
     if (!(f & MPL_F_NO_SPT)) {

@@ -91,8 +91,18 @@ class GatherHandle:
         return torch.cat(parts, 0)
 
 
-def gather_outputs_async(local: torch.Tensor, batch: int, group=None) -> GatherHandle:
-    """Start the ONE all-gather of a batch (see gather_outputs) without blocking the stream that produced ``local``."""
+GATHER_MODES = ("stream", "overlap")
+
+
+def gather_outputs_async(local: torch.Tensor, batch: int, group=None, mode: str = "overlap") -> GatherHandle:
+    """Start the ONE all-gather of a batch (see gather_outputs).
+
+    mode "overlap": the collective runs on the process group's own stream behind an event and the stream that produced ``local``
+    is NOT blocked -- the next forward overlaps it, and ``GatherHandle.wait()`` is where the current stream is made to wait.
+    mode "stream": the collective is ordered INTO the current stream -- it starts behind the forward that produced ``local`` and
+    whatever the caller enqueues next starts behind it (a stream-level wait, the host does not block): see ShardedLifter."""
+    if mode not in GATHER_MODES:
+        raise ValueError("gather mode must be one of %r" % (GATHER_MODES,))
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_range(batch, world, rank)
@@ -105,6 +115,9 @@ def gather_outputs_async(local: torch.Tensor, batch: int, group=None) -> GatherH
         src[: hi - lo] = local
     buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     work = dist.all_gather_into_tensor(buf, src, group=group, async_op=True)
+    if mode == "stream":
+        work.wait()            # RCCL: the CURRENT STREAM waits for the collective (no host block); gloo: the host does
+        work = None
     return GatherHandle(work, buf, batch, world, src)
 
 
@@ -115,17 +128,43 @@ class ShardedLifter:
     shard) and returns the full (B,J,3) result on every rank -- the call shape of the reference's DataParallel wrapper
     (valid_mpl.py:177-178).  ``lifter.lift_shard(poses, ..., batch=B)`` takes inputs that are ALREADY sharded (rank r
     holds poses shard_range(B, world, r) -- what a per-rank data loader produces: no rank ever touches another rank's
-    frames) and returns a GatherHandle, so the exchange of batch i overlaps the forward of batch i+1."""
+    frames) and returns a GatherHandle.
 
-    def __init__(self, model: Callable, group=None):
+    ``gather`` -- where the output exchange of batch i runs relative to the forward of batch i+1:
+
+    * ``"stream"`` (default): ordered into the compute stream, between the tail kernel of batch i and the first kernel of batch
+      i+1.  The block stack of a forward is ONE persistent launch that takes every compute unit (one 160-KiB workgroup per CU,
+      teams spin on their partners: csrc/h2_phase.hpp h2_launch_stack); a collective kernel on another stream would have to
+      wait for a compute unit of that launch, or -- when it got there first -- keep one workgroup of it out while it waits for
+      the SAME collective of a slower rank, whose kernel in turn waits behind that rank's persistent launch.  In the stream
+      the collective of a rank meets nothing of its own device: rank skew costs what the slowest rank's forward costs, once.
+      Price: the 209-kB exchange (tens of microseconds) sits on the critical path of a ~1.3-ms step.
+    * ``"overlap"``: on the process group's stream behind an event; the next forward is enqueued before the wait (rounds 1-5).
+      Kept for launches that leave compute units free (small batches) and for the A/B in bench.py (extra.force_dist_*)."""
+
+    def __init__(self, model: Callable, group=None, gather: str = "stream"):
+        if gather not in GATHER_MODES:
+            raise ValueError("gather mode must be one of %r" % (GATHER_MODES,))
         self.model = model
         self.group = group
+        self.gather = gather
         # a shard must equal the rows of the single-process result bit for bit, whatever the world size leaves of the batch: the
-        # small-batch engine (<= 32 token rows, another fp32 arithmetic: ~1e-7 apart) is therefore off for sharded lifting
-        # (MultiView_MPL.set_small_batch_engine; models wrapped in MultiView_MPL_G expose it through .features)
-        for m in (model, getattr(model, "features", None)):
-            if hasattr(m, "set_small_batch_engine"):
-                m.set_small_batch_engine(False)
+        # small-batch engine (<= 32 token rows, another fp32 arithmetic: ~1e-7 apart) is therefore off DURING a sharded call
+        # (MultiView_MPL.set_small_batch_engine; models wrapped in MultiView_MPL_G expose it through .features).  It is a
+        # per-call override: the caller's own setting is restored afterwards, direct model(...) calls keep the engine they chose
+        self._engine_owner = next((m for m in (getattr(model, "features", None), model)
+                                   if hasattr(m, "set_small_batch_engine") and hasattr(m, "_small_batch_engine")), None)
+
+    def _forward_batch_invariant(self, poses, rays, centers):
+        own = self._engine_owner
+        if own is None:
+            return self.model(poses, rays=rays, centers=centers)
+        keep = own._small_batch_engine
+        own.set_small_batch_engine(False)
+        try:
+            return self.model(poses, rays=rays, centers=centers)
+        finally:
+            own.set_small_batch_engine(keep)
 
     def lift_shard(self, poses, rays=None, centers=None, batch: Optional[int] = None) -> GatherHandle:
         world = dist.get_world_size(self.group)
@@ -137,12 +176,12 @@ class ShardedLifter:
         if nloc != hi - lo:
             raise RuntimeError("rank %d was handed %d poses, its shard of %d is %d" % (rank, nloc, batch, hi - lo))
         if nloc:
-            out = self.model(poses, rays=rays, centers=centers)
+            out = self._forward_batch_invariant(poses, rays, centers)
             if isinstance(out, tuple):                  # head_kadkhod returns (x3, [x1, x2]): exchange the final estimate
                 out = out[0]
         else:
             out = poses[0].new_zeros((0, poses[0].shape[1], 3))
-        return gather_outputs_async(out, batch, self.group)
+        return gather_outputs_async(out, batch, self.group, self.gather)
 
     def __call__(self, poses, rays=None, centers=None):
         world = dist.get_world_size(self.group)

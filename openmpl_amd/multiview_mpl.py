@@ -278,9 +278,7 @@ class MultiView_MPL(nn.Module):
             self.head = nn.ModuleList([first] + rest)
 
         self._unsupported = self._find_unsupported()
-        self.__dict__["_op_handle"] = _NEXT_HANDLE[0]       # plain attributes: not part of state_dict / repr
-        _NEXT_HANDLE[0] += 1
-        _LIVE_MODULES[self._op_handle] = self
+        self.__dict__["_op_handle"] = 0                     # plain attributes: not part of state_dict / repr; see _handle()
         self.__dict__["_use_torch_op"] = "auto"
         self.__dict__["_small_batch_engine"] = "auto"
         self._hip_cache = {}
@@ -642,6 +640,19 @@ class MultiView_MPL(nn.Module):
         self.__dict__["_small_batch_engine"] = mode
         return self
 
+    def _handle(self) -> int:
+        """Integer under which THIS object is registered for openmpl_amd::forward.  The handle is a plain __dict__ entry, so
+        copy.deepcopy, pickle / torch.save of the module and DataParallel's shallow replicas all inherit the number of the
+        module they were made from; it is therefore checked against the registry on every use and re-issued when it does not
+        resolve to this very object (a copy must run its OWN weights through the operator route, never the original's)."""
+        h = self.__dict__.get("_op_handle", 0)
+        if not h or _LIVE_MODULES.get(h) is not self:
+            h = _NEXT_HANDLE[0]
+            _NEXT_HANDLE[0] += 1
+            self.__dict__["_op_handle"] = h
+            _LIVE_MODULES[h] = self
+        return h
+
     def _small_engine_allowed(self) -> bool:
         return self._small_batch_engine in (True, "auto") and not self._dp_replica
 
@@ -649,7 +660,7 @@ class MultiView_MPL(nn.Module):
         mode = self._use_torch_op
         if mode is True or (mode == "auto" and not self._dp_replica and
                             (torch.compiler.is_compiling() or torch.autograd.profiler._is_profiler_enabled)):
-            out = torch.ops.openmpl_amd.forward(self._op_handle, list(poses), list(rays) if rays is not None else [],
+            out = torch.ops.openmpl_amd.forward(self._handle(), list(poses), list(rays) if rays is not None else [],
                                                 list(centers) if centers is not None else [])
             return (out[0], [out[1], out[2]]) if self.head_kadkhod else out[0]
         return self._forward_impl(poses, rays, centers)

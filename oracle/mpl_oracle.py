@@ -96,7 +96,7 @@ def _bf(t):
 
 
 def _ln_linear_bf16(x, sd, ln_prefix, lin_prefix, eps):
-    """LayerNorm + Linear as openmpl_amd's bf16 engine computes it (csrc/x3_gemm.hip, NP = 1): the LayerNorm is folded
+    """LayerNorm + Linear as openmpl_amd's bf16 engine computes it (csrc/b1_gemm.hip on csrc/h2_phase.hpp, NP = 1): the LayerNorm is folded
     into the GEMM, LN(x).W^T + b = rstd (x.(gamma o W)^T - mean s) + c, with the operands x and gamma o W rounded to bf16,
     s summed over the rounded weights, products and sums exact (here: in the evaluation dtype)."""
     W, b = sd[lin_prefix + ".weight"], sd[lin_prefix + ".bias"]

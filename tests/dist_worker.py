@@ -1,6 +1,6 @@
 """Child process of tests/test_dist_gpu.py and tests/test_dist_gloo.py: one rank of the batch-sharded lifter.
 
-    python tests/dist_worker.py <backend> <out.npz> <batch>        (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from env)
+    python tests/dist_worker.py <backend> <out.npz> <batch> [stream|overlap]     (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from env)
 
 backend "single": no process group, plain model call (the reference result the sharded runs must equal bitwise);
 backend "nccl" (= RCCL): the HIP model on cuda:LOCAL_RANK through ShardedLifter; rank 0 writes the npz."""
@@ -19,6 +19,7 @@ FLAGS = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=2, num_views=
 
 def main():
     backend, out_path, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    gather = sys.argv[4] if len(sys.argv) > 4 else "stream"
     from openmpl_amd import detrng
     from openmpl_amd.multiview_mpl import MultiView_MPL
     rank = int(os.environ.get("RANK", "0"))
@@ -45,11 +46,11 @@ def main():
             import torch.distributed as dist
             from openmpl_amd.dist import ShardedLifter, shard_inputs
             dist.init_process_group(backend, device_id=dev)
-            lifter = ShardedLifter(m)
+            lifter = ShardedLifter(m, gather=gather)
             # (1) the DataParallel call shape: full batch on every rank
             for i, (P, R, C) in enumerate(batches):
                 res["full%d" % i] = lifter(P, rays=R, centers=C).cpu().numpy()
-            # (2) pre-sharded inputs, both exchanges in flight before the first wait (overlap with the next forward)
+            # (2) pre-sharded inputs, both exchanges issued before the first wait ("overlap": in flight beside the next forward)
             hs = []
             for P, R, C in batches:
                 p, r, c, _ = shard_inputs(P, R, C, world, rank)

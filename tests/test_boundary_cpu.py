@@ -225,7 +225,7 @@ def test_forward_is_a_registered_torch_operator_with_a_meta_function():
         m = MultiView_MPL(num_views=3, depth=1, **kw).eval()
         with FakeTensorMode():
             poses = [torch.empty(5, 17, 3, device="cuda") for _ in range(3)]
-            out = torch.ops.openmpl_amd.forward(m._op_handle, poses, [], [])
+            out = torch.ops.openmpl_amd.forward(m._handle(), poses, [], [])
         assert len(out) == n_out
         for o in out:
             assert tuple(o.shape) == (5, 17, 3) and o.dtype == torch.float32 and o.device.type == "cuda"
@@ -236,6 +236,43 @@ def test_forward_is_a_registered_torch_operator_with_a_meta_function():
         m.use_torch_op("sometimes")
     with pytest.raises(ValueError):
         m.set_small_batch_engine("maybe")
+
+
+def test_copies_of_a_module_get_their_own_operator_handle():
+    """the operator handle is a plain __dict__ entry, so copy.deepcopy, torch.save / torch.load and DataParallel's
+    shallow replica inherit the ORIGINAL's number.  Through the operator route a copy with modified weights would then run the
+    original's weights.  Every use resolves the handle against the registry and re-issues it when it names another object."""
+    import copy
+    import io
+    from openmpl_amd import multiview_mpl as mm
+    m = MultiView_MPL(num_views=2, depth=1).eval()
+    h = m._handle()
+    assert mm._module_of(h) is m and m._handle() == h                  # stable for the object it was issued to
+    c = copy.deepcopy(m)
+    assert c.__dict__["_op_handle"] == h                               # inherited number ...
+    hc = c._handle()
+    assert hc != h and mm._module_of(hc) is c and mm._module_of(h) is m   # ... re-issued on first use, the original keeps its own
+    with torch.no_grad():
+        c.head[1].weight.add_(1.0)
+    assert not torch.equal(mm._module_of(hc).head[1].weight, mm._module_of(h).head[1].weight)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    l = torch.load(buf, weights_only=False)
+    hl = l._handle()
+    assert hl not in (h, hc) and mm._module_of(hl) is l
+    r = m._replicate_for_data_parallel()
+    assert mm._module_of(r._handle()) is r and mm._module_of(h) is m
+    # a fake-tensor trace through the operator resolves to the copy's own shape contract
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        out = torch.ops.openmpl_amd.forward(hc, [torch.empty(3, 17, 3, device="cuda") for _ in range(2)], [], [])
+    assert tuple(out[0].shape) == (3, 17, 3)
+    del c
+    import gc
+    gc.collect()
+    with pytest.raises(RuntimeError, match="not alive"):
+        mm._module_of(hc)
 
 
 def test_cached_tensor_lists_follow_wholesale_parameter_swaps():

@@ -147,6 +147,75 @@ def test_sharded_lifter_world8_gloo_uneven_batch(batch):
         assert sizes == [1024] * 8                               # BASELINE.json configs[3]: 1024 poses per GPU
 
 
+def _worker_skew(rank, world, port, gather, q):
+    """Rank skew: the ranks take turns being late (one of them sleeps inside its forward, a different one every step) while
+    the caller pipelines exactly as bench.py does -- the exchange of step i is waited for after step i + 1 has been issued.
+    Whatever the skew and wherever the collective runs, step i's result must be step i's poses from EVERY rank."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    step = [0]
+
+    def model(poses, rays=None, centers=None):
+        if step[0] % world == rank:
+            time.sleep(0.15)                                   # this rank is the slow one of this step
+        return poses[0] * (step[0] + 1.0) + rank
+
+    lifter = ShardedLifter(model, gather=gather)
+    nloc, steps = 3, 6
+    x = torch.arange(nloc * 17 * 3, dtype=torch.float32).reshape(nloc, 17, 3)
+    got, pending = [], None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step[0] = i
+        h = lifter.lift_shard([x], batch=nloc * world)
+        if gather == "stream":
+            assert h._work is None                             # ordered into the stream: nothing left to wait for
+        if pending is not None:
+            got.append(pending.wait())
+        pending = h
+    got.append(pending.wait())
+    dt = time.perf_counter() - t0
+    ok = len(got) == steps
+    for i, g in enumerate(got):
+        want = torch.cat([x * (i + 1.0) + r for r in range(world)], 0)
+        ok = ok and torch.equal(g, want)
+    oks = [None] * world
+    dist.all_gather_object(oks, (bool(ok), dt))
+    if rank == 0:
+        q.put(oks)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather", ["stream", "overlap"])
+def test_rank_skew_does_not_mix_steps(gather):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_skew, args=(r, world, port, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    oks = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[0] for o in oks), "a step's exchange returned another step's (or rank's) poses under rank skew"
+    # every step has exactly one slow rank (0.15 s).  "stream": the ranks meet once per step, six steps cost ~0.9 s on every rank
+    # (not 0.9 s x the world size: skew does not accumulate).  "overlap": a rank may run one step ahead of the exchange, so the
+    # alternating delays partly hide behind each other (~0.45 s)
+    lo = 0.85 if gather == "stream" else 0.4
+    assert all(lo < o[1] < 2.5 for o in oks), oks
+
+
+def test_gather_mode_is_validated():
+    with pytest.raises(ValueError):
+        ShardedLifter(lambda *a, **k: None, gather="sometimes")
+
+
 def test_single_rank_group_still_runs_the_collective():
     """World size 1: the all-gather is issued all the same (no single-GPU shortcut to go untested)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -169,25 +238,49 @@ def test_single_rank_group_still_runs_the_collective():
 
 def test_sharded_lifter_asks_the_model_for_batch_invariant_bits():
     """A shard must equal the rows of the single-process result bit for bit whatever the world size leaves of the batch: the lifter
-    switches the model's small-batch engine (another fp32 arithmetic for <= 32 token rows) off -- on the model itself and, for the
-    cfg wrapper MultiView_MPL_G, on the model inside (.features).  No process group is needed for that."""
-    class Inner:
-        mode = "auto"
+    switches the model's small-batch engine (another fp32 arithmetic for <= 32 token rows) off -- on the model itself or, for the
+    cfg wrapper MultiView_MPL_G, on the model inside (.features) -- for the duration of ITS OWN calls only: the
+    caller's setting is back afterwards, also when the forward raises, and merely wrapping a model changes nothing."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        class Inner:
+            def __init__(self):
+                self._small_batch_engine = True
+                self.seen = []
+                self.fail = False
 
-        def set_small_batch_engine(self, mode):
-            self.mode = mode
+            def set_small_batch_engine(self, mode):
+                self._small_batch_engine = mode
 
-    class Wrapper:
-        def __init__(self):
-            self.features = Inner()
+            def __call__(self, poses, rays=None, centers=None):
+                self.seen.append(self._small_batch_engine)
+                if self.fail:
+                    raise RuntimeError("forward failed")
+                return poses[0] * 2
 
-        def __call__(self, *a, **k):
-            raise AssertionError("not called here")
+        class Wrapper:
+            def __init__(self):
+                self.features = Inner()
 
-    inner = Inner()
-    ShardedLifter(inner)
-    assert inner.mode is False
-    w = Wrapper()
-    ShardedLifter(w)
-    assert w.features.mode is False
-    ShardedLifter(lambda poses, rays=None, centers=None: poses[0])        # a plain callable: nothing to switch, no error
+            def __call__(self, poses, rays=None, centers=None):
+                return self.features(poses, rays=rays, centers=centers)
+
+        x = torch.ones(3, 17, 3)
+        inner = Inner()
+        lifter = ShardedLifter(inner)
+        assert inner._small_batch_engine is True and inner.seen == []           # wrapping alone has no side effect
+        assert torch.equal(lifter([x]), x * 2)
+        assert inner.seen == [False] and inner._small_batch_engine is True      # off during the call, restored after it
+        inner.fail = True
+        with pytest.raises(RuntimeError, match="forward failed"):
+            lifter([x])
+        assert inner._small_batch_engine is True
+        w = Wrapper()
+        w.features._small_batch_engine = "auto"
+        assert torch.equal(ShardedLifter(w)([x]), x * 2)
+        assert w.features.seen == [False] and w.features._small_batch_engine == "auto"
+        assert torch.equal(ShardedLifter(lambda poses, rays=None, centers=None: poses[0])([x]), x)   # a plain callable: nothing to switch
+    finally:
+        dist.destroy_process_group()

@@ -27,13 +27,13 @@ def _free_port():
     return p
 
 
-def _run(backend, world, out, batch):
+def _run(backend, world, out, batch, gather="stream"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, WORKER, backend, out, str(batch)], env=env, cwd=ROOT,
+        procs.append(subprocess.Popen([sys.executable, WORKER, backend, out, str(batch), gather], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -51,15 +51,16 @@ def _run(backend, world, out, batch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2])
-@pytest.mark.parametrize("batch", [64, 37, 12, 5])
-def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch, world):
+@pytest.mark.parametrize("batch,gather", [(64, "stream"), (37, "stream"), (12, "stream"), (5, "stream"), (64, "overlap"), (12, "overlap")])
+def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch, gather, world):
     """batch 12 / 5 at V = 4: shards (and at world 1 the whole batch) of at most 32 token rows -- the sizes at which the
-    small-batch engine would otherwise change the bits (ShardedLifter switches it off)."""
+    small-batch engine would otherwise change the bits (ShardedLifter switches it off for its own calls).  Both places the
+    collective can run: ordered into the compute stream (default) and on the process group's stream beside the next forward."""
     if torch.cuda.device_count() < world:
         pytest.skip("world size %d needs %d GPUs, this box has %d (the N > 1 RCCL leg stays unmeasured here)"
                     % (world, world, torch.cuda.device_count()))
     single = _run("single", 1, str(tmp_path / "single.npz"), batch)
-    got = _run("nccl", world, str(tmp_path / ("w%d.npz" % world)), batch)
+    got = _run("nccl", world, str(tmp_path / ("w%d.npz" % world)), batch, gather)
     for i in range(2):
         assert got["full%d" % i].shape == (batch, 17, 3)
         assert np.array_equal(got["full%d" % i], single["full%d" % i]), "world %d full-batch call differs" % world

@@ -35,6 +35,48 @@ def _inputs(B, seed):
     return mk(p), mk(r), mk(c)
 
 
+def test_confidence_weights_beyond_the_fp16_window_are_reported_not_saturated():
+    """confidence_as_attention_uncertainty_weight multiplies the softmax rows of the SPT attention by the caller's `conf`
+    (reference multiview_mpl.py:61-62), which is data: the static scales of the split-operand engine cannot bound it.  Rounds 3-5
+    clamped the weighted attention output to +-65000 -- saturated operands, plausible-looking poses.  Now an out-of-window row
+    poisons ITS sequence (NaN poses), sets bit 1 of the device error word and every later call raises until cleared; the
+    native-fp32 engine has no window and gives the reference's result for the same input.  Ordinary confidences never get there."""
+    from oracle import mpl_oracle
+    flags = dict(FLAGS, num_views=3, confidence_as_attention_uncertainty_weight=True)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=23)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    p, r, c = detrng.make_inputs(6, 3, seed=4)
+    P, R, C = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    huge = [x.clone() for x in P]
+    for x in huge:
+        x[2:4, :, 2] = 1e6                                  # poses 2 and 3 carry absurd confidences, the others stay in [0, 1]
+    dev = lambda lst: [x.to(DEV) for x in lst]
+    ref = mpl_oracle.forward(sd, flags, huge, R, C, dtype=torch.float64)
+    assert torch.isfinite(ref).all()                       # the reference semantics are fine with it
+    with torch.no_grad():
+        ok = m(dev(P), rays=dev(R), centers=dev(C))
+        torch.cuda.synchronize()
+        assert torch.isfinite(ok).all() and not cabi.device_error()
+        bad = m(dev(huge), rays=dev(R), centers=dev(C))
+        torch.cuda.synchronize()
+        assert torch.isnan(bad[2:4]).all(), "saturated operands must not turn into poses"
+        assert torch.equal(bad[[0, 1, 4, 5]], ok[[0, 1, 4, 5]])       # the other sequences are untouched
+        assert cabi.load().mpl_device_error(-1) & 2
+        with pytest.raises(RuntimeError, match="fp16 window"):
+            m(dev(P), rays=dev(R), centers=dev(C))
+        with pytest.raises(RuntimeError, match="fp16 window"):
+            cabi.raise_if_device_error(synchronize=True)
+        cabi.clear_device_error()
+        m.set_matmul_precision("fp32_mfma")                # no window: the same input, the reference's answer
+        full = m(dev(huge), rays=dev(R), centers=dev(C))
+        torch.cuda.synchronize()
+    assert not cabi.device_error()
+    mx, nw = mpl_oracle.rel_errors(full.cpu(), ref)
+    assert mx < 1e-4 and nw < 1e-4, (mx, nw)
+
+
 def test_lost_handoff_is_reported_never_ignored():
     lib = cabi.load()
     m = _model()

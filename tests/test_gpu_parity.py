@@ -212,6 +212,61 @@ def test_kptok_large_view_stress():
         _assert_close(big[sl], ref, "kptok V=31 B=256")
 
 
+def test_kptok_v31_depth12_at_the_timed_size():
+    """The shape bench.py times for BASELINE configs[4] in its joints x views form (`--flagset kptok --views 31 --batch 256`, and
+    extra.legs.v31_b256_kptok): V=31, depth 12, batch 256 -- round 5 gated this variant at depth 2 only.  Poses against the fp64
+    oracle (the first and last three: the CPU oracle needs ~10 s per pose-triple at 527 tokens x 13 block applications), the rest
+    of the batch through batch-slice equality (bitwise: poses are independent)."""
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=12, num_views=31, pose_3d_emb_learnable=True,
+                 FPT_blocks_view_keypoint_tokens=True)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=22)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    p, r, c = detrng.make_inputs(256, 31, seed=6)
+    P, R, Cn = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    dev = lambda lst, sl=slice(None): [x[sl].contiguous().to(DEV) for x in lst]
+    with torch.no_grad():
+        big = m(dev(P), rays=dev(R), centers=dev(Cn))
+        assert torch.isfinite(big).all()
+        for sl in (slice(0, 3), slice(253, 256), slice(97, 160)):
+            assert torch.equal(big[sl], m(dev(P, sl), rays=dev(R, sl), centers=dev(Cn, sl))), "kptok depth 12: batch slice changed results"
+    for sl in (slice(0, 3), slice(253, 256)):
+        ref = mpl_oracle.forward(sd, flags, [x[sl] for x in P], [x[sl] for x in R], [x[sl] for x in Cn], dtype=torch.float64)
+        _assert_close(big[sl], ref, "kptok V=31 depth 12 B=256 poses %s" % (sl,))
+
+
+def test_bf16_v8_depth12_at_the_timed_size():
+    """BASELINE configs[2] at the depth bench.py also times (extra.cmu_v8_depth12: V=8, B=1024, depth 12, bf16) -- round 5 gated
+    V=8 at depth 2 and depth 12 at V=4 only.  The whole batch runs on the GPU; 64 poses from both ends go through the oracle's
+    bf16-operand emulation (same rounding points, fp64 accumulation: tight) and through the fp64 reference semantics (loose,
+    reported: SURVEY.md 8c), the rest of the batch through batch-slice equality."""
+    flags = dict(num_joints=17, embed_dim_ratio=32, num_heads=8, depth=12, num_views=8, pose_3d_emb_learnable=True)
+    m = MultiView_MPL(**flags)
+    detrng.fill_module_(m, seed=24)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    m.set_matmul_precision("bf16")
+    p, r, c = detrng.make_inputs(1024, 8, seed=78)
+    P, R, Cn = ([torch.from_numpy(x) for x in l] for l in (p, r, c))
+    dev = lambda lst, sl=slice(None): [x[sl].contiguous().to(DEV) for x in lst]
+    with torch.no_grad():
+        big = m(dev(P), rays=dev(R), centers=dev(Cn))
+        assert torch.isfinite(big).all()
+        for sl in (slice(0, 32), slice(992, 1024), slice(300, 556)):
+            assert torch.equal(big[sl], m(dev(P, sl), rays=dev(R, sl), centers=dev(Cn, sl))), "bf16 V=8 depth 12: batch slice changed results"
+    for sl in (slice(0, 32), slice(992, 1024)):
+        cut = lambda lst: [x[sl] for x in lst]
+        emu = mpl_oracle.forward(sd, flags, cut(P), cut(R), cut(Cn), dtype=torch.float64, fpt_matmul_bf16=True)
+        ref = mpl_oracle.forward(sd, flags, cut(P), cut(R), cut(Cn), dtype=torch.float64)
+        mx, nw = mpl_oracle.rel_errors(big[sl].cpu(), emu)
+        dx, dn = mpl_oracle.rel_errors(big[sl].cpu(), ref)
+        print("bf16 V=8 depth 12 B=1024 poses %s: vs bf16-emulation %.2e/%.2e ; vs fp64 reference semantics %.2e/%.2e ; MPJPE-vs-ref %.3e"
+              % (sl, mx, nw, dx, dn, mpl_oracle.mpjpe(big[sl].cpu(), ref)))
+        assert mx < 3e-3 and nw < 2.5e-3, "bf16 path deviates from its own emulation: %.2e %.2e" % (mx, nw)
+        assert dx < 5e-2 and dn < 5e-2
+
+
 @pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 1024), ("full_v4_b8_l12", 1024), ("chosen_v8_b4_l2", 1024),
                                     ("chosen_v31_b2_l12", 256)])
 def test_full_size_batch_against_oracle(name, B):
@@ -332,8 +387,9 @@ def test_small_batches_follow_the_engine_contract():
             assert mx < 5e-6 and nw < 5e-6, (n, mx, nw)                 # the other fp32 engine: rounding apart, same result
         part = m(cut(P, 0, 9), rays=cut(R, 0, 9), centers=cut(Cn, 0, 9))
         assert torch.equal(part, full[:9])                              # 36 rows: the team kernels again
+    m.set_small_batch_engine(True)
     ShardedLifter(m)
-    assert m._small_batch_engine is False                               # sharded lifting is batch-invariant by construction
+    assert m._small_batch_engine is True        # wrapping leaves the caller's setting alone (the lifter applies False per call)
     m.set_small_batch_engine("auto")
 
 
@@ -345,7 +401,7 @@ def test_forward_as_torch_operator_passes_opcheck_and_is_bitwise_the_direct_call
     P, R, Cn = golden_inputs(g, DEV)
     with torch.no_grad():
         direct = m(P, rays=R, centers=Cn)
-        torch.library.opcheck(torch.ops.openmpl_amd.forward, (m._op_handle, P, R, Cn),
+        torch.library.opcheck(torch.ops.openmpl_amd.forward, (m._handle(), P, R, Cn),
                               test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
         m.use_torch_op(True)
         via_op = m(P, rays=R, centers=Cn)
@@ -359,6 +415,19 @@ def test_forward_as_torch_operator_passes_opcheck_and_is_bitwise_the_direct_call
     assert torch.equal(direct, via_op) and torch.equal(direct, profiled)
     assert torch.equal(compiled, direct * 2.0)
     _assert_close(direct, torch.from_numpy(g["out"]), "direct route vs golden")
+    # a deepcopy with modified weights runs ITS OWN weights through the operator route (the inherited handle of the
+    # original is re-issued), and the original is unaffected
+    import copy
+    c = copy.deepcopy(m)
+    with torch.no_grad():
+        c.head[1].bias.add_(0.25)
+        c.use_torch_op(True)
+        m.use_torch_op(True)
+        out_c, out_m = c(P, rays=R, centers=Cn), m(P, rays=R, centers=Cn)
+        c.use_torch_op(False)
+        assert torch.equal(out_c, c(P, rays=R, centers=Cn)) and torch.equal(out_m, direct)
+    assert torch.allclose(out_c, direct + 0.25, atol=1e-5) and not torch.equal(out_c, direct)
+    m.use_torch_op("auto")
 
 
 def test_configs3_batch_8192_equals_its_eight_shards_bitwise():
@@ -456,8 +525,10 @@ def test_bf16_matmul_path(name, B):
     # flips: it moved from 7.1e-4 to 1.02e-3 (FULL, 8 views) when the attention of 8-token sequences went from the LDS form to
     # registers in round 5 (another fp32 summation order in the softmax: fp32 noise, which flips other bf16 roundings) while the
     # norm-wise error stayed at 5.5e-4 and the fp32 engine with the same attention code stays at ~1e-6 of every golden
+    # the looser 1.5e-3 is for the ONE case that moved (FULL flag set, 8 views); every other depth-2 shape keeps 1e-3
     deep = g["flags"]["depth"] > 2
-    assert mx < (3e-3 if deep else 1.5e-3) and nw < (2.5e-3 if deep else 7e-4), \
+    mx_tol = 3e-3 if deep else (1.5e-3 if name == "full_v8_b4_l2" else 1e-3)
+    assert mx < mx_tol and nw < (2.5e-3 if deep else 7e-4), \
         "bf16 path deviates from its own emulation: %.2e %.2e" % (mx, nw)
     assert dx < 5e-2 and dn < 5e-2
     m.set_matmul_precision("fp32")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Prebuild library variants of ONE source file (default h2_gemm.hip) for A/B runs inside one gpurun call:
 #   bash tools/build_variants.sh [-f file.hip] tag1="-DH2_DBG=1" tag2="-DH2_ABL=2" ...   ->  build_tmp/lib_<tag>.so
+# (-DMPL_LAB is passed for the varied file: the H2_* switches are compile errors in the product build, csrc/h2_phase.hpp)
 # The other objects are compiled once (build_tmp/obj).  On the GPU box: cp build_tmp/lib_<tag>.so openmpl_amd/lib/libmpl_hip.so
 # (the source hash stamp of the default build stays valid, so cabi.load() does not rebuild).
 set -e
@@ -20,7 +21,7 @@ wait
 n=0
 for v in "$@"; do
   tag=${v%%=*}; flags=${v#*=}
-  ( $CC $flags -c openmpl_amd/csrc/$F -o build_tmp/obj/${F%.hip}.$tag.o
+  ( $CC -DMPL_LAB $flags -c openmpl_amd/csrc/$F -o build_tmp/obj/${F%.hip}.$tag.o
     objs=""
     for s in $SRCS; do if [ "$s" = "$F" ]; then objs="$objs build_tmp/obj/${F%.hip}.$tag.o"; else objs="$objs build_tmp/obj/${s%.hip}.o"; fi; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_tmp/lib_$tag.so $objs

@@ -1,4 +1,5 @@
-"""Time of the fused SPT kernel with one phase compiled... switched off at a time (MPL_SPT_ABL bits: 8 qkv, 1 attention, 32 proj,
+"""(needs a laboratory build of spt.hip: bash tools/build_variants.sh -f spt.hip lab="" -> build_tmp/lib_lab.so; the product library ignores MPL_SPT_ABL)
+Time of the fused SPT kernel with one phase compiled... switched off at a time (MPL_SPT_ABL bits: 8 qkv, 1 attention, 32 proj,
 64 fc1 + GELU, 128 fc2; results are garbage): [SPT_V=2 SPT_B=256] python tools/spt_abl.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
