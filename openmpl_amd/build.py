@@ -119,5 +119,75 @@ def _build_locked(verbose: bool) -> str:
                 pass
 
 
+# ---------------------------------------------------------------------------------------------- the torch extension
+# csrc/torch_ext.cpp: TORCH_LIBRARY operators (openmpl_amd::bind / lift / unbind) over the C ABI -- host C++ only (g++), links
+# against torch, reaches libmpl_hip.so through entry-point addresses handed over at load time.  Built in-tree like the library.
+EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
+EXT_PATH = os.path.join(LIB_DIR, "mpl_torch_ext.so")
+EXT_STAMP = EXT_PATH + ".srchash"
+
+
+def ext_source_hash() -> str:
+    import hashlib
+    import torch
+    h = hashlib.sha256()
+    h.update(torch.__version__.encode())
+    for d in (EXT_SRC, HEADERS[-1]):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def ext_needs_build() -> bool:
+    if not os.path.exists(EXT_PATH) or not os.path.exists(EXT_STAMP):
+        return True
+    try:
+        return open(EXT_STAMP).read().strip() != ext_source_hash()
+    except OSError:
+        return True
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    if not force and not ext_needs_build():
+        return EXT_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    import fcntl
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise CompilerMissing("no C++ compiler for the torch extension")
+    with open(os.path.join(LIB_DIR, ".build_ext.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not ext_needs_build():
+                return EXT_PATH
+            srchash = ext_source_hash()
+            tag = ".%d" % os.getpid()
+            tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+            inc = [i for p in ce.include_paths(True) for i in ("-I", p)] + ["-I", "/opt/rocm/include"]
+            cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+                   "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc + \
+                  [EXT_SRC, "-o", EXT_PATH + tag, "-L", tlib, "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", "-lamdhip64",
+                   "-Wl,-rpath," + tlib]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                try:
+                    os.remove(EXT_PATH + tag)
+                except OSError:
+                    pass
+                raise RuntimeError("torch extension build failed:\n" + r.stdout.decode(errors="replace"))
+            os.replace(EXT_PATH + tag, EXT_PATH)
+            with open(EXT_STAMP + tag, "w") as f:
+                f.write(srchash + "\n")
+            os.replace(EXT_STAMP + tag, EXT_STAMP)
+            return EXT_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

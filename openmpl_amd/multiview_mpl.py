@@ -141,6 +141,24 @@ def _forward_op_fake(handle, poses, rays, centers):
     return [poses[0].new_empty((B, m.num_joints, 3), dtype=torch.float32) for _ in range(n)]
 
 
+_EXT_LIFT = [None]        # torch.ops.openmpl_amd.lift once the extension is loaded (openmpl_amd/torch_ext.py)
+
+
+def _unbind(handle: int):
+    try:
+        if _EXT_LIFT[0] is not None:
+            torch.ops.openmpl_amd.unbind(int(handle))
+        from . import torch_ext
+        torch_ext._FAKE_SHAPES.pop(int(handle), None)
+    except Exception:          # interpreter shutdown: the extension may already be gone
+        pass
+
+
+def _release_binding(ent):
+    if ent is not None and ent.get("bind") is not None:
+        _unbind(ent.pop("bind"))
+
+
 class MultiView_MPL(nn.Module):
     """Constructor surface and parameter layout of the reference ``MultiView_MPL`` (:94-317)."""
 
@@ -285,6 +303,7 @@ class MultiView_MPL(nn.Module):
         self._dp_replica = False
         self._dp_src = None
         self.matmul_precision = "fp32"
+        self.__dict__["_fast_bind"] = {}                    # device index -> (binding handle, _STRUCT_GEN, identity probes)
 
     # ------------------------------------------------------------------ support matrix
     def _find_unsupported(self) -> Optional[str]:
@@ -319,7 +338,7 @@ class MultiView_MPL(nn.Module):
         if precision == "bf16" and not self._x3_supported():
             raise NotImplementedError("the %s engine covers the view-token FPT blocks (widths 544 / 1088, up to 32 views)" % precision)
         self.matmul_precision = precision
-        self._hip_cache = {}
+        self._drop_caches()
         return self
 
     def _x3_supported(self) -> bool:
@@ -368,10 +387,17 @@ class MultiView_MPL(nn.Module):
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .half(): under torch.__future__.set_overwrite_module_params_on_conversion the parameters are REPLACED
         # without any registration hook firing, so every cache that holds tensors goes, not only the packed operands
-        self._hip_cache = {}
+        self._drop_caches()
         self.__dict__.pop("_tl_cache", None)
         self.__dict__.pop("_x3_ok", None)
         return super()._apply(fn, *a, **k)
+
+    def _drop_caches(self):
+        """Forget every struct of addresses, derived operand and extension binding of this module (all devices)."""
+        for ent in list(self.__dict__.get("_hip_cache", {}).values()):
+            _release_binding(ent)
+        self._hip_cache = {}
+        self.__dict__["_fast_bind"] = {}
 
     def _replicate_for_data_parallel(self):
         """DataParallel replicas (valid_mpl.py:177-178) are shallow copies that torch re-creates on EVERY forward with freshly
@@ -381,6 +407,7 @@ class MultiView_MPL(nn.Module):
         rebuilds the small struct of addresses (_marshal).  Round 3 re-packed everything per forward (1.2 ms of GPU time)."""
         r = super()._replicate_for_data_parallel()
         r._dp_replica = True
+        r.__dict__["_fast_bind"] = {}               # replicas take the ctypes route (fresh parameter tensors every forward)
         # a plain attribute: nn.Module.__setattr__ would register the source module as a CHILD of its own replica
         r.__dict__["_dp_src"] = self._dp_src if self._dp_replica else self
         return r
@@ -554,8 +581,68 @@ class MultiView_MPL(nn.Module):
             # the packing kernels ran on THIS stream: the event and the stream stay with the derived operands, which outlive the
             # struct when only addresses change (DataParallel replicas) -- a later forward on another stream waits for it too
             derived["ready"], derived["stream"] = new["ready"], st
+        _release_binding(ent)                  # the extension binding of the entry this one replaces
         self._hip_cache[device.index] = new
         return new
+
+    def _bind(self, ent, dev) -> int:
+        """Register a marshalled entry with the torch extension (csrc/torch_ext.cpp openmpl_amd::bind): the structs as bytes, the
+        parameter tensors they point into (the extension compares their data_ptr / _version on every call: a changed tensor makes
+        lift() answer "stale" and the forward comes back here), and what must stay alive (device blob, derived operands)."""
+        from . import torch_ext
+        ext = torch_ext.ops()
+        plist, fpt, spt = self._tensor_lists()
+        h2, bf16, spt3, d32 = ent["dkey"][1:5]
+        folded = set(id(t) for t in ((fpt if (h2 or bf16 or d32) else []) + (spt if spt3 else [])))
+        versioned = [1 if id(t) in folded else 0 for t in plist]
+        dv = ent["derived"]
+        keep = [ent["keep"][0]] + list(dv["spt"].values()) + list(dv["d32"].values()) + [t for ops in dv["fpt"].values() for t in ops]
+        cur = torch.cuda.current_stream(dev)
+        if dv.get("stream", cur.cuda_stream) != cur.cuda_stream:       # operands packed on another stream: the binding's own event
+            cur.wait_event(dv["ready"])                               # (recorded on the current stream in bind) must cover them
+        if ent["ready_stream"] != cur.cuda_stream:
+            cur.wait_event(ent["ready"])
+        needs_rays = bool(self.input_rays_as_token or not self.pose_3d_emb_learnable)
+        h = int(ext.bind(torch_ext.struct_bytes(ent["cfg"]), torch_ext.struct_bytes(ent["weights"]),
+                         torch_ext.struct_bytes(ent["fpt_blocks"]), list(plist), versioned, keep, dev.index, needs_rays))
+        torch_ext._FAKE_SHAPES[h] = self.num_joints
+        ent["bind"] = h
+        _weakref.finalize(self, _unbind, h)       # a module that dies without being cleared must not pin its parameters in C++
+        return h
+
+    def _forward_fast(self, poses, rays, centers):
+        """The default tail through the extension operator openmpl_amd::lift: ONE dispatcher call per forward.  Returns None when
+        this call has to take the general route (which also owns every error message): replicas, non-default tails, train mode,
+        unsupported flag sets, inputs that are not on a GPU."""
+        t0 = poses[0] if len(poses) else None
+        if t0 is None or not t0.is_cuda or self.training:
+            return None
+        flags = 0 if self._small_engine_allowed() else cabi.F_NO_SMALL_STACK
+        f = self._fast_bind.get(t0.device.index)
+        if f is not None and f[1] == _STRUCT_GEN[0] and all(a is b for a, b in zip(f[2], self._tl_probe())):
+            out = _EXT_LIFT[0](f[0], poses, rays or (), centers or (), flags)
+            if out.dim() != 0:
+                return out
+        # no binding for this device yet, or a parameter moved / changed: marshal (the slow, complete check) and bind again
+        if self._unsupported or self.linear_weighted_mean or self.deep_head or self.head_kadkhod or not _HOOKS_OK:
+            return None
+        dev = self.Spatial_norm.weight.device
+        if dev != t0.device:
+            return None
+        from . import torch_ext
+        if _EXT_LIFT[0] is None:
+            _EXT_LIFT[0] = torch_ext.ops().lift
+        with torch.cuda.device(dev):
+            ent = self._marshal(dev)
+            h = ent.get("bind")
+            if h is None:
+                h = self._bind(ent, dev)
+        self._fast_bind[dev.index] = (h, _STRUCT_GEN[0], self._tl_probe())
+        out = _EXT_LIFT[0](h, poses, rays or (), centers or (), flags)
+        if out.dim() == 0:
+            raise RuntimeError("openmpl_amd::lift reports a stale binding right after it was made (a parameter is being modified "
+                               "concurrently with the forward)")
+        return out
 
     @staticmethod
     def _pack_block(lib, b, device, st, bf16):
@@ -617,11 +704,14 @@ class MultiView_MPL(nn.Module):
 
     # ------------------------------------------------------------------ forward (reference :450-525)
     def use_torch_op(self, mode="auto"):
-        """How forward() reaches the kernels: True -- always through the registered operator openmpl_amd::forward; False -- always
-        the direct ctypes call; "auto" (default) -- through the operator whenever something is watching the dispatcher (a
-        torch.profiler session, torch.compile tracing) and directly otherwise: the direct call is what the benchmarks time, the
-        operator adds the dispatcher's Python round trip (tools/small_batch.py measures it) and nothing else -- same kernels,
-        same stream, bitwise the same poses."""
+        """How forward() reaches the kernels -- every route is the same C-ABI call on the same stream, bitwise the same poses:
+        "auto" (default) -- the C++ operator openmpl_amd::lift of the torch extension (csrc/torch_ext.cpp: one dispatcher call,
+            the parameter check, the allocations and mpl_forward in C++; visible to torch.profiler) for the default tail;
+            replicas of DataParallel, the non-default tails (linear_weighted_mean / deep_head / head_kadkhod) and torch.compile
+            traces take the routes below;
+        True -- the Python-defined operator openmpl_amd::forward (torch.library.custom_op: every flag set, traceable by
+            torch.compile(fullgraph=True) as one node; costs the dispatcher's Python round trip);
+        False -- the direct ctypes call (no dispatcher at all)."""
         if mode not in (True, False, "auto"):
             raise ValueError("use_torch_op: True, False or 'auto'")
         self.__dict__["_use_torch_op"] = mode
@@ -658,6 +748,10 @@ class MultiView_MPL(nn.Module):
 
     def forward(self, poses: Sequence[torch.Tensor], rays=None, centers=None):
         mode = self._use_torch_op
+        if mode == "auto" and not self._dp_replica and not torch.compiler.is_compiling():
+            out = self._forward_fast(poses, rays, centers)           # the C++ operator openmpl_amd::lift (csrc/torch_ext.cpp)
+            if out is not None:
+                return out
         if mode is True or (mode == "auto" and not self._dp_replica and
                             (torch.compiler.is_compiling() or torch.autograd.profiler._is_profiler_enabled)):
             out = torch.ops.openmpl_amd.forward(self._handle(), list(poses), list(rays) if rays is not None else [],

@@ -37,7 +37,7 @@ for fs, V, Bs in (("chosen", 2, (1, 8, 16, 32)), ("chosen", 4, (1, 4, 8, 12, 16)
         cabi.check(lib.mpl_x3_stack_mode(0), "mode")
         # the registered torch operator (openmpl_amd::forward) against the direct ctypes call: host time per call, not synchronised
         host = {}
-        for route in (False, True):
+        for route in (False, True, "auto"):
             m.use_torch_op(route)
             with torch.no_grad():
                 for i in range(5):
@@ -48,8 +48,13 @@ for fs, V, Bs in (("chosen", 2, (1, 8, 16, 32)), ("chosen", 4, (1, 4, 8, 12, 16)
                     m(b[i % 2][0], rays=b[i % 2][1], centers=b[i % 2][2])
                 host[route] = (time.perf_counter() - t0) / 200 * 1e6
                 torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(100):
+                    m(b[i % 2][0], rays=b[i % 2][1], centers=b[i % 2][2])
+                    torch.cuda.synchronize()
+                host[(route, "sync")] = (time.perf_counter() - t0) / 100 * 1e6
         m.use_torch_op("auto")
-        res["host us per call direct / via torch op"] = (host[False], host[True], 0.0, 0.0)
+        res["host us per call direct / via torch op"] = (host[False], host[True], host["auto"], host[(False, "sync")], host[(True, "sync")], host[("auto", "sync")])
         print("%-6s V=%d B=%2d | " % (fs, V, B) + " | ".join("%s: %.0f us per call (%.0f back to back; stack %.0f, SPT %.0f)" % ((t,) + res[t]) for t in res if not t.startswith("host")) +
-              " | host: direct %.1f us, via openmpl_amd::forward %.1f us" % res["host us per call direct / via torch op"][:2], flush=True)
+              " | host enqueue per call: ctypes %.1f us, Python op openmpl_amd::forward %.1f us, C++ op openmpl_amd::lift (default) %.1f us; synchronised per call: %.0f / %.0f / %.0f us" % res["host us per call direct / via torch op"], flush=True)
     del m
