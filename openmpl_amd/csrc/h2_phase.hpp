@@ -34,7 +34,7 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 // switch it varies; the values and what they do are unchanged from rounds 3-5.
 #ifndef MPL_LAB
 #if defined(H2_DBG) || defined(H2_ABL) || defined(H2_DW_PIN) || defined(H2_WT_AUX) || defined(H2_WSPLIT) || defined(H2_R2_AB) || \
-    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2)
+    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2) || defined(H2_PRIO)
 #error "H2_* experiment switches are laboratory-only: build with -DMPL_LAB (tools/build_variants.sh does)"
 #endif
 #endif
@@ -70,6 +70,9 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
 #ifndef H2_TAIL_LOOP
 #define H2_TAIL_LOOP 1
+#endif
+#ifndef H2_PRIO
+#define H2_PRIO 0       // 1 / 2: static s_setprio 1 for the waves 4..7 / 0..3 of the whole-tile stack kernel (guide: "static priority for the younger half")
 #endif
 #ifndef H2_KPS2
 #define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
@@ -1619,6 +1622,8 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
     h2_publish_xcd(s, team, tid);
     int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
+    if (H2_PRIO == 1 && wave_s >= 4) __builtin_amdgcn_s_setprio(1);
+    if (H2_PRIO == 2 && wave_s < 4) __builtin_amdgcn_s_setprio(1);
     __syncthreads();
     for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
         unsigned need = 0;

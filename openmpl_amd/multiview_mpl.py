@@ -730,6 +730,7 @@ class MultiView_MPL(nn.Module):
         self.__dict__["_small_batch_engine"] = mode
         return self
 
+    @torch.compiler.assume_constant_result      # a torch.compile trace calls it ONCE, eagerly (the registry is a weak dictionary)
     def _handle(self) -> int:
         """Integer under which THIS object is registered for openmpl_amd::forward.  The handle is a plain __dict__ entry, so
         copy.deepcopy, pickle / torch.save of the module and DataParallel's shallow replicas all inherit the number of the
