@@ -252,8 +252,8 @@ def stack_kernel_name(precision, batch, views, D, dev, launches=1, heads=8, n_ap
     if launches != 1 and parts:
         return cabi.FORM_KERNELS[cabi.FORM_PER_GEMM]
     with torch.cuda.device(dev):
-        form = cabi.load().mpl_block_stack_form(batch, views, D, heads, n_apps, parts, 0)
-    cabi.check(form if form < 0 else 0, "mpl_block_stack_form")
+        form = cabi.load().mpl_block_stack_form_ex(batch, views, D, heads, n_apps, max(1, n_apps - 1), 1, parts, 0)
+    cabi.check(form if form < 0 else 0, "mpl_block_stack_form_ex")
     name = cabi.FORM_KERNELS[form]
     return name % parts if "%d" in name else name
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MPL_HIP_ABI_VERSION 12
+#define MPL_HIP_ABI_VERSION 13
 #define MPL_MAX_VIEWS 32
 #define MPL_MAX_APPS 64 /* max Block applications in one stack schedule */
 
@@ -243,6 +243,15 @@ enum {
     MPL_FORM_PER_GEMM = 7         /* h2_gemm_kernel: one launch per GEMM (mpl_x3_stack_mode bit 0) */
 };
 int mpl_block_stack_form(int n_seq, int n_tok, int D, int heads, int n_apps, int operand_parts, unsigned flags);
+/* The same question with everything the launch rule looks at: n_blocks = distinct blocks the schedule indexes (mpl_block_stack_form
+ * assumes the reference's schedule: n_apps - 1), raw_tensors != 0 = every nn.Linear / LayerNorm tensor of those blocks is present
+ * (the small-batch engine reads them in place; a caller that hands over packed operands only gets the team kernels).  Both queries
+ * and mpl_block_stack(_ex) itself go through ONE predicate (csrc/api.hip small_engine_taken + h2_phase.hpp h2_stack_form). */
+int mpl_block_stack_form_ex(int n_seq, int n_tok, int D, int heads, int n_apps, int n_blocks, int raw_tensors, int operand_parts,
+                            unsigned flags);
+/* MPL_FORM_* of the calling thread's most recent successful mpl_block_stack(_ex) / mpl_forward: the form that was LAUNCHED (incl.
+ * the fall-through when the small-batch engine's occupancy query refuses); negative before the first one. */
+int mpl_block_stack_last_form(void);
 
 /* softmax(q k^T * hd^-0.5) v per (sequence, head) on a packed qkv (n_seq*n_tok, 3*dim). Attention :55-64. */
 int mpl_token_attention(const float *qkv, int n_seq, int n_tok, int dim, int heads, float *out, void *stream);

@@ -14,7 +14,7 @@ from . import build as _build
 
 MPL_MAX_VIEWS = 32
 MPL_MAX_APPS = 64
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # flag bits (mpl_hip.h MPL_F_*)
 F_MULTI_SPT = 1 << 0
@@ -80,7 +80,7 @@ class Inputs(C.Structure):
 
 EXPORTS = ("mpl_hip_abi_version", "mpl_hip_error_string", "mpl_fpt_width", "mpl_forward_workspace_bytes",
            "mpl_forward", "mpl_spt_tokens", "mpl_block_stack_workspace_bytes", "mpl_block_stack", "mpl_block_stack_ex",
-           "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_d32_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_pack_h2_bytes", "mpl_pack_h2", "mpl_pack_h2_scaled", "mpl_pack_h2_out_scale", "mpl_ln_linear_h2_workspace_bytes", "mpl_ln_linear_h2", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_block_stack_form", "mpl_device_error", "mpl_device_error_clear", "mpl_x3_spin_limit", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
+           "mpl_ln_linear", "mpl_spt_pack_bytes", "mpl_spt_pack", "mpl_d32_pack", "mpl_pack_bf16_bytes", "mpl_pack_bf16", "mpl_pack_h2_bytes", "mpl_pack_h2", "mpl_pack_h2_scaled", "mpl_pack_h2_out_scale", "mpl_ln_linear_h2_workspace_bytes", "mpl_ln_linear_h2", "mpl_x3_debug_buffer", "mpl_x3_stack_mode", "mpl_block_stack_form", "mpl_block_stack_form_ex", "mpl_block_stack_last_form", "mpl_device_error", "mpl_device_error_clear", "mpl_x3_spin_limit", "mpl_token_attention", "mpl_fuse_head", "mpl_view_fuse", "mpl_view_norm",
            "mpl_layernorm", "mpl_linear", "mpl_pose_metrics_size", "mpl_pose_metrics", "mpl_pose_metrics_ex", "mpl_prepare_inputs", "mpl_profile_start",
            "mpl_profile_stop")
 KINDS = ("spt", "row_stats", "gemm", "attention", "fuse_head", "pack")
@@ -174,6 +174,10 @@ def load():
         lib.mpl_x3_stack_mode.argtypes = [C.c_int]
         lib.mpl_block_stack_form.restype = C.c_int
         lib.mpl_block_stack_form.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+        lib.mpl_block_stack_form_ex.restype = C.c_int
+        lib.mpl_block_stack_form_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+        lib.mpl_block_stack_last_form.restype = C.c_int
+        lib.mpl_block_stack_last_form.argtypes = []
         for fn in (lib.mpl_device_error, lib.mpl_device_error_clear, lib.mpl_x3_spin_limit):
             fn.restype = C.c_int
             fn.argtypes = [C.c_int]

@@ -277,6 +277,25 @@ int block_stack_h2(float* x, int n_seq, int n_tok, int D, int H, const mpl_block
     return MPL_OK;
 }
 
+thread_local int t_last_form = MPL_E_INVALID;  // MPL_FORM_* of this thread's most recent block-stack launch (mpl_block_stack_last_form)
+
+inline int device_cu_count(int* cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || *cus < 1)
+        return MPL_E_LAUNCH;
+    return MPL_OK;
+}
+
+// THE rule for "the small-batch engine (sm_stack.hip) takes this stack": block_stack_impl launches by it, mpl_block_stack_form
+// reports by it.  np = packed operand parts of the blocks (0 none, 2 fp16x2, 1 bf16: an explicit bf16 request keeps its engine);
+// raw = every nn.Linear / LayerNorm tensor of every scheduled block is present (the engine reads them in place); cus = compute
+// units of the device (every column tile of the widest GEMM needs a workgroup of its own for the grid barrier).
+inline bool small_engine_taken(int np, bool allow_small, int M, int D, int n_tok, int H, int n_apps, int n_blocks, bool raw, int cus) {
+    return (np == 0 || np == 2) && allow_small && sm_stack_enabled() && n_apps <= MPL_MAX_APPS && raw &&
+           !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0 && sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks) &&
+           3 * D / 16 <= cus;
+}
+
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
                      const uint8_t* schedule, int n_apps, void* ws, size_t ws_bytes, const unsigned** err_ws, bool allow_small,
                      hipStream_t s) {
@@ -290,9 +309,9 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
     // (not when the caller asked for batch-invariant bits -- MPL_F_NO_SMALL_STACK --, nor under the A/B switches of the team
-    // kernels: one launch per GEMM, stop after n phases)
-    if ((np0 == 0 || np0 == 2) && allow_small && sm_stack_enabled() && n_apps <= MPL_MAX_APPS &&
-        !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0) {
+    // kernels: one launch per GEMM, stop after n phases).  ONE predicate decides (small_engine_taken): this function launches
+    // by it and mpl_block_stack_form reports by it.
+    if (n_apps <= MPL_MAX_APPS && (long long)n_seq * n_tok <= sm_stack_max_rows()) {
         int n_blocks = 0;
         bool raw = true;        // the engine reads the nn.Linear tensors in place: a caller that hands over packed operands only
         for (int a = 0; a < n_apps; ++a) {      // (the C ABI allows it) gets the team kernels, not an error
@@ -301,16 +320,28 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
             raw = raw && b.ln1_w && b.ln1_b && b.qkv_w && b.qkv_b && b.proj_w && b.proj_b && b.ln2_w && b.ln2_b && b.fc1_w && b.fc1_b &&
                   b.fc2_w && b.fc2_b;
         }
-        if (raw && sm_stack_ok(n_seq * n_tok, D, n_tok, H, n_apps, n_blocks)) {
+        int cus = 0;
+        if (device_cu_count(&cus) != MPL_OK) return MPL_E_LAUNCH;
+        if (small_engine_taken(np0, allow_small, n_seq * n_tok, D, n_tok, H, n_apps, n_blocks, raw, cus)) {
             const int rc = launch_sm_stack(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, g_spin_log2.load(), s);
-            if (rc != MPL_E_UNSUPPORTED) return rc;       // fewer CUs than column tiles: the team kernels below
+            if (rc != MPL_E_UNSUPPORTED) {               // (UNSUPPORTED: the occupancy query refused one workgroup per CU -- the team kernels below)
+                if (rc == MPL_OK) t_last_form = MPL_FORM_SMALL;
+                return rc;
+            }
             if (err_ws) *err_ws = nullptr;
         }
     }
     if (const int np = np0) {
-        if (np == 2) return block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
-        return block_stack_b1(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
+        const int rc = np == 2 ? block_stack_h2(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s)
+                               : block_stack_b1(x, n_seq, n_tok, D, H, blocks, schedule, n_apps, ws, ws_bytes, err_ws, s);
+        if (rc == MPL_OK) {
+            int cus = 0;
+            t_last_form = g_x3_per_gemm.load(std::memory_order_relaxed) ? (int)MPL_FORM_PER_GEMM
+                          : (device_cu_count(&cus) == MPL_OK ? h2_stack_form_code(n_seq * n_tok, D, n_tok, np, cus) : (int)MPL_E_LAUNCH);
+        }
+        return rc;
     }
+    t_last_form = MPL_FORM_UNPACKED;
     const int M = n_seq * n_tok;
     const StackWs w = carve_stack_ws(ws, (size_t)M, (size_t)D);
     if (!ws || ws_bytes < w.bytes) return MPL_E_WORKSPACE;
@@ -568,26 +599,30 @@ int mpl_ln_linear_h2(const float* x, int M, int K, int has_ln, float eps, const 
     return launch_h2_gemm(nullptr, a2, sc + 2, W2, false, nullptr, 0.f, residual, N, y, N, nullptr, nullptr, M, N, K, 64, epilogue, s);
 }
 
-int mpl_block_stack_form(int n_seq, int n_tok, int D, int heads, int n_apps, int operand_parts, unsigned flags) {
-    if (n_seq <= 0 || n_tok <= 0 || D <= 0 || heads <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS || operand_parts < 0 || operand_parts > 2)
+int mpl_block_stack_form_ex(int n_seq, int n_tok, int D, int heads, int n_apps, int n_blocks, int raw_tensors, int operand_parts,
+                            unsigned flags) {
+    if (n_seq <= 0 || n_tok <= 0 || D <= 0 || heads <= 0 || n_apps <= 0 || n_apps > MPL_MAX_APPS || n_blocks <= 0 || n_blocks > n_apps ||
+        operand_parts < 0 || operand_parts > 2)
         return MPL_E_INVALID;
     if ((long long)n_seq * n_tok > (1ll << 30)) return MPL_E_UNSUPPORTED;
     const int M = n_seq * n_tok;
-    // the same questions, in the same order, as block_stack_impl asks
+    // the same questions, in the same order, as block_stack_impl asks -- through the same predicates
     const int np = (h2_attention_fusable(n_tok, D, heads) && h2_shape_ok(D, 2 * D)) ? operand_parts : 0;
-    const bool per_gemm = g_x3_per_gemm.load(std::memory_order_relaxed);
-    if ((np == 0 || np == 2) && !(flags & MPL_F_NO_SMALL_STACK) && sm_stack_enabled() && !per_gemm && g_x3_stop.load() == 0 &&
-        sm_stack_ok(M, D, n_tok, heads, n_apps, n_apps < 24 ? n_apps : 24)) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MPL_E_LAUNCH;
-        if (3 * D / 16 <= cus) return MPL_FORM_SMALL;
-    }
+    int cus = 0;
+    if (device_cu_count(&cus) != MPL_OK) return MPL_E_LAUNCH;
+    if (M <= sm_stack_max_rows() && small_engine_taken(np, !(flags & MPL_F_NO_SMALL_STACK), M, D, n_tok, heads, n_apps, n_blocks, raw_tensors != 0, cus))
+        return MPL_FORM_SMALL;
     if (np == 0) return MPL_FORM_UNPACKED;
-    if (per_gemm) return MPL_FORM_PER_GEMM;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+    if (g_x3_per_gemm.load(std::memory_order_relaxed)) return MPL_FORM_PER_GEMM;
     return h2_stack_form_code(M, D, n_tok, np, cus);
 }
+
+// the reference's schedule (every block once, the last one twice: multiview_mpl.py:420-423) with the nn.Linear tensors present
+int mpl_block_stack_form(int n_seq, int n_tok, int D, int heads, int n_apps, int operand_parts, unsigned flags) {
+    return mpl_block_stack_form_ex(n_seq, n_tok, D, heads, n_apps, n_apps > 1 ? n_apps - 1 : 1, 1, operand_parts, flags);
+}
+
+int mpl_block_stack_last_form(void) { return t_last_form; }
 
 int mpl_x3_stack_mode(int one_launch_per_gemm) {
     g_x3_per_gemm.store((one_launch_per_gemm & 1) != 0);

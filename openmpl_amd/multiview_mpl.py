@@ -384,6 +384,21 @@ class MultiView_MPL(nn.Module):
         return out
 
     # ------------------------------------------------------------------ nn.Module plumbing
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save of the MODULE: parameters, buffers and flags travel; everything derived from them
+        -- structs of addresses, packed operands, their events (torch.cuda.Event cannot be pickled: a deepcopy of a model that
+        had run a forward raised TypeError before round 6), extension bindings, the operator handle -- is rebuilt by the copy on
+        its first forward."""
+        st = self.__dict__.copy()
+        st["_hip_cache"] = {}
+        st["_fast_bind"] = {}
+        st["_op_handle"] = 0
+        st["_dp_src"] = None
+        st["_dp_replica"] = False
+        st.pop("_tl_cache", None)
+        st.pop("_x3_ok", None)
+        return st
+
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .half(): under torch.__future__.set_overwrite_module_params_on_conversion the parameters are REPLACED
         # without any registration hook firing, so every cache that holds tensors goes, not only the packed operands

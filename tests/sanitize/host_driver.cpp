@@ -72,6 +72,10 @@ int main() {
     (void)mpl_block_stack_form(256, 2, 544, 8, 13, 2, 0);
     (void)mpl_block_stack_form(1, 2, 544, 8, 13, 2, MPL_F_NO_SMALL_STACK);
     (void)mpl_block_stack_form(1024, 4, 1088, 8, MPL_MAX_APPS + 5, 1, 0);
+    EXPECT(mpl_block_stack_form_ex(1, 2, 544, 8, 13, 14, 1, 2, 0) < 0);       // more blocks than applications
+    EXPECT(mpl_block_stack_form_ex(1, 2, 544, 8, 13, 0, 1, 2, 0) < 0);
+    (void)mpl_block_stack_form_ex(1, 2, 544, 8, 13, 12, 0, 2, 0);
+    EXPECT(mpl_block_stack_last_form() < 0);                                  // nothing was launched by this thread
 
     // ---- switches and per-device state
     EXPECT(mpl_x3_spin_limit(0) < 0);

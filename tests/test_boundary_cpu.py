@@ -244,14 +244,20 @@ def test_copies_of_a_module_get_their_own_operator_handle():
     original's weights.  Every use resolves the handle against the registry and re-issues it when it names another object."""
     import copy
     import io
+    import threading
     from openmpl_amd import multiview_mpl as mm
     m = MultiView_MPL(num_views=2, depth=1).eval()
     h = m._handle()
     assert mm._module_of(h) is m and m._handle() == h                  # stable for the object it was issued to
+    m._hip_cache[0] = dict(ready=threading.Lock())                     # stands in for a torch.cuda.Event: cannot be copied / pickled
     c = copy.deepcopy(m)
-    assert c.__dict__["_op_handle"] == h                               # inherited number ...
+    assert c._hip_cache == {} and c._fast_bind == {} and m._hip_cache  # derived state stays behind (a used module copies fine)
+    m._hip_cache = {}
+    assert c.__dict__["_op_handle"] == 0                               # no inherited number:
     hc = c._handle()
-    assert hc != h and mm._module_of(hc) is c and mm._module_of(h) is m   # ... re-issued on first use, the original keeps its own
+    assert hc != h and mm._module_of(hc) is c and mm._module_of(h) is m   # issued on first use, the original keeps its own
+    r0 = m._replicate_for_data_parallel()                              # the SHALLOW copy of DataParallel inherits the number ...
+    assert r0.__dict__["_op_handle"] == h and mm._module_of(r0._handle()) is r0 and mm._module_of(h) is m   # ... re-issued on use
     with torch.no_grad():
         c.head[1].weight.add_(1.0)
     assert not torch.equal(mm._module_of(hc).head[1].weight, mm._module_of(h).head[1].weight)

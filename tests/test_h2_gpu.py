@@ -372,6 +372,41 @@ def test_the_library_reports_the_form_of_a_stack_launch():
         cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
 
 
+@pytest.mark.parametrize("name,B,prec", [("chosen_v4_b8_l2", 1, "fp32"), ("chosen_v4_b8_l2", 8, "fp32"), ("chosen_v4_b8_l2", 9, "fp32"),
+                                         ("chosen_v2_b1_l12", 256, "fp32"), ("chosen_v4_b8_l12", 1024, "fp32"), ("chosen_v8_b4_l2", 1024, "fp32"),
+                                         ("chosen_v8_b4_l2", 1024, "bf16"), ("chosen_v4_b8_l2", 4, "bf16"), ("full_v4_b8_l2", 64, "fp32"),
+                                         ("kptok_v3_b3_l2", 3, "fp32"), ("chosen_v4_b8_l2", 2, "fp32_mfma")])
+def test_the_reported_form_is_the_form_that_was_launched(name, B, prec):
+    """the query (mpl_block_stack_form_ex) and the launch (block_stack_impl) go through ONE predicate, and
+    mpl_block_stack_last_form() says what the last forward of this thread actually launched: they agree on every engine, also for
+    the small-batch engine (n_blocks from the schedule, raw tensors present) and with the per-call MPL_F_NO_SMALL_STACK flag."""
+    lib = cabi.load()
+    m, g = _model(name)
+    m.set_matmul_precision(prec)
+    V, L = g["flags"]["num_views"], g["flags"]["depth"]
+    kp = bool(g["flags"].get("FPT_blocks_view_keypoint_tokens"))
+    D = 32 if kp else 17 * 32 * (2 if g["flags"].get("input_rays_as_token") else 1)
+    n_tok = 17 * V if kp else V
+    parts = {"fp32": 2, "bf16": 1, "fp32_mfma": 0}[prec] if not kp else 0
+    p, r, c = detrng.make_inputs(B, V, seed=5)
+    dev = lambda lst: [torch.from_numpy(x).to(DEV) for x in lst]
+    for small in ("auto", False):
+        m.set_small_batch_engine(small)
+        with torch.no_grad():
+            out = m(dev(p), rays=dev(r), centers=dev(c))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        launched = lib.mpl_block_stack_last_form()
+        flags = 0 if small == "auto" else cabi.F_NO_SMALL_STACK
+        asked = lib.mpl_block_stack_form_ex(B, n_tok, D, 8, L + 1, L, 1, parts, flags)
+        assert launched == asked and launched >= 0, (name, B, prec, small, launched, asked)
+        assert lib.mpl_block_stack_form(B, n_tok, D, 8, L + 1, parts, flags) == asked          # the short form: the reference's schedule
+    m.set_small_batch_engine("auto")
+    # a caller that hands over packed operands only (no nn.Linear tensors) never gets the small-batch engine
+    assert lib.mpl_block_stack_form_ex(1, 2, 544, 8, 13, 12, 0, 2, 0) != cabi.FORM_SMALL
+    assert lib.mpl_block_stack_form_ex(1, 2, 544, 8, 13, 14, 1, 2, 0) < 0                     # more blocks than applications
+
+
 @pytest.mark.parametrize("name,B", [("chosen_v4_b8_l12", 512), ("chosen_v4_b8_l2", 48), ("chosen_v4_b8_l2", 1), ("full_v4_b8_l2", 200),
                                     ("chosen_v5_b19_l2", 100), ("chosen_v31_b2_l12", 9), ("chosen_v8_b4_l2", 37), ("chosen_v2_b1_l12", 97)])
 def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
