@@ -534,7 +534,7 @@ int mpl_ln_linear(const float* x, int M, int K, const float* ln_w, const float* 
         if (rc) return rc;
     }
     // bench-only: with MPL_GEMM_ABL=4 (tools/gemm_phase.py) the scratch pointer receives per-wave phase timings
-    static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
+    static const bool timing = lab_getenv("MPL_GEMM_ABL") && atoi(lab_getenv("MPL_GEMM_ABL")) == 4;
     return launch_ln_gemm(x, K, stats, ln_w, ln_b, eps, W, bias, residual, N, y, N, M, N, K, epilogue,
                           (timing && !ln_w) ? stats : nullptr, s);
 }

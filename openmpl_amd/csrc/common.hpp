@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -10,6 +11,18 @@
 #include "../../include/mpl_hip.h"
 
 namespace mpl {
+
+// Environment switches of measurement scripts (geometry overrides, phase timing, alternative kernels).  They exist in laboratory
+// builds only (-DMPL_LAB, tools/build_variants.sh): the product library never changes behaviour because a variable happens to be set.
+inline const char* lab_getenv(const char* name) {
+#ifdef MPL_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -752,13 +752,13 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
                           int K, float eps, float* stats_out, hipStream_t s) {
     // widest column grouping that still yields >= 256 workgroups (one per CU); small problems stay at NG = 1
     const int gm = (M + BM - 1) / BM;
-    static const int force = getenv("MPL_GEMM_NG") ? atoi(getenv("MPL_GEMM_NG")) : 0;   // bench-only
-    static const int kgsel = getenv("MPL_GEMM_KG") ? atoi(getenv("MPL_GEMM_KG")) : 0;    // bench-only
+    static const int force = lab_getenv("MPL_GEMM_NG") ? atoi(lab_getenv("MPL_GEMM_NG")) : 0;   // bench-only
+    static const int kgsel = lab_getenv("MPL_GEMM_KG") ? atoi(lab_getenv("MPL_GEMM_KG")) : 0;    // bench-only
     int ng = 1;
     if (N % (BN * 3) == 0 && gm * (N / (BN * 3)) >= 256) ng = 3;
     if (force) ng = force;
 #define MPL_ARGS2 A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
-    static const int abl = getenv("MPL_GEMM_ABL") ? atoi(getenv("MPL_GEMM_ABL")) : 0;   // bench-only ablations
+    static const int abl = lab_getenv("MPL_GEMM_ABL") ? atoi(lab_getenv("MPL_GEMM_ABL")) : 0;   // bench-only ablations
     if (abl == 4 && !LN) {
         if (ng == 3) return launch_ng<EPI, false, 3, 1, 1, 2, 4>(MPL_ARGS2);
         return launch_ng<EPI, false, 1, 1, 1, 2, 4>(MPL_ARGS2);
@@ -772,7 +772,7 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
     // Measured on MI355X (tools/gemm_ab.py, M = 4096, D = 544): QKV 80 us with either geometry; the 4-wave
     // workgroup (two per CU, 3-stage ring) wins for N = D and N = 2 D, k-group splitting never paid.
     // bench-only geometry override: MPL_GEMM_CFG = ng*100 + ks*10 + nst
-    static const int cfg = getenv("MPL_GEMM_CFG") ? atoi(getenv("MPL_GEMM_CFG")) : 0;
+    static const int cfg = lab_getenv("MPL_GEMM_CFG") ? atoi(lab_getenv("MPL_GEMM_CFG")) : 0;
     switch (cfg) {
         case 116: return launch_ng<EPI, LN, 1, 1, 1, 6>(MPL_ARGS2);
         case 114: return launch_ng<EPI, LN, 1, 1, 1, 4>(MPL_ARGS2);
@@ -804,7 +804,7 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
     // with its loader wave.  Measured on MI355X at M = 4096, D = 544 against the best 4-wave configuration:
     // proj 29.1 -> 27.1 us, fc2 52.2 -> 48.7 us, fc1 (512 workgroups, two per CU) 56.0 -> 52.0 us; with more
     // workgroups per CU the 4-wave kernels below win (D = 1088: fc1 186 vs 210 us).  Bitwise identical results.
-    static const int nocs = getenv("MPL_GEMM_NOCS") ? atoi(getenv("MPL_GEMM_NOCS")) : 0;   // bench-only A/B switch
+    static const int nocs = lab_getenv("MPL_GEMM_NOCS") ? atoi(lab_getenv("MPL_GEMM_NOCS")) : 0;   // bench-only A/B switch
     if (!(nocs & 1) && wgs <= 256) return launch_cs<EPI, LN, 2>(MPL_ARGS2);
     if (!(nocs & 2) && EPI != MPL_EPI_BIAS_RESIDUAL && wgs <= 512) return launch_cs<EPI, LN, 2>(MPL_ARGS2);
     if (wgs <= 256) return launch_ng<EPI, LN, 1, 1, 1, 2, 0, false, true>(MPL_ARGS2);
@@ -816,7 +816,7 @@ static int launch_ng_auto(const float* A, int lda, const float* stats, const flo
 // LN1 + qkv projection + softmax attention in one launch: att[M, D] from x[M, D].  Requirements (else the caller
 // uses the separate kernels): 136 % hd == 0, 64 % n_tok == 0, D % 136 == 0.
 bool qkv_attention_fusable(int n_tok, int dim, int heads) {
-    static const bool off = getenv("MPL_NO_ATT_FUSION") != nullptr;   // bench-only A/B switch
+    static const bool off = lab_getenv("MPL_NO_ATT_FUSION") != nullptr;   // bench-only A/B switch
     if (off || heads <= 0 || dim % heads) return false;
     const int hd = dim / heads;
     return dim % BN == 0 && BN % hd == 0 && (hd & 3) == 0 && n_tok >= 1 && BM % n_tok == 0 && n_tok * n_tok * (BN / hd) * (BM / n_tok) <= ATT_SCORE_FLOATS;
@@ -838,7 +838,7 @@ int launch_ln_gemm(const float* A, int lda, const float* stats, const float* ln_
     const bool ln = ln_w != nullptr;
     if (ln && (!stats || !ln_b)) return MPL_E_INVALID;
     if (epi == MPL_EPI_BIAS_RESIDUAL && !R) return MPL_E_INVALID;
-    static const bool timing = getenv("MPL_GEMM_ABL") && atoi(getenv("MPL_GEMM_ABL")) == 4;
+    static const bool timing = lab_getenv("MPL_GEMM_ABL") && atoi(lab_getenv("MPL_GEMM_ABL")) == 4;
     if (stats_out && !timing && (epi != MPL_EPI_BIAS_RESIDUAL || N % BN != 0)) return MPL_E_INVALID;
 #define MPL_ARGS A, lda, stats, ln_w, ln_b, W, bias, R, ldr, C, ldc, M, N, K, eps, stats_out, s
 #define MPL_GEMM_CASE(E)                                                                              \

@@ -1379,11 +1379,8 @@ int launch_spt(const mpl_config* cfg, const mpl_weights* w, const mpl_inputs* in
     p.B = in->batch; p.V = cfg->num_views; p.in_ch = cfg->in_chans;
     p.flags = f;
     p.c3 = (f & MPL_F_POS3D_TO_RAYS) ? 2 * SD : SD;
-#ifdef MPL_LAB       // the phase ablations (garbage results) exist in laboratory builds only: tools/build_variants.sh -f spt.hip
-    static const int abl = getenv("MPL_SPT_ABL") ? atoi(getenv("MPL_SPT_ABL")) : 0;
-#else
-    constexpr int abl = 0;
-#endif
+    // the phase ablations (garbage results) exist in laboratory builds only: tools/build_variants.sh -f spt.hip
+    static const int abl = lab_getenv("MPL_SPT_ABL") ? atoi(lab_getenv("MPL_SPT_ABL")) : 0;
     p.abl = abl;
     {
         int dev = 0;

@@ -448,7 +448,7 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
         const size_t lds = (size_t)n_tok * hd * 8;
         int waves = (n_tok + 191) / 192;             // three row slots per wave
         waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
-        static const bool no_pairs = getenv("MPL_ATT_NOPAIRS") != nullptr;      // bench-only A/B switch
+        static const bool no_pairs = lab_getenv("MPL_ATT_NOPAIRS") != nullptr;      // bench-only A/B switch
         if (hd == 4 && !no_pairs)
             hipLaunchKernelGGL(token_attention_long_p4_kernel, dim3(n_seq * heads), dim3(64 * waves), (size_t)((n_tok + 1) / 2) * 64, s,
                                qkv, out, n_tok, dim, heads, sc);
@@ -465,7 +465,7 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
     ProfScope prof(MPL_K_ATTENTION, s);
     {
         const size_t seq_bytes = (size_t)n_tok * (3 * dim + 4) * 4 + (size_t)heads * n_tok * n_tok * 4;
-        static const bool force_v1 = getenv("MPL_ATT_V1") != nullptr;   // bench-only A/B switch
+        static const bool force_v1 = lab_getenv("MPL_ATT_V1") != nullptr;   // bench-only A/B switch
         if (seq_bytes <= 150 * 1024 && !force_v1) {
             int spw = (int)((56 * 1024) / seq_bytes);
             if (spw < 1) spw = 1;
