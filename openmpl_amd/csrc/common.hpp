@@ -23,6 +23,47 @@ inline const char* lab_getenv(const char* name) {
 #endif
 }
 
+#ifndef MPL_LAB
+#ifdef MPL_SPLIT_MIX
+#error "MPL_SPLIT_MIX is a laboratory switch: build with -DMPL_LAB"
+#endif
+#endif
+#ifndef MPL_SPLIT_MIX
+#define MPL_SPLIT_MIX 1     // 0: the lo part of the two-term fp16 split by convert / subtract / convert (rounds 3-5); bitwise the same
+#endif
+// x = hi + lo in fp16: hi = fp16(x), lo = fp16(x - hi) (RNE; the residual is exact in fp32; subnormal results are kept) -- the
+// operand split of the fp16x2 engines (h2_phase.hpp, spt.hip).  8 values per lane = one MFMA fragment per part.
+// Round 6: the lo part is ONE v_fma_mix{lo,hi}_f16 per value (fp16(hi * -1.0 + x): hi read as fp16, the fma in fp32, one rounding
+// to fp16) instead of v_cvt_f32_f16 + v_sub_f32 + half a v_cvt_pk_f16_f32: 20 VALU per split of 8 values instead of 32-36 --
+// the LayerNorm GEMMs of the FPT stack split one A fragment per k-tile and wave, the SPT kernel is VALU-bound.  Bit for bit the
+// old result (tools/micro/mix_probe.hip: 2 M values incl. subnormals, ties and the edges of the window; every byte-exact
+// operand test and golden).
+typedef _Float16 mpl_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mpl_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_f16(const float (&x)[8], mpl_f16x8& hi, mpl_f16x8& lo) {
+#if MPL_SPLIT_MIX
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const mpl_f16x2 hp = {(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};       // v_cvt_pk_f16_f32 (RNE)
+        h[p] = __builtin_bit_cast(unsigned, hp);
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(d) : "v"(h[p]), "v"(x[2 * p]), "v"(x[2 * p + 1]));
+        l[p] = d;
+    }
+    hi = __builtin_bit_cast(mpl_f16x8, h);
+    lo = __builtin_bit_cast(mpl_f16x8, l);
+#else
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
+#endif
+}
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

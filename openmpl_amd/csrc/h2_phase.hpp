@@ -34,7 +34,7 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 // switch it varies; the values and what they do are unchanged from rounds 3-5.
 #ifndef MPL_LAB
 #if defined(H2_DBG) || defined(H2_ABL) || defined(H2_DW_PIN) || defined(H2_WT_AUX) || defined(H2_WSPLIT) || defined(H2_R2_AB) || \
-    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2) || defined(H2_PRIO)
+    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2) || defined(H2_PRIO) || defined(H2_RAWA_EARLY)
 #error "H2_* experiment switches are laboratory-only: build with -DMPL_LAB (tools/build_variants.sh does)"
 #endif
 #endif
@@ -74,6 +74,10 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #ifndef H2_PRIO
 #define H2_PRIO 0       // 1 / 2: static s_setprio 1 for the waves 4..7 / 0..3 of the whole-tile stack kernel (guide: "static priority for the younger half")
 #endif
+#ifndef H2_RAWA_EARLY
+#define H2_RAWA_EARLY 0 // 1: the waves 0..3 read the RAW LayerNorm rows of the next k-tile in FRONT of their product rows (their
+                        // conversion behind the rows then finds the values there) instead of right in front of the conversion
+#endif
 #ifndef H2_KPS2
 #define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
                        // ring slot of slack); 0: a barrier in front of every stage, refill 6 stages ahead
@@ -89,12 +93,7 @@ __host__ __device__ inline int h2_col(int t, int kq, int j, int G) {
     return 136 * (4 * (t - 4 * G) + kq) + 128 + j;
 }
 // 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept)
-__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
-}
+__device__ __forceinline__ void split2(const float (&x)[8], f16x8& hi, f16x8& lo) { split2_f16(x, hi, lo); }      // common.hpp
 // largest power of two p with p * v <= 2^15 (v > 0, finite); 1 for v == 0
 __host__ __device__ inline float h2_window_scale(float v) {
     if (!(v > 0.f)) return 1.0f;
@@ -732,9 +731,8 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
             float z[8] = {cvr0[rt].x, cvr0[rt].y, cvr0[rt].z, cvr0[rt].w, cvr1[rt].x, cvr1[rt].y, cvr1[rt].z, cvr1[rt].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                z[j] = fmaf(z[j], cv_a[rt], cv_b[rt]);
+                z[j] = fmaf(z[j], cv_a[rt], cv_b[rt]);        // rows beyond the tile: cv_a = cv_b = 0 (set with the statistics): z = 0
                 z[j] = __builtin_amdgcn_fmed3f(z[j], -65000.0f, 65000.0f);     // never an inf in an operand, whatever the statistics
-                if (!row_ok[rt]) z[j] = 0.f;
             }
             split2(z, f[rt][0], f[rt][1]);
         }
@@ -813,8 +811,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                     }
                     const float rs = 1.0f / sqrtf(fmaf(m2, 1.0f / (float)K, a.eps));
                     if constexpr (NP == 2) {
-                        cv_a[rt] = rs * H2_SA;
-                        cv_b[rt] = -mean * cv_a[rt];
+                        // a row beyond the tile (its loads are clamped to the last row) multiplies as zeros: 0 * x + 0 in finish_a
+                        // instead of a select per value there (8 v_cndmask per conversion and wave, round 6)
+                        cv_a[rt] = row_ok[rt] ? rs * H2_SA : 0.f;
+                        cv_b[rt] = row_ok[rt] ? -mean * (rs * H2_SA) : 0.f;
                     } else {            // folded LayerNorm, applied by the epilogue: rstd (acc - mean s_n) + c_n
                         cv_a[rt] = rs;
                         cv_b[rt] = mean;
@@ -906,9 +906,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 b_nxt[n][1] = bs[(n * 2 + 1) * 64];
             }
         };
+        constexpr bool A_EARLY = H2_RAWA_EARLY != 0 && LEAD && RAWX && RT == 1 && !DW;
         auto loads = [&]() {
             if constexpr (ACT) {
-                if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+                if (!A_EARLY && more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
                 rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
             }
             // the requested stage t + DIST has the pass (g + DIST) mod NPASS (= g when DIST = NST) and carries A when that is 0
@@ -928,6 +929,10 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         unsigned long long m0 = 0;
         if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
+        if constexpr (A_EARLY && ACT) {
+            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (!ACT) {
         } else if constexpr (NP == 2) {
             mfma_row(accp, a_cur, 1, b_cur, 0);         // lo . hi

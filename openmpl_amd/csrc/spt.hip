@@ -700,12 +700,7 @@ typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 8 fp32 -> hi / lo packed fp16 (RNE; the residual is exact in fp32; subnormal results are kept): h2_gemm.hip
-__device__ __forceinline__ void spt_split2(const float (&x)[8], sf16x8& hi, sf16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) hi[i] = (_Float16)x[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lo[i] = (_Float16)(x[i] - (float)hi[i]);
-}
+__device__ __forceinline__ void spt_split2(const float (&x)[8], sf16x8& hi, sf16x8& lo) { ::mpl::split2_f16(x, hi, lo); }     // common.hpp
 // largest power of two p with p * v <= 2^15 (v > 0, finite); 1 for v == 0
 __device__ inline float spt_window_scale(float v) {
     if (!(v > 0.f) || !(v < 3.0e38f)) return 1.0f;
