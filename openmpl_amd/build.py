@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmpl_hip.so")
 SOURCES = ["api.hip", "spt.hip", "ln_gemm.hip", "h2_gemm.hip", "h2n_gemm.hip", "h2d_gemm.hip", "b1_gemm.hip", "sm_stack.hip", "token_attention.hip", "fuse_head.hip", "heads.hip", "metrics.hip", "inputs.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_common.hpp"), os.path.join(CSRC, "h2_phase.hpp"), os.path.join(os.path.dirname(HERE), "include", "mpl_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_common.hpp"), os.path.join(CSRC, "h2_phase.hpp"), os.path.join(CSRC, "fuse_head.hpp"), os.path.join(os.path.dirname(HERE), "include", "mpl_hip.h")]
 ARCH = "gfx950"
 
 

@@ -114,10 +114,13 @@ def gather_outputs_async(local: torch.Tensor, batch: int, group=None, mode: str 
         src = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         src[: hi - lo] = local
     buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(buf, src, group=group, async_op=True)
     if mode == "stream":
-        work.wait()            # RCCL: the CURRENT STREAM waits for the collective (no host block); gloo: the host does
+        # a SYNCHRONOUS collective: ordered with respect to the current stream (torch >= 2.7 enqueues it on that very stream, older
+        # versions on the process group's stream between two events); the host does not block with RCCL (gloo: it does)
+        dist.all_gather_into_tensor(buf, src, group=group, async_op=False)
         work = None
+    else:
+        work = dist.all_gather_into_tensor(buf, src, group=group, async_op=True)
     return GatherHandle(work, buf, batch, world, src)
 
 
