@@ -8,6 +8,14 @@ the same process also launches the kernel once on the 64-pose parity batch, whic
 be the one reported (round 2 did exactly that)."""
 import collections, csv, glob, json, os, shutil, sys
 
+if len(sys.argv) > 2 and sys.argv[1] == "--check":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from openmpl_amd import build as _b
+    cur = _b.source_hash()
+    for f in sorted(glob.glob("profiles/%s_*gemm_traffic.json" % sys.argv[2])):
+        h = json.load(open(f)).get("srchash")
+        print("%-50s %s" % (f, "HEAD sources" if h == cur else "OTHER sources (%s...)" % str(h)[:12]))
+    sys.exit(0)
 tag = sys.argv[1]
 extra = sys.argv[2] if len(sys.argv) > 2 else None
 G = "gpurun_out/prof_%s" % tag + ("_" + extra if extra else "")
@@ -132,5 +140,15 @@ if cands:
          "source": "%spmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the bench command itself, HEADLINE "
                    "launch group only, FETCH_SIZE x2 gfx950 correction)" % stem}
     json.dump(j, open(stem + "gemm_traffic.json", "w"), indent=1)
+    # a profile set taken on other kernel sources than the tree's is evidence for THOSE sources -- say so here, and
+    # `python tools/make_profiles.py --check <tag>` lists every committed set of a round whose hash is not the tree's
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from openmpl_amd import build as _b
+        if j["srchash"] and j["srchash"] != _b.source_hash():
+            print("WARNING: this session ran on library sources %s..., the tree hashes to %s...: stale evidence for HEAD"
+                  % (j["srchash"][:12], _b.source_hash()[:12]))
+    except Exception as e:
+        print("(source hash not compared: %r)" % (e,))
     print("traffic MB per launch: fetch %.1f write %.1f ratio %s hit %s" % (m["fetch_bytes"] / 1e6, m["write_bytes"] / 1e6,
                                                                            j["traffic_ratio"], j["tcc_hit_rate"]))
