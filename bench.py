@@ -10,7 +10,9 @@ Metric (BASELINE.json): poses/s at V=4, J=17, batch 1024 (per GPU), fp32, the pa
 that are already resident in HBM when the timed region starts; with N ranks every rank lifts its own 1024 poses
 (weak scaling, inputs pre-sharded: no rank touches another rank's frames) and the per-shard (B,17,3) outputs are
 exchanged with ONE RCCL all-gather per step -- the MI355X equivalent of the reference's DataParallel gather
-(valid_mpl.py:177-178) -- issued asynchronously so that it overlaps the next step's forward.
+(valid_mpl.py:177-178) -- ordered into the compute stream between two forwards (--gather stream, default: the block stack of a
+forward is one persistent launch on every compute unit, a collective kernel beside it would fight it for one) or issued
+asynchronously beside the next step's forward (--gather overlap: rounds 1-5).
 
 When invoked plainly with --gpus N > 1 the parent process imports nothing that touches the GPU: it starts N fresh
 children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relays rank 0's line.

@@ -3,7 +3,8 @@
     python tests/dist_worker.py <backend> <out.npz> <batch> [stream|overlap]     (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from env)
 
 backend "single": no process group, plain model call (the reference result the sharded runs must equal bitwise);
-backend "nccl" (= RCCL): the HIP model on cuda:LOCAL_RANK through ShardedLifter; rank 0 writes the npz."""
+backend "nccl" (= RCCL): the HIP model on cuda:LOCAL_RANK through ShardedLifter; rank 0 writes the npz;
+backend "gloo": the same with the collective staged through the host -- lets TWO ranks share ONE GPU (LOCAL_RANK 0 for both)."""
 import os
 import sys
 
@@ -45,7 +46,10 @@ def main():
         else:
             import torch.distributed as dist
             from openmpl_amd.dist import ShardedLifter, shard_inputs
-            dist.init_process_group(backend, device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group(backend, device_id=dev)
+            else:                       # gloo with device tensors (staged through the host): the one-GPU world-2 leg of test_dist_gpu.py
+                dist.init_process_group(backend)
             lifter = ShardedLifter(m, gather=gather)
             # (1) the DataParallel call shape: full batch on every rank
             for i, (P, R, C) in enumerate(batches):

@@ -27,11 +27,11 @@ def _free_port():
     return p
 
 
-def _run(backend, world, out, batch, gather="stream"):
+def _run(backend, world, out, batch, gather="stream", one_gpu=False):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, WORKER, backend, out, str(batch), gather], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -66,6 +66,23 @@ def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch, gat
         assert np.array_equal(got["full%d" % i], single["full%d" % i]), "world %d full-batch call differs" % world
         assert np.array_equal(got["shard%d" % i], single["full%d" % i]), "world %d pre-sharded call differs" % world
     assert not np.array_equal(single["full0"], single["full1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,gather", [(64, "stream"), (37, "overlap"), (5, "stream")])
+def test_two_ranks_on_one_gpu_match_single_process_bitwise(tmp_path, batch, gather):
+    """No box of this build has two GPUs, so the world-2 RCCL leg above is skipped everywhere.  This leg runs the SAME rank code
+    (tests/dist_worker.py: ShardedLifter, shard_inputs, lift_shard with both exchanges issued before the first wait, uneven shards,
+    shards of at most 32 token rows) with two ranks that SHARE the one GPU and exchange through gloo (device tensors staged through
+    the host) -- everything but the RCCL transport: the HIP forward of each rank's shard, the shard arithmetic, the batch-invariant
+    engine selection, the order of the gathered poses.  Bitwise the single-process result.  (Small launches: two processes on one
+    GPU must not both want every compute unit for a persistent launch -- the single-tenant rule of INTEGRATION.md.)"""
+    single = _run("single", 1, str(tmp_path / "single.npz"), batch)
+    got = _run("gloo", 2, str(tmp_path / "w2.npz"), batch, gather, one_gpu=True)
+    for i in range(2):
+        assert got["full%d" % i].shape == (batch, 17, 3)
+        assert np.array_equal(got["full%d" % i], single["full%d" % i]), "two ranks on one GPU: full-batch call differs"
+        assert np.array_equal(got["shard%d" % i], single["full%d" % i]), "two ranks on one GPU: pre-sharded call differs"
 
 
 @pytest.mark.gpu
