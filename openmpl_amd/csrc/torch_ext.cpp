@@ -118,7 +118,7 @@ int64_t bind(const at::Tensor& cfg_b, const at::Tensor& w_b, const at::Tensor& f
         TORCH_CHECK(t.is_cuda() && t.device().index() == device && t.scalar_type() == at::kFloat && t.is_contiguous(),
                     "MultiView_MPL (HIP): every parameter must be a contiguous float32 tensor on cuda:", device);
         b->ptrs.push_back(t.data_ptr());
-        b->versions.push_back(t._version());
+        b->versions.push_back(t.is_inference() ? 0u : (uint32_t)t._version());      // inference tensors track no version
         b->versioned.push_back(versioned[i] ? 1 : 0);
     }
     b->keep.assign(keep.begin(), keep.end());
@@ -159,7 +159,8 @@ at::Tensor lift(int64_t h, at::TensorList poses, at::TensorList rays, at::Tensor
     // ---- is the struct of addresses still what the module holds?  (moved storage: any tensor; changed values: folded tensors)
     for (size_t i = 0; i < b->params.size(); ++i) {
         const at::Tensor& t = b->params[i];
-        if (t.data_ptr() != b->ptrs[i] || (b->versioned[i] && t._version() != b->versions[i])) return stale_answer();
+        if (t.data_ptr() != b->ptrs[i] || (b->versioned[i] && !t.is_inference() && (uint32_t)t._version() != b->versions[i]))
+            return stale_answer();
     }
     // ---- MultiView_MPL._check_inputs (same conditions, same messages: RuntimeError)
     const int V = b->cfg.num_views, J = b->cfg.num_joints;

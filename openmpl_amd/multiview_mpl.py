@@ -103,6 +103,15 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+def _ver(t: torch.Tensor) -> int:
+    """Version counter of a tensor; inference tensors (created under torch.inference_mode) do not track one -- and cannot be
+    updated in place outside that mode either, so 0 is the right key for them."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 # ---------------------------------------------------------------------------------------------- the forward as ONE torch operator
 # north_star: "hand-written HIP ... exposed as a torch extension".  The library is reached through ctypes (cabi.py); this
 # registration makes the same call a dispatcher-visible operator, openmpl_amd::forward, without another build: torch.profiler
@@ -486,7 +495,7 @@ class MultiView_MPL(nn.Module):
         src = self._dp_src if self._dp_replica else self
         _, fpt, spt = src._tensor_lists()
         ts = (fpt if (h2 or bf16 or d32) else []) + (spt if spt3 else [])
-        return (self.matmul_precision, h2, bf16, spt3, d32) + tuple([(t.data_ptr(), t._version) for t in ts])
+        return (self.matmul_precision, h2, bf16, spt3, d32) + tuple([(t.data_ptr(), _ver(t)) for t in ts])
 
     def _marshal(self, device: torch.device):
         """Build (and cache per device) the mpl_weights struct.  Parameters are consumed in place, so the struct stays valid

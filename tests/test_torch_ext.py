@@ -162,6 +162,23 @@ def test_extension_raises_the_boundary_errors_and_leaves_other_flag_sets_to_the_
 
 
 @pytest.mark.gpu
+def test_inference_mode_and_inference_tensors():
+    """torch.inference_mode(): the forward works inside it, and a model whose parameters BECAME inference tensors (moved to the
+    device inside the mode: they track no version counter) still binds -- such tensors cannot be updated in place outside the mode,
+    so the extension keys them by address only."""
+    m = MultiView_MPL(**FLAGS)
+    detrng.fill_module_(m, seed=31)
+    P, R, C = _inputs(8, seed=6)
+    with torch.inference_mode():
+        mi = m.to(DEV).eval()
+        out = mi(P, rays=R, centers=C)
+        again = mi(P, rays=R, centers=C)
+    with torch.no_grad():
+        ref = _model()(P, rays=R, centers=C)
+    assert torch.equal(out, again) and torch.equal(out, ref) and mi._fast_bind
+
+
+@pytest.mark.gpu
 def test_bindings_die_with_their_module_and_streams_are_honoured():
     o = torch_ext.ops()
     gc.collect()
