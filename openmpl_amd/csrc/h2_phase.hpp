@@ -34,7 +34,7 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 // switch it varies; the values and what they do are unchanged from rounds 3-5.
 #ifndef MPL_LAB
 #if defined(H2_DBG) || defined(H2_ABL) || defined(H2_DW_PIN) || defined(H2_WT_AUX) || defined(H2_WSPLIT) || defined(H2_R2_AB) || \
-    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2) || defined(H2_PRIO) || defined(H2_RAWA_EARLY)
+    defined(H2_R2_AB2) || defined(H2_TAIL_LOOP) || defined(H2_KPS2)
 #error "H2_* experiment switches are laboratory-only: build with -DMPL_LAB (tools/build_variants.sh does)"
 #endif
 #endif
@@ -70,13 +70,6 @@ constexpr int H2_TRV = 5;                    // fp32 vectors of length N behind 
 #define H2_WC2 (H2_WSPLIT == 1 ? 2 : 3)
 #ifndef H2_TAIL_LOOP
 #define H2_TAIL_LOOP 1
-#endif
-#ifndef H2_PRIO
-#define H2_PRIO 0       // 1 / 2: static s_setprio 1 for the waves 4..7 / 0..3 of the whole-tile stack kernel (guide: "static priority for the younger half")
-#endif
-#ifndef H2_RAWA_EARLY
-#define H2_RAWA_EARLY 0 // 1: the waves 0..3 read the RAW LayerNorm rows of the next k-tile in FRONT of their product rows (their
-                        // conversion behind the rows then finds the values there) instead of right in front of the conversion
 #endif
 #ifndef H2_KPS2
 #define H2_KPS2 1      // 1: one barrier per TWO stages: it publishes two stages at once, the refill then targets 5 stages ahead (one
@@ -906,10 +899,9 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
                 b_nxt[n][1] = bs[(n * 2 + 1) * 64];
             }
         };
-        constexpr bool A_EARLY = H2_RAWA_EARLY != 0 && LEAD && RAWX && RT == 1 && !DW;
         auto loads = [&]() {
             if constexpr (ACT) {
-                if (!A_EARLY && more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
+                if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
                 rd_b(0); rd_b(1); rd_b(2); rd_b(3); rd_b(4);
             }
             // the requested stage t + DIST has the pass (g + DIST) mod NPASS (= g when DIST = NST) and carries A when that is 0
@@ -929,10 +921,6 @@ __device__ __forceinline__ bool h2_phase(const H2Args& a, char* smem, int tid, i
         }
         unsigned long long m0 = 0;
         if (H2_DBG && a.dbg) m0 = __builtin_amdgcn_s_memtime();
-        if constexpr (A_EARLY && ACT) {
-            if (more && next_has_a && !(H2_ABL & 4)) read_a(slot_n, a_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if constexpr (!ACT) {
         } else if constexpr (NP == 2) {
             mfma_row(accp, a_cur, 1, b_cur, 0);         // lo . hi
@@ -1627,8 +1615,6 @@ __global__ __launch_bounds__(512, 2) void h2_stack_kernel(const H2StackArgs s) {
     if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + H2_FAIL) = 0u;
     h2_publish_xcd(s, team, tid);
     int plain = 0, seen = 0;       // plain hand-off stores once the team is known to sit on one XCD (h2_publish_xcd)
-    if (H2_PRIO == 1 && wave_s >= 4) __builtin_amdgcn_s_setprio(1);
-    if (H2_PRIO == 2 && wave_s < 4) __builtin_amdgcn_s_setprio(1);
     __syncthreads();
     for (int tile0 = team; tile0 < s.n_tiles; tile0 += s.n_teams) {
         unsigned need = 0;

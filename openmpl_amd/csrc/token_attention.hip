@@ -446,7 +446,15 @@ int launch_token_attention(const float* qkv, int n_seq, int n_tok, int dim, int 
         const float sc = 1.0f / sqrtf((float)hd);
         ProfScope prof(MPL_K_ATTENTION, s);
         const size_t lds = (size_t)n_tok * hd * 8;
-        int waves = (n_tok + 191) / 192;             // three row slots per wave
+        // Waves per (sequence, head) block: a lane takes up to three query rows (the kernel walks the remaining rows in further
+        // rounds).  Rounds 3-5 used as few waves as hold three rows per lane (527 tokens: 3).  Round 6 measured the block size
+        // (profiles/r06_kptok_waves_*.txt, attention us per launch at depth 2): 85 tokens 172 (1 wave) / 153 (2); 136: 279 / 267 /
+        // 249 (1 / 2 / 3); 204: 155 / 174 / 135 (2 / 3 / 4); 272: 217 / 230 / 223; 408: 407 / 391 (3 / 4); 527: 592 / 549 (3 / 4) --
+        // more waves with fewer rows each win almost everywhere.  Kernels specialised for at most two / one rows per lane (110 / 60
+        // instead of 158 registers: 4 / 8 waves per SIMD instead of 3) do NOT: 527 tokens 587 (2 rows, 4 waves), 607 (1 row, 9
+        // waves) against 549 (profiles/r06_kptok_rows_x_waves.txt) -- the kernel is bound by issue slots, and a row that shares
+        // its K / V reads with two others is cheaper than a resident wave more.  The result of a row does not depend on any of this.
+        int waves = (n_tok + 47) / 48;
         waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
         static const bool no_pairs = lab_getenv("MPL_ATT_NOPAIRS") != nullptr;      // bench-only A/B switch
         if (hd == 4 && !no_pairs)
