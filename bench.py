@@ -538,13 +538,13 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                     peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     arithmetic="native fp32 MFMA")
     if small:
-        # at most 32 token rows: 2-4 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
-        # and is bounded by that and by its 65 grid barriers, not by the matrix pipe
+        # at most 16 token rows: 2-4 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
+        # and is bounded by that and by its 65 all-to-all hand-offs, not by the matrix pipe
         gbs = alg_bytes * gemms / launches / (avg_launch_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x4_f32", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
                     unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                    arithmetic="native fp32 MFMA; whole chip per GEMM (one 16-column tile per workgroup), 5 grid barriers per block "
-                               "application; `achieved` = algorithmic bytes (fp32 weights once + activations) / launch duration",
+                    arithmetic="native fp32 MFMA; whole chip per GEMM (one 16-column tile per workgroup), 5 all-to-all hand-offs of {value, tag} pairs "
+                               "per block application; `achieved` = algorithmic bytes (fp32 weights once + activations) / launch duration",
                     fp32_equivalent=dict(achieved=round(alg, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                                          frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4)))
     spt_ms, spt_n = prof["spt"]
@@ -838,7 +838,7 @@ def extras(a, model, flags, batches, dev, sd, got, ref, nb):
                                        achieved=round(w0 / (us0 * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(w0 / (us0 * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                                        kernel_ms_per_step={k: round(t / 20, 4) for k, (t, n) in pr0.items()},
-                                       note="grid barriers (latency), not bandwidth, bound this launch (DESIGN.md section 4)")
+                                       note="65 all-to-all hand-offs (latency), not bandwidth, bound this launch (DESIGN.md section 4)")
         # the same frame through the team kernels (the small-batch engine of sm_stack.hip switched off: mpl_x3_stack_mode bit 3)
         try:
             cabi.check(cabi.load().mpl_x3_stack_mode(8), "stack mode")

@@ -289,7 +289,7 @@ inline int device_cu_count(int* cus) {
 // THE rule for "the small-batch engine (sm_stack.hip) takes this stack": block_stack_impl launches by it, mpl_block_stack_form
 // reports by it.  np = packed operand parts of the blocks (0 none, 2 fp16x2, 1 bf16: an explicit bf16 request keeps its engine);
 // raw = every nn.Linear / LayerNorm tensor of every scheduled block is present (the engine reads them in place); cus = compute
-// units of the device (every column tile of the widest GEMM needs a workgroup of its own for the grid barrier).
+// units of the device (every column tile of the widest GEMM needs a resident workgroup of its own: they poll each other's output).
 inline bool small_engine_taken(int np, bool allow_small, int M, int D, int n_tok, int H, int n_apps, int n_blocks, bool raw, int cus) {
     return (np == 0 || np == 2) && allow_small && sm_stack_enabled() && n_apps <= MPL_MAX_APPS && raw &&
            !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0 && sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks) &&
@@ -306,7 +306,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
-    // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
+    // at most 16 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
     // (not when the caller asked for batch-invariant bits -- MPL_F_NO_SMALL_STACK --, nor under the A/B switches of the team
     // kernels: one launch per GEMM, stop after n phases).  ONE predicate decides (small_engine_taken): this function launches
