@@ -473,3 +473,33 @@ def test_small_batch_engine(name, B):
     mx, nw = mpl_oracle.rel_errors(out.cpu(), team.cpu())
     print("%s B=%d: small-batch engine %.2e/%.2e, team kernels %.2e/%.2e from fp64; apart %.2e" % ((name, B) + e_sm + e_tm + (mx,)))
     assert mx < 5e-6 and nw < 5e-6
+
+
+@pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 1), ("chosen_v4_b8_l12", 4), ("full_v2_b1_l12", 3)])
+def test_small_batch_engine_hands_off_correctly_beside_other_work(name, B):
+    """The steps of sm_stack.hip hand their activations over as {value, tag} pairs that the consumers poll -- no barrier, no fence.
+    The guide's rule for such hand-offs: test them under UNEVEN load, not on an idle chip.  A second stream keeps the GPU busy with
+    GEMMs of changing sizes (they take compute units away from the launch in bursts: workgroups of a step start late, finish at
+    different times, lines are evicted between polls); every forward beside them must carry the bits of the quiet one, and no
+    hand-off may be reported lost."""
+    m, g = _model(name)
+    V = g["flags"]["num_views"]
+    P, R, Cn = _big_inputs(B, V, 11)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    small = torch.randn(512, 512, device=DEV)
+    with torch.no_grad():
+        quiet = m(P, rays=R, centers=Cn).clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for it in range(150):
+            with torch.cuda.stream(side):
+                for k in range(1 + it % 3):
+                    (a @ a) if (it + k) % 2 == 0 else (small @ small)
+            out = m(P, rays=R, centers=Cn)
+            if it % 10 == 9:
+                torch.cuda.synchronize()
+            bad += int(not torch.equal(out, quiet))
+        torch.cuda.synchronize()
+    assert not cabi.device_error(), "a hand-off was reported lost beside other work"
+    assert bad == 0, "%d of 150 forwards beside other work differ from the quiet one" % bad
