@@ -108,6 +108,34 @@ def _lost_handoff(lib, m, P, R, C):
     assert not cabi.device_error()
 
 
+def test_small_batch_engine_reports_a_hand_off_that_does_not_arrive():
+    """The steps of the single-frame engine (sm_stack.hip) wait for each other by polling the {value, tag} pairs of their operands,
+    with a bound.  With the bound at TWO polls (~1 us) consumers give up before their producers have finished a step (~4 us): the launch must
+    leave, the poses must be NaN, the device error must be raised on the next call -- and after clearing it the engine gives the
+    quiet result again (the workspace of the failed launch is zeroed by the next one: no stale tag survives)."""
+    lib = cabi.load()
+    m = _model()
+    P, R, C = _inputs(2, 5)           # 8 token rows: the small-batch engine
+    with torch.no_grad():
+        good = m(P, rays=R, centers=C)
+        torch.cuda.synchronize()
+        assert lib.mpl_block_stack_last_form() == cabi.FORM_SMALL and not cabi.device_error()
+        try:
+            cabi.check(lib.mpl_x3_spin_limit(1), "spin limit")
+            bad = m(P, rays=R, centers=C)
+            torch.cuda.synchronize()
+        finally:
+            cabi.check(lib.mpl_x3_spin_limit(23), "spin limit")
+        assert torch.isnan(bad).all(), "a forward whose hand-off was lost must not return poses"
+        assert cabi.device_error()
+        with pytest.raises(RuntimeError, match="lost a hand-off"):
+            m(P, rays=R, centers=C)
+        cabi.clear_device_error()
+        again = m(P, rays=R, centers=C)
+        torch.cuda.synchronize()
+    assert torch.equal(again, good) and not cabi.device_error()
+
+
 def test_two_streams_are_serialised_and_bitwise_equal_to_serial():
     m = _model()
     A = _inputs(1024, 2)
