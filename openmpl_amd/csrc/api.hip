@@ -292,8 +292,7 @@ inline int device_cu_count(int* cus) {
 // units of the device (every column tile of the widest GEMM needs a resident workgroup of its own: they poll each other's output).
 inline bool small_engine_taken(int np, bool allow_small, int M, int D, int n_tok, int H, int n_apps, int n_blocks, bool raw, int cus) {
     return (np == 0 || np == 2) && allow_small && sm_stack_enabled() && n_apps <= MPL_MAX_APPS && raw &&
-           !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0 && sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks) &&
-           3 * D / 16 <= cus;
+           !g_x3_per_gemm.load(std::memory_order_relaxed) && g_x3_stop.load() == 0 && sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks, cus);
 }
 
 int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_block_weights* blocks,
@@ -306,7 +305,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
-    // at most 16 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
+    // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
     // (not when the caller asked for batch-invariant bits -- MPL_F_NO_SMALL_STACK --, nor under the A/B switches of the team
     // kernels: one launch per GEMM, stop after n phases).  ONE predicate decides (small_engine_taken): this function launches

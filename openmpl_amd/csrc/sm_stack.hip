@@ -72,10 +72,13 @@ __device__ unsigned long long sm_dbg_buf[2][2][400][8];
 #endif
 
 constexpr int SM_MAX_BLOCKS = 24;
-constexpr int SM_MAX_ROWS = 16;  // ONE 16-row MFMA tile of token rows per launch.  More were built and measured in every round: every one of the N / 16
+constexpr int SM_TILE_ROWS = 16; // ONE 16-row MFMA tile of token rows per workgroup.  More were built and measured in every round: every one of the N / 16
                                  // workgroups of a GEMM reads ALL of A past its L1, and as pairs that is 139 KB per workgroup and step at 32 rows -- two
-                                 // tiles: 0.96-1.07 ms per stack in this form, 0.55-0.63 with the grid barriers of rounds 4-5, 0.62-0.63 for the team
-                                 // kernels, which take those batches now; four tiles 0.90-0.93 (round 4).
+                                 // tiles per workgroup: 0.96-1.07 ms per stack in this form, 0.55-0.63 with the grid barriers of rounds 4-5, 0.62-0.63
+                                 // for the team kernels; four tiles 0.90-0.93 (round 4).
+constexpr int SM_MAX_ROWS = 2 * SM_TILE_ROWS;      // 17 .. 32 rows: TWO independent groups of sequences (rows of different sequences never meet: a GEMM
+                                 // treats rows independently, the attention stays inside a sequence), each on its own N / 16 workgroups -- the
+                                 // launch of a 16-row problem twice, side by side (2 x 102 workgroups at D = 544)
 constexpr int SM_MAX_TOK = 16;
 constexpr int SM_NW = 8;         // waves per workgroup: they split K (two per SIMD: each hides the other's LDS / memory latencies)
 constexpr int SM_NT = 64 * SM_NW;
@@ -93,14 +96,24 @@ struct SmArgs {
     float *x;                           // [M][D] plain fp32: input of the stack, and its output (written by the last fc2 step)
     float *xp, *qkvp, *attp, *hidp;     // {value, tag} pairs: [M][D], [M][3 D], [M][D], [M][2 D]
     unsigned *err_ws, *err_host;
-    int M, D, n_tok, H, n_apps, n_wg, spin_log2;
+    int M, M0, D, n_tok, H, n_apps, n_wg, spin_log2;      // M0: rows of the first group (= M: one group); n_wg: workgroups per group
     float eps;
     unsigned char sched[MPL_MAX_APPS];
     SmBlock blk[SM_MAX_BLOCKS];
 };
 
-bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks) {
-    return D <= 16 * SM_NW * SM_NU_MAX && D >= 16 * SM_NW && M >= 1 && M <= SM_MAX_ROWS && n_tok >= 1 && n_tok <= SM_MAX_TOK && M % n_tok == 0 && D % 16 == 0 && H > 0 && D % H == 0 &&
+// Groups of sequences of a launch: two (the first takes the first half of the sequences, rounded up) whenever there are two
+// sequences or more and the device has the compute units for twice the workgroups -- also below 17 rows: a workgroup then polls and
+// multiplies half the rows (V = 2: 16 rows 375 -> 332 us per stack, 8 rows 327 -> 313, same box); one group otherwise; 0 = not a
+// launch for this engine.
+int sm_stack_groups(int M, int D, int n_tok, int cus) {
+    if (n_tok <= 0 || M <= 0 || M % n_tok) return 0;
+    const int n_seq = M / n_tok, wgs = 3 * D / 16;
+    if (n_seq >= 2 && 2 * wgs <= cus && (n_seq + 1) / 2 * n_tok <= SM_TILE_ROWS) return 2;
+    return M <= SM_TILE_ROWS && wgs <= cus ? 1 : 0;
+}
+bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks, int cus) {
+    return D <= 16 * SM_NW * SM_NU_MAX && D >= 16 * SM_NW && M >= 1 && sm_stack_groups(M, D, n_tok, cus) > 0 && n_tok >= 1 && n_tok <= SM_MAX_TOK && M % n_tok == 0 && D % 16 == 0 && H > 0 && D % H == 0 &&
            ((D / H) & 3) == 0 && 16 * 2 * D * 4 <= SM_LDS_W && n_apps >= 1 && n_apps <= MPL_MAX_APPS && n_blocks >= 1 &&
            n_blocks <= SM_MAX_BLOCKS && n_tok * 3 * (D / H) * 4 <= 64 * D /* the q | k | v slice of a (sequence, head) in the first tile buffer */;
 }
@@ -329,7 +342,15 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    const int M = a.M, D = a.D, G = a.n_wg;
+    const int D = a.D, G = a.n_wg;
+    // the group of sequences this workgroup belongs to: its rows of x and of every pair buffer (the groups share nothing else)
+    const bool second = (int)blockIdx.x >= G;
+    const int M = second ? a.M - a.M0 : a.M0, r0 = second ? a.M0 : 0;
+    float* const xg = a.x + (size_t)r0 * D;
+    float* const xp = a.xp + (size_t)r0 * 2 * D;
+    float* const qkvp = a.qkvp + (size_t)r0 * 6 * D;
+    float* const attp = a.attp + (size_t)r0 * 2 * D;
+    float* const hidp = a.hidp + (size_t)r0 * 4 * D;
     if (tid == 0) *s_fail = 0u;
     __syncthreads();
 #ifdef SM_DBG
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
 #endif
     const int hd = D / a.H;
     const float scale = 1.0f / sqrtf((float)hd);
-    const int t = blockIdx.x;                             // this workgroup's column tile in every GEMM that has that many
+    const int t = (int)blockIdx.x - (second ? G : 0);     // this workgroup's column tile in every GEMM that has that many
     const bool has_qkv = t < 3 * D / 16, has_d = t < D / 16, has_fc1 = t < 2 * D / 16;
     // Weight-tile buffers (a tile = 16 K 4 bytes: 64 D for K = D, 128 D for fc2): qkv and fc1 at 0, proj at 64 D, fc2 at 64 D when
     // fc1's tile fits below it (192 D bytes in all: D = 544), else at 0 -- then fc2's tile is requested when fc1's multiply-adds
@@ -364,8 +385,8 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
         const int m = 4 * kq + wave;
         if (m < M) {
             const unsigned co = (unsigned)(m * D + 16 * t + li);
-            rsd = a.x[co];
-            sm_stp(a.xp, co, rsd, 1u);
+            rsd = xg[co];
+            sm_stp(xp, co, rsd, 1u);
         }
     }
     for (int app = 0; app < a.n_apps; ++app) {
@@ -394,8 +415,8 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
             //    3: hid = gelu(norm2(x) . W1^T + b) (Mlp.forward :32-33) | 4: x += hid . W2^T + b (:35, Block.forward :91)
             const SmTile cur = ph == 0 ? t_qkv : ph == 2 ? t_proj : ph == 3 ? t_fc1 : t_fc2;
             const SmTile nxt = ph == 0 ? t_proj : ph == 2 ? t_fc1 : ph == 3 ? (roomy ? t_fc2 : none) : t_nq;
-            const float* Ap = ph == 0 || ph == 3 ? a.xp : ph == 2 ? a.attp : a.hidp;
-            float* Cp = ph == 0 ? a.qkvp : ph == 3 ? a.hidp : a.xp;
+            const float* Ap = ph == 0 || ph == 3 ? xp : ph == 2 ? attp : hidp;
+            float* Cp = ph == 0 ? qkvp : ph == 3 ? hidp : xp;
             const int lda = ph == 4 ? 2 * D : D, ldc = ph == 0 ? 3 * D : ph == 3 ? 2 * D : D;
             const float* g = ph == 0 ? b.ln1_w : b.ln2_w;
             const float* be = ph == 0 ? b.ln1_b : b.ln2_b;
@@ -405,9 +426,9 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
             // (two instantiations by the k steps per wave: K <= 640 | longer -- K = D and K = 2 D at D = 544)
             const bool okk = cur.K <= 16 * SM_NW * 5
                                  ? sm_tile<5>(epi, ph == 0 || ph == 3, a, smem, lds_base, cur, nxt, Ap, lda, tg + (unsigned)ph - 1u, g, be, a.eps, bias, Cp, ldc,
-                                                  tg + (unsigned)ph, rsd, ph == 4 && !more ? a.x : nullptr, M, wave, lane, s_fail, 5 * app + ph)
+                                                  tg + (unsigned)ph, rsd, ph == 4 && !more ? xg : nullptr, M, wave, lane, s_fail, 5 * app + ph)
                                  : sm_tile<SM_NU_MAX>(epi, ph == 0 || ph == 3, a, smem, lds_base, cur, nxt, Ap, lda, tg + (unsigned)ph - 1u, g, be, a.eps, bias, Cp,
-                                                          ldc, tg + (unsigned)ph, rsd, ph == 4 && !more ? a.x : nullptr, M, wave, lane, s_fail, 5 * app + ph);
+                                                          ldc, tg + (unsigned)ph, rsd, ph == 4 && !more ? xg : nullptr, M, wave, lane, s_fail, 5 * app + ph);
             if (!okk) return;
         } else
         // ---- attention, one (sequence, head) at a time                              (:56-64)
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
             const int nt = a.n_tok, n_pairs = (M / nt) * a.H;
             float* T = reinterpret_cast<float*>(smem);      // [q | k | v][token][hd]: the first tile buffer (qkv's tile is spent, fc1's comes later)
             const int hh = hd / 2, per_row = 3 * hh, items = nt * per_row;
-            for (int p = blockIdx.x; p < n_pairs; p += G) {
+            for (int p = t; p < n_pairs; p += G) {
                 const int sq = p / a.H, h = p % a.H;
                 const unsigned base = (unsigned)(sq * nt * 3 * D + h * hd);
                 const unsigned lim = 1u << a.spin_log2;
@@ -428,7 +449,7 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
                     const unsigned z = sm_fresh();
                     for (int o = tid; o < items; o += SM_NT) {
                         const int i = o / per_row, rem = o - i * per_row, seg = rem / hh, e = 2 * (rem - seg * hh);
-                        const sm_u32x4 pr = sm_ld2p(a.qkvp, base + (unsigned)(i * 3 * D + seg * D + e), z);
+                        const sm_u32x4 pr = sm_ld2p(qkvp, base + (unsigned)(i * 3 * D + seg * D + e), z);
                         *reinterpret_cast<float2*>(T + (seg * nt + i) * hd + e) = float2{sm_f(pr.x), sm_f(pr.z)};
                         bad |= (pr.y ^ (tg)) | (pr.w ^ (tg));
                     }
@@ -489,8 +510,8 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
                         acc.w = fmaf(pj, v.w, acc.w);
                     }
                     const unsigned co = (unsigned)((sq * nt + i) * D + h * hd + e);      // out channel = h hd + e (:64)
-                    sm_st2p(a.attp, co, acc.x, acc.y, tg + 1u);
-                    sm_st2p(a.attp, co + 2u, acc.z, acc.w, tg + 1u);
+                    sm_st2p(attp, co, acc.x, acc.y, tg + 1u);
+                    sm_st2p(attp, co + 2u, acc.z, acc.w, tg + 1u);
                 }
                 __syncthreads();
             }
@@ -521,13 +542,15 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     const int M = n_seq * n_tok;
     int n_blocks = 0;
     for (int i = 0; i < n_apps; ++i) n_blocks = schedule[i] + 1 > n_blocks ? schedule[i] + 1 : n_blocks;
-    if (!x || !blocks || !schedule || !sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks)) return MPL_E_INVALID;
+    if (!x || !blocks || !schedule) return MPL_E_INVALID;
     if (!ws || ws_bytes < sm_stack_ws_bytes(M, D)) return MPL_E_WORKSPACE;
     (void)take_fault_injection();       // the one-shot test hook deserts a workgroup of a TEAM launch: an armed one must not outlive
                                         // this (unrelated) launch and hit the next team launch of the process
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
+    if (!sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks, cus)) return MPL_E_INVALID;
+    const int groups = sm_stack_groups(M, D, n_tok, cus);
     SmArgs a;
     a.x = x;
     a.xp = reinterpret_cast<float*>(ws);
@@ -536,11 +559,12 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     a.hidp = a.attp + (size_t)M * 2 * D;
     a.err_ws = reinterpret_cast<unsigned*>(a.hidp + (size_t)M * 4 * D);
     a.err_host = device_error_word(dev);
-    a.M = M; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
-    // every workgroup must be resident (grid barrier, ~150 KiB of LDS each: one per CU) and every column tile of the widest GEMM
-    // needs a workgroup of its own: a device with fewer CUs than that runs the team kernels instead
-    if (3 * D / 16 > cus) return MPL_E_UNSUPPORTED;
+    a.M = M; a.M0 = groups == 2 ? (n_seq + 1) / 2 * n_tok : M; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
+    // every workgroup must be resident (they poll each other's output; ~150 KiB of LDS each: one per CU) and every column tile of
+    // the widest GEMM of every group of sequences needs a workgroup of its own: a device with fewer CUs than that runs the team
+    // kernels instead
     a.n_wg = 3 * D / 16;
+    const int grid = groups * a.n_wg;                      // <= cus (sm_stack_groups)
     a.spin_log2 = spin_log2;
     a.eps = 1e-6f;      // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     for (int i = 0; i < MPL_MAX_APPS; ++i) a.sched[i] = i < n_apps ? schedule[i] : 0;
@@ -561,13 +585,12 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
         // workgroups that poll each other's output need grid <= resident workgroups.  The LDS footprint (~150 KiB of 160) allows ONE workgroup per CU
         // whatever the occupancy API says, so the API's known over-count of one block per CU at 81 .. 112 SGPRs (256-thread
         // blocks, MI355X_MICROARCH.md "Correctness boundaries"; these kernels spill ~340 SGPRs and sit in that bucket) cannot
-        // strand a workgroup here: per_cu is clamped to 1 and the grid (3 D / 16 <= cus, checked above) to per_cu x CUs
+        // strand a workgroup here: per_cu is clamped to 1 and the grid (<= cus, checked above) to per_cu x CUs
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, SM_NT, SM_LDS_BYTES) != hipSuccess || per_cu < 1)
             return MPL_E_UNSUPPORTED;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    if (a.n_wg > cus) return MPL_E_UNSUPPORTED;            // grid <= min(per_cu, 1) x CUs
     // tag 0 = "not of this launch": the pairs of an earlier launch on this workspace carry the same step numbers
     if (hipMemsetAsync(ws, 0, ((size_t)M * 14 * D + SM_TAIL_WORDS) * sizeof(float), s) != hipSuccess) return MPL_E_LAUNCH;
     // workgroups that wait for each other need the chip like the team kernels do: serialised with them per device (api.hip)
@@ -578,7 +601,7 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     int rc;
     {
         ProfScope prof(MPL_K_GEMM, s);
-        hipLaunchKernelGGL(kernel, dim3(a.n_wg), dim3(SM_NT), SM_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(SM_NT), SM_LDS_BYTES, s, a);
         rc = hip_check_launch();
     }
     if (hipEventRecord(ev, s) != hipSuccess) return MPL_E_LAUNCH;

@@ -150,9 +150,9 @@ def test_forward_matches_reference_golden(name):
     ref = torch.from_numpy(g["out"])
     mx, nw = _assert_close(out, ref, name)
     print("%s: max-scaled %.2e norm-wise %.2e MPJPE-vs-ref %.3e" % (name, mx, nw, mpl_oracle.mpjpe(out.cpu(), ref)))
-    # fixtures of at most 16 token rows run the small-batch engine (sm_stack.hip) by default: the team kernels must reproduce
+    # fixtures of at most 32 token rows run the small-batch engine (sm_stack.hip) by default: the team kernels must reproduce
     # the same golden
-    if g["meta"]["batch"] * g["flags"]["num_views"] <= 16:
+    if g["meta"]["batch"] * g["flags"]["num_views"] <= 32:
         lib = cabi.load()
         try:
             cabi.check(lib.mpl_x3_stack_mode(8), "stack mode")
@@ -368,7 +368,7 @@ def test_poses_are_independent_bitwise(name, prec):
 
 
 def test_small_batches_follow_the_engine_contract():
-    """At most 16 token rows (B x V <= 16) the default ("auto") runs the small-batch engine -- exact fp32 MFMA, another fp32
+    """At most 32 token rows (B x V <= 32) the default ("auto") runs the small-batch engine -- exact fp32 MFMA, another fp32
     arithmetic than the team kernels: within rounding of them (<= 5e-6 max-scaled), NOT bit for bit.  set_small_batch_engine(False)
     keeps the team kernels for every size: then a pose carries the same bits alone, in a ragged last batch, in a shard of any world
     size and inside a batch of 1024 (VERDICT r4 Weak #7: the contract is explicit now, and ShardedLifter / DataParallel replicas
@@ -380,7 +380,7 @@ def test_small_batches_follow_the_engine_contract():
     with torch.no_grad():
         full = m(P, rays=R, centers=Cn)
         m.set_small_batch_engine(False)
-        for n in (1, 3, 4, 5, 9):                                       # 4 .. 36 token rows: across the 16-row boundary
+        for n in (1, 3, 4, 5, 8, 9):                                    # 4 .. 36 token rows: across the 16- and the 32-row boundary
             part = m(cut(P, 0, n), rays=cut(R, 0, n), centers=cut(Cn, 0, n))
             assert torch.equal(part, full[:n]), "team kernels: the first %d poses alone differ from the same poses in the batch" % n
         # batch 12 over two ranks (shards of 6 poses = 24 rows) and batch 37 over eight (4-5 poses): what ShardedLifter computes
@@ -390,12 +390,12 @@ def test_small_batches_follow_the_engine_contract():
                      for r in range(W)]
             assert torch.equal(whole, torch.cat(parts, 0)) and torch.equal(whole, full[:B])
         m.set_small_batch_engine("auto")
-        for n in (1, 3, 4):
+        for n in (1, 3, 4, 5, 8):                                       # one group of sequences (<= 16 rows) and two
             part = m(cut(P, 0, n), rays=cut(R, 0, n), centers=cut(Cn, 0, n))
             mx, nw = mpl_oracle.rel_errors(part.cpu(), full[:n].cpu())
             assert mx < 5e-6 and nw < 5e-6, (n, mx, nw)                 # the other fp32 engine: rounding apart, same result
-        part = m(cut(P, 0, 5), rays=cut(R, 0, 5), centers=cut(Cn, 0, 5))
-        assert torch.equal(part, full[:5])                              # 20 rows: the team kernels again
+        part = m(cut(P, 0, 9), rays=cut(R, 0, 9), centers=cut(Cn, 0, 9))
+        assert torch.equal(part, full[:9])                              # 36 rows: the team kernels again
     m.set_small_batch_engine(True)
     ShardedLifter(m)
     assert m._small_batch_engine is True        # wrapping leaves the caller's setting alone (the lifter applies False per call)
