@@ -1,4 +1,5 @@
-// Block stack for SMALL batches: at most 16 token rows (B V <= 16: a single frame, a few frames / persons).
+// Block stack for SMALL batches: at most 32 token rows (B V <= 32: a single frame, a few frames / persons), in one or two groups of
+// sequences of at most 16 rows.
 //
 // Reference ops (MPL/lib/models/multiview_mpl.py): the `for blk in self.blocks` loop :420-423 -- Block.forward :84-92
 // (x += proj(attn(qkv(norm1(x)))); x += fc2(gelu(fc1(norm2(x))))), Attention.forward :55-64, Mlp.forward :31-37.
@@ -7,7 +8,9 @@
 // workgroups: 4 (8) CUs stream all 120 MB of packed weights through their LDS-DMA path, 0.6-0.8 ms however few rows there are.
 // With so few rows the GEMMs are weight-streaming problems, and the MI355X shape of that is the WHOLE chip on every GEMM: a GEMM
 // of N output columns is N / 16 independent column tiles (102 for qkv at D = 544), one 512-thread workgroup each (all resident:
-// grid <= CU count).  Inside a workgroup:
+// grid <= CU count).  Rows of different sequences never meet (a GEMM treats rows independently, the attention stays inside a
+// sequence): with two sequences or more the launch is TWO such problems side by side, each on its own N / 16 workgroups with half
+// the sequences (2 x 102 workgroups at D = 544) -- a workgroup then polls and multiplies half the rows.  Inside a workgroup:
 //   * the 16 weight rows of its tile (the nn.Linear tensor in place: no packed copy) come by LDS-DMA straight into FRAGMENT
 //     order -- one 1-KiB piece per 16-deep k step, lane (j, kq) fetching W[n0 + j][16 u + 4 kq ..] -- and, because weights do
 //     not depend on anybody, the tile of the NEXT GEMM is requested as soon as the multiply-adds of this one are done: its
@@ -40,8 +43,9 @@
 // steps (67 -> 29 KB): 484 (it was not the instruction cache).  + eight waves and straight-line code over 5 / 9 k steps per wave
 // (steps beyond K: zeroed operands instead of branches): 301.  + no probe poll in front of the fragment loads: 289.  Measured and
 // not kept: the epilogue by wave 0 alone (the same); the attention of <= 4 rows inside the proj workgroups (a hand-off less, but
-// every proj workgroup polls all of q | k | v and walks all heads: 301); two row tiles (32 rows: 139 KB of pairs per workgroup
-// and step, 0.96-1.07 ms against 0.55-0.63 with barriers and 0.62-0.63 for the team kernels, which take 17-32 rows now).
+// every proj workgroup polls all of q | k | v and walks all heads: 301); two row tiles PER WORKGROUP (32 rows: 139 KB of pairs per
+// workgroup and step, 0.96-1.07 ms against 0.55-0.63 with barriers and 0.62-0.63 for the team kernels).  + two groups of sequences
+// on twice the workgroups: 17-32 rows 354-413 us per stack (V = 2 B = 12: 354, V = 4 B = 8: 388), 16 rows 375 -> 332, 8 rows 327 -> 313.
 // A step is now ~4.4 us: ~1.5 hand-off (write-through store -> fabric -> L1-bypassing load: the guide's all-to-all edge), ~1.0
 // LayerNorm (three workgroup barriers behind the slowest wave's arrival), ~0.6 multiply-adds (34 fp32 MFMAs per SIMD), ~0.6
 // epilogue + weight requests.
