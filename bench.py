@@ -538,7 +538,7 @@ def report(a, model, flags, batches, dev, world, value, ms_per_step, split, used
                     peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     arithmetic="native fp32 MFMA")
     if small:
-        # at most 32 token rows: 2-4 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
+        # up to 80 token rows: 2-4 FLOP per weight byte-quarter -- the launch streams every fp32 weight of the stack once (L2 / HBM)
         # and is bounded by that and by its 65 all-to-all hand-offs, not by the matrix pipe
         gbs = alg_bytes * gemms / launches / (avg_launch_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=gemm_kernel, instruction="v_mfma_f32_16x16x4_f32", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,

@@ -61,8 +61,8 @@ extern "C" {
 #define MPL_F_NO_FPT (1u << 9)          /* no_transformer_fpt */
 #define MPL_F_CONF_IN_FPT (1u << 10)    /* confidence_in_FPT */
 #define MPL_F_KPTOK (1u << 11)          /* FPT_blocks_view_keypoint_tokens: FPT blocks of width d over 17*V tokens */
-/* not a constructor kwarg: engine selection of the FPT block stack.  Stacks of at most 32 token rows (a single frame, a few
- * persons; two groups of sequences of at most 16 rows) normally run the small-batch engine (csrc/sm_stack.hip: exact fp32 MFMA, the whole chip per GEMM), larger ones the
+/* not a constructor kwarg: engine selection of the FPT block stack.  Stacks of up to 80 token rows (a single frame, a few
+ * persons; groups of sequences of at most 16 rows, as many as the compute units hold) normally run the small-batch engine (csrc/sm_stack.hip: exact fp32 MFMA, the whole chip per GEMM), larger ones the
  * team kernels (fp16x2 operands): two fp32 engines that agree to ~1e-7 but not bit for bit.  With this flag the team kernels
  * run for EVERY batch size, so that a pose carries the same bits whatever batch or shard it arrives in. */
 #define MPL_F_NO_SMALL_STACK (1u << 12)
@@ -219,7 +219,7 @@ int mpl_x3_debug_buffer(void *device_buffer);
  * deterministic).  Bits 1-2: 0 = the stack picks its stage by the shape of the launch (fp16x2: teams that own two or more row
  * tiles walk PAIRS of tiles, h2_stack2_kernel; bf16: always one tile at a time), 1 / 2 = force the one- / two-tile stage
  * (bitwise the same poses; bf16: h2_stackp_kernel, pairs in every phase).  Bit 3: no
- * small-batch engine (sm_stack.hip: stacks of at most 32 token rows run every GEMM on the whole chip, the activations handed
+ * small-batch engine (sm_stack.hip: stacks of up to 80 token rows run every GEMM on the whole chip, the activations handed
  * over as {value, tag} pairs, exact fp32 MFMA on the nn.Linear tensors in place; two fp32 engines, <= 1e-6 apart).  Bit 4: the 16-row teams in
  * the ring form (h2_stackn_kernel) instead of the direct-W form (h2_stackd_kernel).  Bits 5-6: row-narrow teams: 0 = by the
  * shape of the launch, 1 = never, 2 / 3 = 32- / 16-row workgroups wherever legal.  Bit 7: write-through hand-off stores also
@@ -234,7 +234,7 @@ int mpl_x3_stack_mode(int one_launch_per_gemm);
  * (the query assumes they are there).  Negative = MPL_E_*.  Every team form yields bitwise the same poses. */
 enum {
     MPL_FORM_UNPACKED = 0,        /* no packed operands: one launch per GEMM on the fp32-MFMA engine (ln_gemm.hip / the D = 32 path) */
-    MPL_FORM_SMALL = 1,           /* sm_stack_kernel: at most 32 token rows, every GEMM on the whole chip */
+    MPL_FORM_SMALL = 1,           /* sm_stack_kernel: up to 80 token rows, every GEMM on the whole chip */
     MPL_FORM_TEAMS = 2,           /* h2_stack_kernel<NP>: one 64-row tile per team step */
     MPL_FORM_PAIRS = 3,           /* h2_stack2_kernel<2> (A/B: h2_stackp_kernel<1>): pairs of row tiles */
     MPL_FORM_ROWS32 = 4,          /* h2_stackn_kernel<2>: 32-row teams */

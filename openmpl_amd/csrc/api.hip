@@ -305,7 +305,7 @@ int block_stack_impl(float* x, int n_seq, int n_tok, int D, int H, const mpl_blo
     if (n_apps == 0) return MPL_OK;
     if (!blocks || !schedule) return MPL_E_INVALID;
     const int np0 = stack_packed_parts(blocks, schedule, n_apps, n_tok, D, H);
-    // at most 32 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
+    // up to 80 token rows (a single frame, a few frames): the whole chip on every GEMM instead of one team of D / 136
     // workgroups (sm_stack.hip) -- for the fp32 engines; an explicit bf16 request keeps its engine
     // (not when the caller asked for batch-invariant bits -- MPL_F_NO_SMALL_STACK --, nor under the A/B switches of the team
     // kernels: one launch per GEMM, stop after n phases).  ONE predicate decides (small_engine_taken): this function launches

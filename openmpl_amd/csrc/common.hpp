@@ -242,7 +242,7 @@ int launch_b1_qkv_attention(const unsigned short* x16, const unsigned short* W1,
 int launch_b1_stack(float* x, unsigned short* x16, int M, int D, int n_tok, int heads, const unsigned short* const* ops, int n_apps,
                     unsigned short* att1, unsigned short* hid1, float* stats, unsigned* counters, float eps, int stop_after,
                     hipStream_t s);
-// Block stack for at most 32 token rows (sm_stack.hip; beyond one sequence: two groups of sequences of at most 16 rows): every GEMM on the whole chip (one 16-column tile per workgroup, weights
+// Block stack for up to 80 token rows (sm_stack.hip; beyond one sequence: groups of sequences of at most 16 rows side by side): every GEMM on the whole chip (one 16-column tile per workgroup, weights
 // read in place), activations handed over as {value, tag} pairs, exact fp32 on the matrix cores
 bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks, int cus);      // cus: every workgroup must be resident
 bool sm_stack_enabled();

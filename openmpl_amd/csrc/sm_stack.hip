@@ -1,5 +1,5 @@
-// Block stack for SMALL batches: at most 32 token rows (B V <= 32: a single frame, a few frames / persons), in one or two groups of
-// sequences of at most 16 rows.
+// Block stack for SMALL batches: up to 80 token rows (a single frame, a few frames / persons), in groups of sequences of at most
+// 16 rows that run side by side.
 //
 // Reference ops (MPL/lib/models/multiview_mpl.py): the `for blk in self.blocks` loop :420-423 -- Block.forward :84-92
 // (x += proj(attn(qkv(norm1(x)))); x += fc2(gelu(fc1(norm2(x))))), Attention.forward :55-64, Mlp.forward :31-37.
@@ -9,8 +9,9 @@
 // With so few rows the GEMMs are weight-streaming problems, and the MI355X shape of that is the WHOLE chip on every GEMM: a GEMM
 // of N output columns is N / 16 independent column tiles (102 for qkv at D = 544), one 512-thread workgroup each (all resident:
 // grid <= CU count).  Rows of different sequences never meet (a GEMM treats rows independently, the attention stays inside a
-// sequence): with two sequences or more the launch is TWO such problems side by side, each on its own N / 16 workgroups with half
-// the sequences (2 x 102 workgroups at D = 544) -- a workgroup then polls and multiplies half the rows.  Inside a workgroup:
+// sequence): with two sequences or more the launch is SEVERAL such problems side by side, each group of sequences on its own
+// workgroups (sm_stack_groups: 2 x 102 workgroups up to 32 rows at D = 544; 3-5 x 51 with two column tiles per workgroup up to 80
+// rows) -- a workgroup then polls and multiplies a fraction of the rows.  Inside a workgroup:
 //   * the 16 weight rows of its tile (the nn.Linear tensor in place: no packed copy) come by LDS-DMA straight into FRAGMENT
 //     order -- one 1-KiB piece per 16-deep k step, lane (j, kq) fetching W[n0 + j][16 u + 4 kq ..] -- and, because weights do
 //     not depend on anybody, the tile of the NEXT GEMM is requested as soon as the multiply-adds of this one are done: its
@@ -45,7 +46,8 @@
 // not kept: the epilogue by wave 0 alone (the same); the attention of <= 4 rows inside the proj workgroups (a hand-off less, but
 // every proj workgroup polls all of q | k | v and walks all heads: 301); two row tiles PER WORKGROUP (32 rows: 139 KB of pairs per
 // workgroup and step, 0.96-1.07 ms against 0.55-0.63 with barriers and 0.62-0.63 for the team kernels).  + two groups of sequences
-// on twice the workgroups: 17-32 rows 354-413 us per stack (V = 2 B = 12: 354, V = 4 B = 8: 388), 16 rows 375 -> 332, 8 rows 327 -> 313.
+// on twice the workgroups: 17-32 rows 354-413 us per stack (V = 2 B = 12: 354, V = 4 B = 8: 388), 16 rows 375 -> 332, 8 rows 327 -> 313;
+// + three to five groups of 51 workgroups with two column tiles each: 33-80 rows 386-447 us (the team kernels: 616-640).
 // A step is now ~4.4 us: ~1.5 hand-off (write-through store -> fabric -> L1-bypassing load: the guide's all-to-all edge), ~1.0
 // LayerNorm (three workgroup barriers behind the slowest wave's arrival), ~0.6 multiply-adds (34 fp32 MFMAs per SIMD), ~0.6
 // epilogue + weight requests.
@@ -80,9 +82,9 @@ constexpr int SM_TILE_ROWS = 16; // ONE 16-row MFMA tile of token rows per workg
                                  // workgroups of a GEMM reads ALL of A past its L1, and as pairs that is 139 KB per workgroup and step at 32 rows -- two
                                  // tiles per workgroup: 0.96-1.07 ms per stack in this form, 0.55-0.63 with the grid barriers of rounds 4-5, 0.62-0.63
                                  // for the team kernels; four tiles 0.90-0.93 (round 4).
-constexpr int SM_MAX_ROWS = 2 * SM_TILE_ROWS;      // 17 .. 32 rows: TWO independent groups of sequences (rows of different sequences never meet: a GEMM
-                                 // treats rows independently, the attention stays inside a sequence), each on its own N / 16 workgroups -- the
-                                 // launch of a 16-row problem twice, side by side (2 x 102 workgroups at D = 544)
+constexpr int SM_MAX_ROWS = 6 * SM_TILE_ROWS;      // more rows: GROUPS of sequences of at most 16 rows, side by side (rows of different sequences never meet: a
+                                 // GEMM treats rows independently, the attention stays inside a sequence), each group on its own workgroups --
+                                 // the launch of a 16-row problem several times on disjoint compute units (sm_stack_groups)
 constexpr int SM_MAX_TOK = 16;
 constexpr int SM_NW = 8;         // waves per workgroup: they split K (two per SIMD: each hides the other's LDS / memory latencies)
 constexpr int SM_NT = 64 * SM_NW;
@@ -100,24 +102,43 @@ struct SmArgs {
     float *x;                           // [M][D] plain fp32: input of the stack, and its output (written by the last fc2 step)
     float *xp, *qkvp, *attp, *hidp;     // {value, tag} pairs: [M][D], [M][3 D], [M][D], [M][2 D]
     unsigned *err_ws, *err_host;
-    int M, M0, D, n_tok, H, n_apps, n_wg, spin_log2;      // M0: rows of the first group (= M: one group); n_wg: workgroups per group
+    int M, M0, D, n_tok, H, n_apps, n_wg, spin_log2;      // M0: rows of a (full) group of sequences; n_wg: workgroups per group
     float eps;
     unsigned char sched[MPL_MAX_APPS];
     SmBlock blk[SM_MAX_BLOCKS];
 };
 
-// Groups of sequences of a launch: two (the first takes the first half of the sequences, rounded up) whenever there are two
-// sequences or more and the device has the compute units for twice the workgroups -- also below 17 rows: a workgroup then polls and
-// multiplies half the rows (V = 2: 16 rows 375 -> 332 us per stack, 8 rows 327 -> 313, same box); one group otherwise; 0 = not a
-// launch for this engine.
-int sm_stack_groups(int M, int D, int n_tok, int cus) {
-    if (n_tok <= 0 || M <= 0 || M % n_tok) return 0;
-    const int n_seq = M / n_tok, wgs = 3 * D / 16;
-    if (n_seq >= 2 && 2 * wgs <= cus && (n_seq + 1) / 2 * n_tok <= SM_TILE_ROWS) return 2;
-    return M <= SM_TILE_ROWS && wgs <= cus ? 1 : 0;
+// Layout of a launch: groups of sequences (each of at most 16 rows, on *wpg workgroups of its own) -- 0 = not a launch for this
+// engine.  Up to two 16-row groups: one workgroup per column tile of the widest GEMM and group (3 D / 16 = 102 at D = 544), and TWO
+// groups whenever there are two sequences or more and the device has the compute units for them -- also below 17 rows: a
+// workgroup then polls and multiplies half the rows (V = 2: 16 rows 375 -> 332 us per stack, 8 rows 327 -> 313, same box).  More
+// rows (or a device too small for that): the two-tile layout, half as many workgroups per group, each owning the column tiles t and
+// t + wpg -- as many groups as there are sequences and compute units (D = 544: 51 workgroups per group, five groups = 80 rows on
+// 256 CUs); it needs the LDS for two qkv / fc1 weight tiles beside fc2's (256 D bytes: D <= 544).
+int sm_stack_groups(int M, int D, int n_tok, int cus, int* wpg_out, int* rows_out) {
+    if (n_tok <= 0 || n_tok > SM_TILE_ROWS || M <= 0 || M % n_tok || D % 16) return 0;
+    const int n_seq = M / n_tok, tiles = 3 * D / 16, fit = SM_TILE_ROWS / n_tok;      // fit: sequences in a 16-row group
+    const int g_min = (n_seq + fit - 1) / fit;
+    int g = 0, wpg = 0;
+    if (g_min <= 2 && (n_seq >= 2 ? 2 : 1) * tiles <= cus) {      // (the two-tile layout below 33 rows, measured: 16 rows 343 -> 389 us, 32 rows 393 -> 384)
+        g = n_seq >= 2 ? 2 : 1;
+        wpg = tiles;
+    } else if (g_min == 1 && tiles <= cus) {
+        g = 1;
+        wpg = tiles;
+    } else {
+        const int half = (tiles + 1) / 2;
+        if (256 * D > SM_LDS_W || D / 16 > half || g_min * half > cus) return 0;
+        g = cus / half < n_seq ? cus / half : n_seq;
+        wpg = half;
+    }
+    const int spg = (n_seq + g - 1) / g;                  // sequences per group; the last group may hold fewer
+    if (wpg_out) *wpg_out = wpg;
+    if (rows_out) *rows_out = spg * n_tok;
+    return (n_seq + spg - 1) / spg;
 }
 bool sm_stack_ok(int M, int D, int n_tok, int H, int n_apps, int n_blocks, int cus) {
-    return D <= 16 * SM_NW * SM_NU_MAX && D >= 16 * SM_NW && M >= 1 && sm_stack_groups(M, D, n_tok, cus) > 0 && n_tok >= 1 && n_tok <= SM_MAX_TOK && M % n_tok == 0 && D % 16 == 0 && H > 0 && D % H == 0 &&
+    return D <= 16 * SM_NW * SM_NU_MAX && D >= 16 * SM_NW && M >= 1 && sm_stack_groups(M, D, n_tok, cus, nullptr, nullptr) > 0 && n_tok >= 1 && n_tok <= SM_MAX_TOK && M % n_tok == 0 && D % 16 == 0 && H > 0 && D % H == 0 &&
            ((D / H) & 3) == 0 && 16 * 2 * D * 4 <= SM_LDS_W && n_apps >= 1 && n_apps <= MPL_MAX_APPS && n_blocks >= 1 &&
            n_blocks <= SM_MAX_BLOCKS && n_tok * 3 * (D / H) * 4 <= 64 * D /* the q | k | v slice of a (sequence, head) in the first tile buffer */;
 }
@@ -159,18 +180,21 @@ __device__ __forceinline__ float sm_f(unsigned u) { return __builtin_bit_cast(fl
 // (LDS-typed: with a generic pointer to this word inside the poll loops the gfx950 backend of ROCm 7.2 stops with "Illegal instruction
 // detected: V_CMP_NE_U32_e32 0, $src_shared_base")
 typedef volatile __attribute__((address_space(3))) unsigned* sm_fail_t;
+// A workgroup owns `cnt` column tiles of a GEMM (0: none in this step; 2 in the two-tile layout of sm_stack_groups): columns
+// n0 + i dn .., weight buffers buf + i x 64 K bytes.
 struct SmTile {
     const float* W;
     int K, n0;
     unsigned buf;
-    bool on;
+    int cnt, dn;
 };
 // (lds_base: the LDS address of the dynamic shared array, taken once from the symbol itself)
 __device__ __forceinline__ void sm_request_w(unsigned lds_base, const SmTile& t, int wave, int li, int kq) {
-    if (!t.on) return;
-    const float* src = t.W + (size_t)(t.n0 + li) * t.K + 4 * kq;
-    const unsigned lds0 = lds_base + t.buf;
-    for (int u = wave; 16 * u < t.K; u += SM_NW) dma16(src + 16 * u, lds0 + (unsigned)(u * 1024));
+    for (int i = 0; i < t.cnt; ++i) {
+        const float* src = t.W + (size_t)(t.n0 + i * t.dn + li) * t.K + 4 * kq;
+        const unsigned lds0 = lds_base + t.buf + (unsigned)(i * 64 * t.K);
+        for (int u = wave; 16 * u < t.K; u += SM_NW) dma16(src + 16 * u, lds0 + (unsigned)(u * 1024));
+    }
 }
 
 __device__ __forceinline__ void sm_report_lost(const SmArgs& a, sm_fail_t s_fail) {
@@ -231,15 +255,18 @@ __device__ __forceinline__ bool sm_tile(int EPI, bool LN, const SmArgs& a, char*
                                         int wave, int lane, sm_fail_t s_fail, int dbg_step = 0) {
     const int li = lane & 15, kq = lane >> 4;
     const int K = cur.K;
-    const bool active = cur.on;
+    const bool active = cur.cnt > 0;
     SM_STAMP(0);
     float* xch = reinterpret_cast<float*>(smem + SM_LDS_X);          // [SM_NW waves][256]
     float* red = reinterpret_cast<float*>(smem + SM_LDS_RED);        // [sums | squares][SM_NW waves][16] LayerNorm partials
     const unsigned ao = (unsigned)((li < M ? li : M - 1) * lda + 4 * kq);
     const int n_go = (K / 16 + SM_NW * NU - 1) / (SM_NW * NU);      // 1 for every LayerNorm GEMM (sm_stack_ok)
-    float bn = 0.f;
-    if (wave < 4 && active) bn = bias[cur.n0 + li];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bn[2] = {0.f, 0.f};
+    if (wave < 4 && active) {
+        bn[0] = bias[cur.n0 + li];
+        if (cur.cnt > 1) bn[1] = bias[cur.n0 + cur.dn + li];
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     for (int go = 0; go < n_go; ++go) {
         const int i0 = go * NU;
         bool val[NU];                                                // step i of this go exists (16 u < K)
@@ -301,39 +328,48 @@ __device__ __forceinline__ bool sm_tile(int EPI, bool LN, const SmArgs& a, char*
 #pragma unroll
             for (int i = 0; i < NU; ++i) wv[i] = wf[(val[i] ? wave + SM_NW * (i0 + i) : wave) * 64];      // (a step that does not exist: A = 0 against a finite W)
 #pragma unroll
-            for (int i = 0; i < NU; ++i) acc = mfma16_k16(a4[i], wv[i], acc);
+            for (int i = 0; i < NU; ++i) acc[0] = mfma16_k16(a4[i], wv[i], acc[0]);
+            if (cur.cnt > 1) {                                           // the second column tile of this workgroup: the same A fragments
+#pragma unroll
+                for (int i = 0; i < NU; ++i) wv[i] = wf[4 * K + (val[i] ? wave + SM_NW * (i0 + i) : wave) * 64];      // + 64 K bytes
+#pragma unroll
+                for (int i = 0; i < NU; ++i) acc[1] = mfma16_k16(a4[i], wv[i], acc[1]);
+            }
         }
     }
-    // the K parts, added in a fixed order by the waves 0..3 -- which may still be reading the exchange area of the step in front of
-    // this one (no grid barrier separates the steps any more)
+    // the K parts, added in a fixed order by the waves 0..3 -- which may still be reading the exchange area of the step (or tile) in
+    // front of this one (no grid barrier separates the steps any more)
     SM_STAMP(4);
-    __syncthreads();
+    bool ok = true;
+    for (int ti = 0; ti < (cur.cnt > 1 ? 2 : 1); ++ti) {
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xch[wave * 256 + r * 64 + lane] = acc[r];
-    __syncthreads();                                                 // every wave is done with the tile in LDS, too
-    SM_STAMP(5);
-    const bool ok = *s_fail == 0u;
-    // the next weight tile: a wave stands in the issue of its pieces (the CU accepts a fragment-order piece per ~60 cycles): the
-    // waves 4.. now, the finishing waves behind their epilogue -- the output pairs are what the other workgroups wait for
-    if (wave >= 4) sm_request_w(lds_base, next, wave, li, kq);
-    if (wave < 4) {
-        if (active) {
+        for (int r = 0; r < 4; ++r) xch[wave * 256 + r * 64 + lane] = ti ? acc[1][r] : acc[0][r];
+        __syncthreads();                                             // every wave is done with the tile in LDS, too
+        if (ti == 0) {
+            SM_STAMP(5);
+            ok = *s_fail == 0u;
+            // the next weight tile: a wave stands in the issue of its pieces (the CU accepts a fragment-order piece per ~60 cycles): the
+            // waves 4.. now, the finishing waves behind their epilogue -- the output pairs are what the other workgroups wait for
+            if (wave >= 4) sm_request_w(lds_base, next, wave, li, kq);
+        }
+        if (wave < 4 && active) {
             const int m = 4 * kq + wave;                             // D[row = 4 kq + r][col = li], r = this wave
             const float* x0 = xch + wave * 64 + lane;
-            float v = (((x0[0] + x0[256]) + (x0[512] + x0[768])) + ((x0[1024] + x0[1280]) + (x0[1536] + x0[1792]))) + bn;
+            float v = (((x0[0] + x0[256]) + (x0[512] + x0[768])) + ((x0[1024] + x0[1280]) + (x0[1536] + x0[1792]))) + (ti ? bn[1] : bn[0]);
             if (EPI == SM_EPI_GELU) v = gelu_erf(v);
-            if (EPI == SM_EPI_RES) {
+            if (EPI == SM_EPI_RES) {                                 // (never two tiles: D / 16 column tiles <= workgroups per group)
                 v += rsd;
                 rsd = v;
             }
             if (m < M) {
-                const unsigned co = (unsigned)(m * ldc + cur.n0 + li);
+                const unsigned co = (unsigned)(m * ldc + cur.n0 + ti * cur.dn + li);
                 sm_stp(Cp, co, v, tout);
                 if (EPI == SM_EPI_RES && Cplain) Cplain[co] = v;
             }
         }
-        sm_request_w(lds_base, next, wave, li, kq);
     }
+    if (wave < 4) sm_request_w(lds_base, next, wave, li, kq);
     SM_STAMP(6);
     return ok;
 }
@@ -348,8 +384,8 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int D = a.D, G = a.n_wg;
     // the group of sequences this workgroup belongs to: its rows of x and of every pair buffer (the groups share nothing else)
-    const bool second = (int)blockIdx.x >= G;
-    const int M = second ? a.M - a.M0 : a.M0, r0 = second ? a.M0 : 0;
+    const int grp = (int)blockIdx.x / G, r0 = grp * a.M0;
+    const int M = a.M - r0 < a.M0 ? a.M - r0 : a.M0;
     float* const xg = a.x + (size_t)r0 * D;
     float* const xp = a.xp + (size_t)r0 * 2 * D;
     float* const qkvp = a.qkvp + (size_t)r0 * 6 * D;
@@ -370,16 +406,21 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
 #endif
     const int hd = D / a.H;
     const float scale = 1.0f / sqrtf((float)hd);
-    const int t = (int)blockIdx.x - (second ? G : 0);     // this workgroup's column tile in every GEMM that has that many
-    const bool has_qkv = t < 3 * D / 16, has_d = t < D / 16, has_fc1 = t < 2 * D / 16;
-    // Weight-tile buffers (a tile = 16 K 4 bytes: 64 D for K = D, 128 D for fc2): qkv and fc1 at 0, proj at 64 D, fc2 at 64 D when
-    // fc1's tile fits below it (192 D bytes in all: D = 544), else at 0 -- then fc2's tile is requested when fc1's multiply-adds
-    // are done and the next qkv tile when fc2's are (D = 1088).
-    const bool roomy = 192 * D <= SM_LDS_W;
-    const unsigned b_lo = 0, b_hi = 64 * D, b_fc2 = roomy ? 64 * D : 0;
-    const SmTile none{nullptr, 0, 0, 0, false};
+    const int t = (int)blockIdx.x - grp * G;              // this workgroup's column tiles in a GEMM of n tiles: t and, below 2 G workgroups
+                                                           // per widest GEMM (the two-tile layout of sm_stack_groups), t + G
+    auto owned = [&](int n_tiles) -> int { return t < n_tiles ? (t + G < n_tiles ? 2 : 1) : 0; };
+    const int c_qkv = owned(3 * D / 16), c_fc1 = owned(2 * D / 16), c_d = owned(D / 16);      // c_d <= 1: D / 16 <= G
+    const bool has_d = c_d > 0;
+    // Weight-tile buffers (a tile = 16 K 4 bytes: 64 D for K = D, 128 D for fc2): qkv and fc1 at 0 (one tile, or two in the two-tile
+    // layout), proj behind them, fc2 at proj's place when it fits (192 D bytes in all with one tile per workgroup, 256 D with two:
+    // D = 544), else at 0 -- then fc2's tile is requested when fc1's multiply-adds are done and the next qkv tile when fc2's are
+    // (D = 1088).
+    const unsigned b_lo = 0, b_hi = (3 * D / 16 > G ? 128 : 64) * D;
+    const bool roomy = b_hi + 128 * D <= (unsigned)SM_LDS_W;
+    const unsigned b_fc2 = roomy ? b_hi : 0;
+    const SmTile none{nullptr, 0, 0, 0, 0, 0};
     {
-        const SmTile first{a.blk[a.sched[0]].qkv_w, D, 16 * t, b_lo, has_qkv};
+        const SmTile first{a.blk[a.sched[0]].qkv_w, D, 16 * t, b_lo, c_qkv, 16 * G};
         sm_request_w(lds_base, first, wave, li, kq);
     }
     // step 0: x (plain fp32, written by the kernel in front of this launch) becomes pairs; the workgroup that owns 16 columns of x
@@ -408,9 +449,9 @@ __global__ __launch_bounds__(SM_NT) void sm_stack_kernel(const SmArgs a) {
         }
 #endif
         const unsigned tg = 2u + 5u * (unsigned)app;      // tags of this application's five steps: tg .. tg + 4
-        const SmTile t_qkv{b.qkv_w, D, 16 * t, b_lo, has_qkv}, t_proj{b.proj_w, D, 16 * t, b_hi, has_d}, t_fc1{b.fc1_w, D, 16 * t, b_lo, has_fc1},
-            t_fc2{b.fc2_w, 2 * D, 16 * t, b_fc2, has_d};
-        const SmTile t_nq{more ? a.blk[a.sched[app + 1]].qkv_w : nullptr, D, 16 * t, b_lo, more && has_qkv};
+        const SmTile t_qkv{b.qkv_w, D, 16 * t, b_lo, c_qkv, 16 * G}, t_proj{b.proj_w, D, 16 * t, b_hi, c_d, 0}, t_fc1{b.fc1_w, D, 16 * t, b_lo, c_fc1, 16 * G},
+            t_fc2{b.fc2_w, 2 * D, 16 * t, b_fc2, c_d, 0};
+        const SmTile t_nq{more ? a.blk[a.sched[app + 1]].qkv_w : nullptr, D, 16 * t, b_lo, more ? c_qkv : 0, 16 * G};
         // the five steps of Block.forward :84-92 as a LOOP with one call site of the tile code (see sm_tile: instruction cache)
 #pragma nounroll
         for (int ph = 0; ph < 5; ++ph) {
@@ -554,7 +595,8 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MPL_E_LAUNCH;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return MPL_E_LAUNCH;
     if (!sm_stack_ok(M, D, n_tok, H, n_apps, n_blocks, cus)) return MPL_E_INVALID;
-    const int groups = sm_stack_groups(M, D, n_tok, cus);
+    int wpg = 0, rows = 0;
+    const int groups = sm_stack_groups(M, D, n_tok, cus, &wpg, &rows);
     SmArgs a;
     a.x = x;
     a.xp = reinterpret_cast<float*>(ws);
@@ -563,12 +605,12 @@ int launch_sm_stack(float* x, int n_seq, int n_tok, int D, int H, const mpl_bloc
     a.hidp = a.attp + (size_t)M * 2 * D;
     a.err_ws = reinterpret_cast<unsigned*>(a.hidp + (size_t)M * 4 * D);
     a.err_host = device_error_word(dev);
-    a.M = M; a.M0 = groups == 2 ? (n_seq + 1) / 2 * n_tok : M; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
+    a.M = M; a.M0 = rows; a.D = D; a.n_tok = n_tok; a.H = H; a.n_apps = n_apps;
     // every workgroup must be resident (they poll each other's output; ~150 KiB of LDS each: one per CU) and every column tile of
     // the widest GEMM of every group of sequences needs a workgroup of its own: a device with fewer CUs than that runs the team
     // kernels instead
-    a.n_wg = 3 * D / 16;
-    const int grid = groups * a.n_wg;                      // <= cus (sm_stack_groups)
+    a.n_wg = wpg;
+    const int grid = groups * wpg;                         // <= cus (sm_stack_groups)
     a.spin_log2 = spin_log2;
     a.eps = 1e-6f;      // norm_layer = partial(nn.LayerNorm, eps=1e-6), multiview_mpl.py:139
     for (int i = 0; i < MPL_MAX_APPS; ++i) a.sched[i] = i < n_apps ? schedule[i] : 0;

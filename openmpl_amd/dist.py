@@ -152,7 +152,7 @@ class ShardedLifter:
         self.group = group
         self.gather = gather
         # a shard must equal the rows of the single-process result bit for bit, whatever the world size leaves of the batch: the
-        # small-batch engine (<= 32 token rows, another fp32 arithmetic: ~1e-7 apart) is therefore off DURING a sharded call
+        # small-batch engine (<= 80 token rows, another fp32 arithmetic: ~1e-7 apart) is therefore off DURING a sharded call
         # (MultiView_MPL.set_small_batch_engine; models wrapped in MultiView_MPL_G expose it through .features).  It is a
         # per-call override: the caller's own setting is restored afterwards, direct model(...) calls keep the engine they chose
         self._engine_owner = next((m for m in (getattr(model, "features", None), model)

@@ -742,10 +742,10 @@ class MultiView_MPL(nn.Module):
         return self
 
     def set_small_batch_engine(self, mode="auto"):
-        """Engine of the FPT block stack for at most 32 token rows (B x V <= 32: a single frame, a few persons), fp32 precision:
+        """Engine of the FPT block stack for up to 80 token rows (B x V <= 80 on 256 compute units: a single frame, a few persons), fp32 precision:
         True / "auto" -- the small-batch engine (csrc/sm_stack.hip: every GEMM on the whole chip, exact fp32 MFMA), 2x lower
         latency; False -- the team kernels of the large batches for EVERY batch size.  The two fp32 engines agree to ~1e-7 but
-        not bit for bit, so with "auto" a pose of a batch of <= 32 / V poses does not carry the bits it would carry inside a
+        not bit for bit, so with "auto" a pose of a batch of <= 80 / V poses does not carry the bits it would carry inside a
         larger batch.  Code that needs results independent of how a batch is split -- the last ragged batch of a validate()
         loop against a rerun, shards against the unsharded batch -- asks for False; openmpl_amd.dist.ShardedLifter and
         DataParallel replicas always run with False for that reason (a shard must equal the single-process result bitwise)."""

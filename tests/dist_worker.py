@@ -32,7 +32,7 @@ def main():
     detrng.fill_module_(m, seed=5)
     m = m.to(dev).eval()
     # the single-process reference of a sharded run is the batch-invariant arithmetic: ShardedLifter switches the small-batch
-    # engine (another fp32 arithmetic for <= 32 token rows) off, and so does the reference run
+    # engine (another fp32 arithmetic for <= 80 token rows) off, and so does the reference run
     m.set_small_batch_engine(False)
     batches = []
     for step in range(2):

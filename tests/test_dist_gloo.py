@@ -238,7 +238,7 @@ def test_single_rank_group_still_runs_the_collective():
 
 def test_sharded_lifter_asks_the_model_for_batch_invariant_bits():
     """A shard must equal the rows of the single-process result bit for bit whatever the world size leaves of the batch: the lifter
-    switches the model's small-batch engine (another fp32 arithmetic for <= 32 token rows) off -- on the model itself or, for the
+    switches the model's small-batch engine (another fp32 arithmetic for <= 80 token rows) off -- on the model itself or, for the
     cfg wrapper MultiView_MPL_G, on the model inside (.features) -- for the duration of ITS OWN calls only: the
     caller's setting is back afterwards, also when the forward raises, and merely wrapping a model changes nothing."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -53,7 +53,7 @@ def _run(backend, world, out, batch, gather="stream", one_gpu=False):
 @pytest.mark.parametrize("world", [1, 2])
 @pytest.mark.parametrize("batch,gather", [(64, "stream"), (37, "stream"), (12, "stream"), (5, "stream"), (64, "overlap"), (12, "overlap")])
 def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch, gather, world):
-    """batch 12 / 5 at V = 4: shards (and at world 1 the whole batch of 5) of at most 32 token rows -- the sizes at which the
+    """batch 12 / 5 at V = 4: shards (and at world 1 the whole batch of 5) of at most 80 token rows -- the sizes at which the
     small-batch engine would otherwise change the bits (ShardedLifter switches it off for its own calls).  Both places the
     collective can run: ordered into the compute stream (default) and on the process group's stream beside the next forward."""
     if torch.cuda.device_count() < world:
@@ -73,7 +73,7 @@ def test_sharded_lifter_rccl_matches_single_process_bitwise(tmp_path, batch, gat
 def test_two_ranks_on_one_gpu_match_single_process_bitwise(tmp_path, batch, gather):
     """No box of this build has two GPUs, so the world-2 RCCL leg above is skipped everywhere.  This leg runs the SAME rank code
     (tests/dist_worker.py: ShardedLifter, shard_inputs, lift_shard with both exchanges issued before the first wait, uneven shards,
-    shards of at most 32 token rows) with two ranks that SHARE the one GPU and exchange through gloo (device tensors staged through
+    shards of at most 80 token rows) with two ranks that SHARE the one GPU and exchange through gloo (device tensors staged through
     the host) -- everything but the RCCL transport: the HIP forward of each rank's shard, the shard arithmetic, the batch-invariant
     engine selection, the order of the gathered poses.  Bitwise the single-process result.  (Small launches: two processes on one
     GPU must not both want every compute unit for a persistent launch -- the single-tenant rule of INTEGRATION.md.)"""

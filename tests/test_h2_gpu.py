@@ -321,7 +321,7 @@ def test_row_narrow_teams_are_bitwise_the_whole_tile_teams(name, B):
     outs = {}
     try:
         for tag, bits in (("whole", 1 << 5), ("rows32", 2 << 5), ("rows16", 3 << 5), ("rows16ring", (3 << 5) | 16), ("auto", 0)):
-            cabi.check(lib.mpl_x3_stack_mode(bits | 8), "stack mode")           # bit 3: the team kernels also at <= 32 rows
+            cabi.check(lib.mpl_x3_stack_mode(bits | 8), "stack mode")           # bit 3: the team kernels also at <= 80 rows
             with torch.no_grad():
                 outs[tag] = m(P, rays=R, centers=Cn)
             torch.cuda.synchronize()
@@ -346,8 +346,10 @@ def test_the_library_reports_the_form_of_a_stack_launch():
     form = lambda B, V, parts=2, flags=0, D=544: lib.mpl_block_stack_form(B, V, D, 8, 13, parts, flags)
     try:
         cabi.check(lib.mpl_x3_stack_mode(0), "stack mode")
-        assert form(1, 2) == cabi.FORM_SMALL and form(8, 4) == cabi.FORM_SMALL           # <= 32 token rows (two groups of sequences of <= 16)
-        assert form(2, 12) == cabi.FORM_SMALL and form(3, 12) != cabi.FORM_SMALL          # 24 rows = 12 + 12; 36 rows: the team kernels
+        assert form(1, 2) == cabi.FORM_SMALL and form(8, 4) == cabi.FORM_SMALL           # one group of sequences; two groups of 16 rows
+        assert form(2, 12) == cabi.FORM_SMALL and form(3, 12) == cabi.FORM_SMALL          # 24 rows = 12 + 12; 36 rows = 3 groups, two column tiles per workgroup
+        assert form(32, 2) == cabi.FORM_SMALL and form(20, 4) == cabi.FORM_SMALL          # 64 / 80 rows: five groups of 51 workgroups
+        assert form(48, 2) != cabi.FORM_SMALL and form(8, 12) != cabi.FORM_SMALL          # six / eight groups do not fit 256 compute units: the team kernels
         assert form(1, 2, flags=cabi.F_NO_SMALL_STACK) == cabi.FORM_ROWS16_DIRECT         # batch-invariant bits: team kernels
         assert form(1, 2, parts=1) == cabi.FORM_TEAMS                                     # an explicit bf16 request keeps its engine
         assert form(256, 2) == cabi.FORM_ROWS16_DIRECT                                    # the shipped call shape: 8 tiles x 4 sub-tiles x 4
@@ -442,10 +444,12 @@ def test_two_tile_stage_is_bitwise_the_one_tile_stage(name, B):
                                     ("chosen_v2_b1_l12", 3), ("full_v4_b8_l2", 4), ("full_v2_b1_l12", 2), ("chosen_v5_b19_l2", 1),
                                     ("chosen_v8_b4_l2", 1), ("chosen_v2_b1_l12", 5), ("chosen_v4_b8_l12", 8), ("chosen_v2_b1_l12", 13),
                                     ("chosen_v2_b1_l12", 16), ("chosen_v5_b19_l2", 6), ("chosen_v8_b4_l2", 4),
-                                    ("chosen_v8_b4_l2", 3)])
+                                    ("chosen_v8_b4_l2", 3), ("chosen_v2_b1_l12", 32), ("chosen_v4_b8_l12", 16), ("chosen_v5_b19_l2", 13),
+                                    ("chosen_v4_b8_l2", 9), ("chosen_v8_b4_l2", 5)])
 def test_small_batch_engine(name, B):
-    """At most 32 token rows (a single frame, a few frames / persons; beyond 16 rows as two independent groups of sequences of at most
-    16 rows each, side by side on twice the workgroups) run sm_stack.hip: every GEMM of the block stack on the whole chip
+    """Up to 80 token rows (a single frame, a few frames / persons; from two sequences on as independent groups of sequences of at most
+    16 rows each, side by side on disjoint workgroups: two groups of 102, or three to five of 51 with two column tiles each) run
+    sm_stack.hip: every GEMM of the block stack on the whole chip
     (one 16-column tile per workgroup, the nn.Linear weights read in place, exact fp32 on the matrix cores), the activations handed
     from step to step as {value, tag} pairs, instead of one team of D / 136 workgroups.  Checked against the fp64 oracle, against
     the team kernels on the same inputs (two fp32 engines: rounding noise apart), and for batch invariance inside the engine
@@ -454,7 +458,7 @@ def test_small_batch_engine(name, B):
     lib = cabi.load()
     m, g = _model(name)
     V = g["flags"]["num_views"]
-    assert B * V <= 32
+    assert B * V <= 80
     P, R, Cn = _big_inputs(B, V, 321)
     with torch.no_grad():
         out, k = _kinds(lambda: m(P, rays=R, centers=Cn))

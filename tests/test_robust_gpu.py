@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _team_kernels_only():
-    """The tests are about the fp16x2 team kernels: the small-batch engine (sm_stack.hip, exact fp32 MFMA, at most 32 token rows)
+    """The tests are about the fp16x2 team kernels: the small-batch engine (sm_stack.hip, exact fp32 MFMA, up to 80 token rows)
     is switched off for their duration, whatever the size of a fixture."""
     from openmpl_amd import cabi
     lib = cabi.load()

@@ -17,12 +17,13 @@ SHAPES = ((dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 1024),
                  (dict(num_views=8, depth=2, pose_3d_emb_learnable=True), 1000),       # 125 row tiles: pairs, the last one half empty
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True), 8190),       # four pairs per team, ragged last tile
                  (dict(num_views=5, depth=2, pose_3d_emb_learnable=True), 333),
-                 (dict(num_views=2, depth=12, pose_3d_emb_learnable=True), 1),         # <= 32 token rows: the small-batch engine (sm_stack.hip)
+                 (dict(num_views=2, depth=12, pose_3d_emb_learnable=True), 1),         # <= 80 token rows: the small-batch engine (sm_stack.hip)
                  (dict(num_views=4, depth=2, pose_3d_emb_learnable=True, confidence_input_as_third=True, input_rays_as_token=True,
                        multiple_spatial_blocks=True, add_3D_pos_encoding_to_rays=True), 4),
                  (dict(num_views=8, depth=12, pose_3d_emb_learnable=True), 2),
                  (dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 4),         # 16 rows: two groups of two sequences
                  (dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 8),         # 32 rows: two full row tiles, side by side
+                 (dict(num_views=4, depth=12, pose_3d_emb_learnable=True), 17),        # 68 rows: five groups of sequences, two column tiles per workgroup
                  (dict(num_views=3, depth=2, pose_3d_emb_learnable=True, confidence_as_attention_uncertainty_weight=True), 7),
                  (dict(num_views=6, depth=2, pose_3d_emb_learnable=True, FPT_blocks_view_keypoint_tokens=True), 100),
                  # row-narrow teams: 16-row workgroups in the direct-W form (h2_stackd_kernel), 32-row ones in the ring form
