@@ -482,13 +482,15 @@ def test_small_batch_engine(name, B):
     assert mx < 5e-6 and nw < 5e-6
 
 
-@pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 1), ("chosen_v4_b8_l12", 4), ("full_v2_b1_l12", 3)])
+@pytest.mark.parametrize("name,B", [("chosen_v2_b1_l12", 1), ("chosen_v4_b8_l12", 4), ("full_v2_b1_l12", 3), ("chosen_v2_b1_l12", 20),
+                                    ("chosen_v4_b8_l12", 20)])
 def test_small_batch_engine_hands_off_correctly_beside_other_work(name, B):
     """The steps of sm_stack.hip hand their activations over as {value, tag} pairs that the consumers poll -- no barrier, no fence.
     The guide's rule for such hand-offs: test them under UNEVEN load, not on an idle chip.  A second stream keeps the GPU busy with
     GEMMs of changing sizes (they take compute units away from the launch in bursts: workgroups of a step start late, finish at
     different times, lines are evicted between polls); every forward beside them must carry the bits of the quiet one, and no
-    hand-off may be reported lost."""
+    hand-off may be reported lost.  One group of sequences, two, and five groups with two column tiles per workgroup (40 / 80 rows:
+    255 of the 256 compute units in one launch)."""
     m, g = _model(name)
     V = g["flags"]["num_views"]
     P, R, Cn = _big_inputs(B, V, 11)
